@@ -1,0 +1,352 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (/root/reference) in this container.
+
+    python tests/golden/gen_golden.py            # writes the .npz files next to this script
+
+Only data (inputs + the reference's outputs) is written; no reference source travels.
+Inputs come from oracle/synth.py (our own seeded generators) so that the tests can
+rebuild the large ones (full-model weights, images) bit-identically on any box.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_import  # noqa: E402
+from oracle import synth  # noqa: E402
+
+torch.set_num_threads(8)
+ref_import.install()
+
+from radet.models import build_detector  # noqa: E402
+from radet.core.anchor import build_anchor_generator  # noqa: E402
+from radet.core.bbox import build_bbox_coder  # noqa: E402
+from radet.core import bbox_overlaps  # noqa: E402
+from radet.core.mask.structures import BitmapMasks  # noqa: E402
+from radet.datasets.pipelines.label_assignment import LabelAssignment  # noqa: E402
+from radet.models.losses.focal_loss import py_sigmoid_focal_loss  # noqa: E402
+from radet.ops import vote_nms, global_vote_nms, cluster_nms  # noqa: E402
+
+ANCHOR_CFG = dict(type="AnchorGenerator", ratios=[1.0], octave_base_scale=8, scales_per_octave=1,
+                  strides=[8, 16, 32, 64, 128])
+STRIDES = (8, 16, 32, 64, 128)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ----------------------------------------------------------------------------- anchors
+def gen_anchors():
+    ag = build_anchor_generator(ANCHOR_CFG)
+    out = {}
+    for tag, (h, w) in dict(a480x640=(480, 640), a800x800=(800, 800)).items():
+        sizes = [(int(np.ceil(h / s)), int(np.ceil(w / s))) for s in STRIDES]
+        anchors = ag.grid_anchors(sizes, device="cpu")
+        out[tag] = torch.cat(anchors).numpy()
+        out[tag + "_sizes"] = np.asarray(sizes, np.int64)
+    save("anchors", **out)
+
+
+# ----------------------------------------------------------------------------- assigner
+ASSIGN_CASES = [
+    # (tag, synth seed, G, tiny_visible, np seed)
+    ("g0", 1, 0, False, 5),
+    ("g1", 2, 1, False, 6),
+    ("g8", 0, 8, False, 123),
+    ("g8b", 7, 8, True, 124),
+    ("g20", 3, 20, False, 7),
+    ("g3", 11, 3, False, 125),
+]
+
+
+def run_ref_assigner(boxes, labels, masks, np_seed):
+    la = LabelAssignment(anchor_generator_cfg=ANCHOR_CFG, neg_threshold=0.2, positive_num=10,
+                         adapt_positive_num=False, balance_sample=True)
+    np.random.seed(np_seed)
+    res = dict(img_shape=(480, 640, 3), gt_bboxes=boxes, gt_labels=labels,
+               distance_maps=BitmapMasks([m for m in masks], 480, 640))
+    st0 = np.random.get_state()
+    res = la(res)
+    # how many uniforms were consumed: replay the stream until the state matches
+    probe = np.random.RandomState()
+    probe.set_state(st0)
+    st1 = np.random.get_state()
+    used = 0
+    while not (probe.get_state()[2] == st1[2] and np.array_equal(probe.get_state()[1], st1[1])):
+        probe.random_sample()
+        used += 1
+        assert used < 100000
+    return res["points_to_gt_index"], res["points_weight"], used
+
+
+def gen_assigner():
+    out = {}
+    for tag, sseed, G, tiny, npseed in ASSIGN_CASES:
+        boxes, labels, masks = synth.synth_objects(sseed, G, tiny_visible=tiny)
+        if G == 0:
+            p2g = np.full(6400, -1, np.int64)
+            w = np.ones(6400, np.float32)
+            used = 0
+            # the reference crashes on an empty gt list inside BitmapMasks/np.stack; the
+            # documented behaviour (no gts => all negative, weight 1) is what train uses.
+        else:
+            p2g, w, used = run_ref_assigner(boxes, labels, masks, npseed)
+        out[tag + "_boxes"] = boxes
+        out[tag + "_labels"] = labels
+        out[tag + "_masks"] = np.packbits(masks.reshape(G, -1), axis=1) if G else np.zeros((0, 38400), np.uint8)
+        out[tag + "_npseed"] = np.int64(npseed)
+        out[tag + "_p2g"] = p2g.astype(np.int16)
+        out[tag + "_w"] = w.astype(np.float32)
+        out[tag + "_used"] = np.int64(used)
+        print(tag, "pos", int((p2g > 0).sum()), "ign", int((p2g == 0).sum()), "sumw", float(w[p2g > 0].sum()),
+              "uniforms", used)
+    save("assigner", **out)
+    return out
+
+
+# ----------------------------------------------------------------------------- small ops
+def gen_ops():
+    g = torch.Generator().manual_seed(42)
+    coder = build_bbox_coder(dict(type="TBLRBBoxCoder", normalizer=1 / 8))
+    ag = build_anchor_generator(ANCHOR_CFG)
+    anchors = torch.cat(ag.grid_anchors([(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)], device="cpu"))
+    sel = torch.randint(0, 6400, (64,), generator=g)
+    pri = anchors[sel]
+    xy = torch.rand(64, 2, generator=g) * torch.tensor([400.0, 300.0])
+    wh = torch.rand(64, 2, generator=g) * 200 + 5
+    gts = torch.cat([xy, xy + wh], 1)
+    enc = coder.encode(pri, gts)
+    pred = torch.rand(64, 4, generator=g) * 6
+    dec = coder.decode(pri, pred)
+    dec_clip = coder.decode(pri, pred, max_shape=(480, 640, 3))
+    b1 = torch.cat([xy[:32], xy[:32] + wh[:32]], 1)
+    b2 = torch.cat([xy[32:] * 0.8, xy[32:] * 0.8 + wh[32:]], 1)
+    logits = torch.randn(96, 21, generator=g) * 2
+    lab = torch.randint(0, 22, (96,), generator=g)
+    t = torch.zeros(96, 21)
+    fg = lab < 21
+    t[fg.nonzero().reshape(-1), lab[fg]] = 1
+    focal = py_sigmoid_focal_loss(logits, t, reduction="none")
+    save("ops", priors=pri.numpy(), gts=gts.numpy(), enc=enc.numpy(), pred=pred.numpy(), dec=dec.numpy(),
+         dec_clip=dec_clip.numpy(), b1=b1.numpy(), b2=b2.numpy(),
+         iou_aligned=bbox_overlaps(b1, b2, is_aligned=True).numpy(),
+         giou_aligned=bbox_overlaps(b1, b2, mode="giou", is_aligned=True, eps=1e-6).numpy(),
+         iou_matrix=bbox_overlaps(b1, b2).numpy(),
+         giou_matrix=bbox_overlaps(b1, b2, mode="giou").numpy(),
+         logits=logits.numpy(), labels=lab.numpy(), focal=focal.numpy())
+
+
+# ----------------------------------------------------------------------------- raw NMS ops
+def synth_nms_boxes(seed, n_base, per, n_labels=21):
+    g = torch.Generator().manual_seed(seed)
+    base_xy = torch.rand(n_base, 2, generator=g) * torch.tensor([500.0, 350.0])
+    base_wh = torch.rand(n_base, 2, generator=g) * 120 + 20
+    base = torch.cat([base_xy, base_xy + base_wh], 1)
+    base_lab = torch.randint(0, n_labels, (n_base,), generator=g)
+    boxes = base.repeat_interleave(per, 0) + torch.randn(n_base * per, 4, generator=g) * 4.0
+    labels = base_lab.repeat_interleave(per, 0)
+    cls = torch.rand(n_base * per, generator=g) * 0.9 + 0.05
+    ctr = torch.rand(n_base * per, generator=g) * 0.9 + 0.05
+    perm = torch.randperm(n_base * per, generator=g)
+    return boxes[perm].contiguous(), cls[perm].contiguous(), ctr[perm].contiguous(), labels[perm].contiguous()
+
+
+def nms_margin(boxes, labels, thr):
+    iou = bbox_overlaps(boxes, boxes)
+    same = labels[:, None] == labels[None, :]
+    d = (iou - thr).abs()[same]
+    return float(d.min())
+
+
+def gen_nms(test_cfg):
+    out = {}
+    for tag, seed, nb, per in [("a", 100, 60, 25), ("b", 101, 300, 5), ("c", 102, 8, 3)]:
+        while True:   # tie-free scores and no IoU within 2e-6 of the threshold (knife-edge guard)
+            boxes, cls, ctr, labels = synth_nms_boxes(seed, nb, per)
+            score = cls * ctr
+            if score.unique().numel() == score.numel() and nms_margin(boxes, labels, 0.65) > 2e-6:
+                break
+            seed += 1000
+        out[f"{tag}_seed"] = np.int64(seed)
+        vb, vl = vote_nms(boxes, cls, labels, test_cfg.nms, score_factor=ctr, max_num=0)
+        gb, gl = global_vote_nms(boxes, cls, labels, test_cfg.nms, score_factor=ctr, max_num=0)
+        ids, num = cluster_nms(boxes, score, labels, 0.65)
+        out.update({f"{tag}_boxes": boxes.numpy(), f"{tag}_cls": cls.numpy(), f"{tag}_ctr": ctr.numpy(),
+                    f"{tag}_labels": labels.numpy(), f"{tag}_vote_b": vb.numpy(), f"{tag}_vote_l": vl.numpy(),
+                    f"{tag}_gvote_b": gb.numpy(), f"{tag}_gvote_l": gl.numpy(),
+                    f"{tag}_cl_ids": ids.numpy(), f"{tag}_cl_num": num.numpy()})
+        print("nms", tag, boxes.shape[0], "->", vb.shape[0], gb.shape[0])
+    save("nms", **out)
+
+
+# ----------------------------------------------------------------------------- head loss / decode
+LEVEL_HW = [(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)]
+
+
+def synth_head_outputs(seed, B, cls_mean=-2.0):
+    """Flat, level-major head outputs -> lists of NCHW tensors (what the reference consumes)."""
+    g = torch.Generator().manual_seed(seed)
+    cls, reg, iou = [], [], []
+    for (h, w) in LEVEL_HW:
+        cls.append(torch.randn(B, 21, h, w, generator=g) * 1.5 + cls_mean)
+        reg.append(torch.relu(torch.randn(B, 4, h, w, generator=g) * 2.0 + 2.5))
+        iou.append(torch.randn(B, 1, h, w, generator=g))
+    return cls, reg, iou
+
+
+def flat(ts):
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts])
+
+
+def gen_head(det, assign):
+    head = det.bbox_head
+    B = 2
+    tags = ["g8", "g3"]
+    gt_b = [torch.from_numpy(assign[t + "_boxes"]) for t in tags]
+    gt_l = [torch.from_numpy(assign[t + "_labels"]) for t in tags]
+    p2g = [torch.from_numpy(assign[t + "_p2g"].astype(np.int64)) for t in tags]
+    pw = [torch.from_numpy(assign[t + "_w"]) for t in tags]
+    cls, reg, iou = synth_head_outputs(7, B)
+    for t in cls + reg + iou:
+        t.requires_grad_(True)
+    metas = synth.img_metas(B)
+    losses = head.loss(cls, reg, iou, gt_b, gt_l, p2g, pw, metas)
+    total = sum(losses.values())
+    total.backward()
+    # targets, flattened exactly like loss() does
+    anchor_list, _ = head.get_anchors([t.shape[-2:] for t in cls], metas, device="cpu")
+    labels, bbox_t, weights, _ = head.get_targets(anchors_list=anchor_list, bbox_preds=reg, cls_scores=cls,
+                                                 gt_bboxes_list=gt_b, gt_labels_list=gt_l,
+                                                 points_to_gt_index_list=p2g, points_weight_list=pw,
+                                                 image_metas=metas)
+    labels, bbox_t, weights = torch.cat(labels), torch.cat(bbox_t), torch.cat(weights)
+    pos = ((labels >= 0) & (labels < 21)).nonzero().reshape(-1)
+    g_cls, g_reg, g_iou = flat([t.grad for t in cls]), flat([t.grad for t in reg]), flat([t.grad for t in iou])
+    out = dict(loss_cls=losses["loss_cls"].detach().numpy(), loss_bbox=losses["loss_bbox"].detach().numpy(),
+               loss_iou=losses["loss_iou"].detach().numpy(),
+               labels=labels.numpy().astype(np.int16), bbox_targets_pos=bbox_t[pos].numpy(),
+               weights=weights.numpy(), pos=pos.numpy(),
+               g_cls_rows=g_cls[::7].numpy(), g_cls_sum=g_cls.double().sum().numpy(),
+               g_cls_abs=g_cls.double().abs().sum().numpy(),
+               g_cls_pos=g_cls[pos].numpy(),
+               g_reg_pos=g_reg[pos].numpy(), g_reg_abs=g_reg.double().abs().sum().numpy(),
+               g_iou_pos=g_iou[pos].numpy(), g_iou_abs=g_iou.double().abs().sum().numpy())
+    # empty-gt image pair: num_pos == 0 branch
+    cls0, reg0, iou0 = synth_head_outputs(8, B)
+    for t in cls0 + reg0 + iou0:
+        t.requires_grad_(True)
+    e_b = [torch.zeros(0, 4), torch.zeros(0, 4)]
+    e_l = [torch.zeros(0, dtype=torch.long)] * 2
+    e_p = [torch.full((6400,), -1, dtype=torch.long)] * 2
+    e_w = [torch.ones(6400)] * 2
+    l0 = head.loss(cls0, reg0, iou0, e_b, e_l, e_p, e_w, metas)
+    sum(l0.values()).backward()
+    out.update(e_loss_cls=l0["loss_cls"].detach().numpy(), e_loss_bbox=l0["loss_bbox"].detach().numpy(),
+               e_loss_iou=l0["loss_iou"].detach().numpy(),
+               e_g_cls_abs=flat([t.grad for t in cls0]).double().abs().sum().numpy(),
+               e_g_reg_abs=flat([t.grad for t in reg0]).double().abs().sum().numpy())
+    save("head_loss", **out)
+
+    # decode + NMS (inference) on synthetic head outputs with a healthy number of candidates
+    res = {}
+    for nms_type in ["vote", "global_vote"]:
+        cfg = ref_import.attrify(dict(head.test_cfg))
+        cfg["nms"] = ref_import.attrify(dict(cfg["nms"], type=nms_type))
+        with torch.no_grad():
+            cls1, reg1, iou1 = synth_head_outputs(9, B, cls_mean=-4.0)
+            dets = head.get_bboxes(cls1, reg1, iou1, metas, cfg=cfg, rescale=True)
+        for i, (db, dl) in enumerate(dets):
+            res[f"{nms_type}_{i}_b"] = db.numpy()
+            res[f"{nms_type}_{i}_l"] = dl.numpy()
+            print("get_bboxes", nms_type, i, db.shape)
+    # candidate statistics so the tests know the case is non-trivial
+    sc = flat(cls1).sigmoid()
+    res["n_candidates"] = np.int64((sc > 0.05).sum().item())
+    save("get_bboxes", **res)
+
+
+# ----------------------------------------------------------------------------- full model
+def gen_model(det, assign):
+    synth.fill_state_dict(det.state_dict(), seed=0)
+    det.train()
+    B = 2
+    img = synth.synth_images(0, B)
+    tags = ["g8", "g3"]
+    gt_b = [torch.from_numpy(assign[t + "_boxes"]) for t in tags]
+    gt_l = [torch.from_numpy(assign[t + "_labels"]) for t in tags]
+    p2g = [torch.from_numpy(assign[t + "_p2g"].astype(np.int64)) for t in tags]
+    pw = [torch.from_numpy(assign[t + "_w"]) for t in tags]
+    metas = synth.img_metas(B)
+    feats = det.extract_feat(img)
+    outs = det.bbox_head(feats)
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    c_feats = det.backbone(img)
+    for i, f in enumerate(c_feats):
+        idx = torch.randint(0, f.numel(), (256,), generator=g)
+        out[f"c{i + 2}_idx"] = idx.numpy()
+        out[f"c{i + 2}_val"] = f.detach().reshape(-1)[idx].numpy()
+        out[f"c{i + 2}_absmean"] = f.detach().double().abs().mean().numpy()
+    for i, f in enumerate(feats):
+        idx = torch.randint(0, f.numel(), (256,), generator=g)
+        out[f"p{i + 3}_idx"] = idx.numpy()
+        out[f"p{i + 3}_val"] = f.detach().reshape(-1)[idx].numpy()
+        out[f"p{i + 3}_absmean"] = f.detach().double().abs().mean().numpy()
+    for nm, ts in zip(["cls", "reg", "iou"], outs):
+        fl = flat(ts).detach()
+        idx = torch.randint(0, fl.numel(), (512,), generator=g)
+        out[f"{nm}_idx"] = idx.numpy()
+        out[f"{nm}_val"] = fl.reshape(-1)[idx].numpy()
+        out[f"{nm}_absmean"] = fl.double().abs().mean().numpy()
+    det.zero_grad()
+    losses = det(img=img, img_metas=metas, return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    loss, log_vars = det._parse_losses(losses)
+    loss.backward()
+    names, norms = [], []
+    for n, p in det.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(p.grad.double().norm().item())
+    out.update(loss_cls=losses["loss_cls"].detach().numpy(), loss_bbox=losses["loss_bbox"].detach().numpy(),
+               loss_iou=losses["loss_iou"].detach().numpy(), loss=loss.detach().numpy(),
+               grad_names=np.asarray(names), grad_norms=np.asarray(norms, np.float64),
+               total_grad_norm=np.float64(np.sqrt((np.asarray(norms) ** 2).sum())),
+               n_params=np.int64(sum(p.numel() for p in det.parameters())),
+               n_trainable=np.int64(sum(p.numel() for p in det.parameters() if p.requires_grad)))
+    print("model loss", {k: float(v) for k, v in losses.items()}, "gradnorm", out["total_grad_norm"])
+    # inference
+    det.eval()
+    with torch.no_grad():
+        results = det(img=[img], img_metas=[metas], return_loss=False, rescale=True)
+    for i, per_cls in enumerate(results):
+        dets = np.concatenate([np.concatenate([d, np.full((d.shape[0], 1), c, np.float32)], 1)
+                               for c, d in enumerate(per_cls)], 0)
+        out[f"det_{i}"] = dets
+        print("simple_test", i, dets.shape)
+    save("model", **out)
+
+
+def main():
+    torch.manual_seed(0)
+    model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
+    gen_anchors()
+    assign = gen_assigner()
+    gen_ops()
+    gen_nms(test_cfg)
+    det = build_detector(model_cfg, train_cfg=train_cfg, test_cfg=test_cfg)
+    synth.fill_state_dict(det.state_dict(), seed=0)
+    gen_head(det, assign)
+    gen_model(det, assign)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/* radet_hip.h -- C ABI of libradet_hip.so, the MI355X (gfx950) implementation of RADet's detector hot path.
+ *
+ * Every entry point: plain pointers (DEVICE memory unless stated "host"), sizes, and a `void* stream`
+ * (hipStream_t; NULL = default stream).  Stream-ordered, no allocation, no host synchronisation
+ * inside; workspaces are supplied by the caller.  Return value: 0 = ok, -1 = bad argument, -2 = launch
+ * failure.  Activations are NHWC fp32, several pyramid levels concatenated row-wise ("multi-level
+ * buffer"): level l holds B images of Ho_l x Wo_l pixels starting at row out_row_off_l.
+ *
+ * seg_desc (host): nseg x 6 ints {Hi, Wi, Ho, Wo, in_row_off, out_row_off} per level.
+ *
+ * Each function names the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef RADET_HIP_H
+#define RADET_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution stack: replaces torch.nn.Conv2d/BatchNorm2d(eval)/ReLU/residual-add behind
+ *      radet/models/backbones/resnet.py:260-299,622-637, necks/fpn.py:170-221,
+ *      dense_heads/atss_head.py:118-145 (cuDNN in the reference) ------------------------------- */
+
+/* One convolution's parameter bundle for the batched fold / unfold kernels (device pointers). */
+typedef struct RadetConvDesc {
+    const float* w;        /* [Cout][Cin][KH][KW]  parameter (OIHW, state-dict layout) */
+    const float* bias;     /* [Cout] conv bias or NULL */
+    const float* bn_gamma; /* [Cout] or NULL (no BN) */
+    const float* bn_beta;
+    const float* bn_mean;
+    const float* bn_var;
+    float* wf;             /* [Cout][KH*KW][Cin]   folded weights (OHWI) for forward */
+    float* wft;            /* [Cin][KH*KW][Cout]   transposed copy for dgrad, or NULL */
+    float* bias_f;         /* [Cout] folded bias (BN shift or conv bias or 0) */
+    const float* dwf_slabs;      /* [nsplit][Cout][KH*KW][Cin] wgrad partial slabs */
+    const float* dbias_partials; /* [nsplit][Cout] or NULL */
+    float* dw;             /* [Cout][Cin][KH][KW] gradient (OIHW) or NULL (frozen) */
+    float* dbias;          /* [Cout] or NULL */
+    float* dgamma;         /* [Cout] or NULL */
+    float* dbeta;          /* [Cout] or NULL */
+    int cout, cin, kh, kw;
+    int nsplit;
+    float eps;
+    int wft_ld;            /* row stride of wft's last dim (>= Cout; zero-padded K for small heads), 0 = Cout */
+    int wft_off;           /* column offset inside that padded row */
+} RadetConvDesc;
+
+/* Implicit-GEMM conv on MFMA. Forward: (so, sr, off, div) = (stride, 1, -pad, 1), w = wf.
+ * dgrad: x = dy, w = wft, Cin/Cout swapped, (so, sr, off, div) = (1, -1, pad, stride), segs swapped.
+ * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0. */
+int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
+                       float* y, int B, int Cin, int Cout, int KH, int KW, int so, int sr, int off, int div, int relu,
+                       const int* seg_desc, int nseg, int tile_override, void* stream);
+/* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[gather(m,tap),c];
+ * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits. */
+int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
+int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, int B, int Cin, int Cout,
+                       int ld_dy, int KH, int KW, int so, int sr, int off, int div, const int* seg_desc, int nseg,
+                       int S, void* stream);
+int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream);
+int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, void* stream);
+/* stem: 7x7/2 conv (3->64) + folded BN + ReLU, NCHW image in, NHWC out (resnet.py:558-570,627-629) */
+int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc, int B,
+                            int H, int W, void* stream);
+int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* resnet.py:570,630 */
+
+/* ---- GroupNorm(32, 256) + ReLU over a multi-level buffer (atss_head.py:32,60-76 via mmcv ConvModule) */
+int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg);
+int radet_gn_relu_fwd(const float* z, const float* gamma, const float* beta, float* y, float* stats /*[nseg*B][32][2]*/,
+                      float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,
+                      void* stream);
+int radet_gn_relu_bwd(const float* dy, const float* z, const float* stats, const float* gamma, const float* beta,
+                      float* dz, float* dgamma, float* dbeta, float* partial_ws, int B, int C, int groups, int relu,
+                      const int* seg_desc, int nseg, void* stream);
+
+/* ---- FPN top-down: dst += nearest_upsample(src) and its adjoint (fpn.py:182-191) */
+int radet_upsample_add(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
+int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
+/* ReLU backward for a junction with no producing GEMM: dx = (dy + addend?) * [act > 0]; n % 4 == 0 */
+int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream);
+int radet_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int radet_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream);
+
+/* ---- head loss: targets + sigmoid focal + GIoU + IoU-BCE, forward and gradients in one pass.
+ *      Replaces RADetHead.get_targets/_get_target_single/loss (dense_heads/radet_head.py:173-392),
+ *      TBLRBBoxCoder.encode/decode (core/bbox/coder/tblr_bbox_coder.py:71-172), bbox_overlaps aligned
+ *      (core/bbox/iou_calculators/iou2d_calculator.py:116-158), FocalLoss/GIoULoss/CrossEntropyLoss
+ *      (models/losses/{focal,iou,cross_entropy}_loss.py) and mmcv.ops.sigmoid_focal_loss.
+ *  Rows are level-major: level l rows [off_l, off_l + B*h_l*w_l), image-major inside, row-major pixels.
+ *  cls [R,C] logits; reg_u [R,4] = atss_reg output BEFORE Scale/ReLU; iou [R] logits; scales [nlvl].
+ *  gt_boxes [sumG,4], gt_labels i64 [sumG], gt_off i32 [B+1]; p2g i64 [B,N], pw f32 [B,N] (N = points/img).
+ *  level_desc (host): nlvl x 3 ints {h, w, stride}.  grad_scale: 3 device floats (upstream grads) or NULL.
+ *  Outputs: losses[3] = {loss_cls, loss_bbox, loss_iou}; dcls [R,dcls_ld]; dreg_u [R,dreg_ld]; diou [R,diou_ld]
+ *  (row strides let the gradients land in zero-padded buffers that the dgrad GEMM consumes directly; the
+ *  sparse dreg_u / diou rows of non-positive points are zero-filled here); dscales [nlvl];
+ *  optional dumps (may be NULL): labels_out i64 [R], bbox_targets_out [R,4].
+ *  ws: int32 workspace of radet_head_loss_ws_ints(R) ints. */
+int radet_head_loss_ws_ints(int R);
+int radet_head_loss(const float* cls, const float* reg_u, const float* iou, const float* scales,
+                    const float* gt_boxes, const int64_t* gt_labels, const int* gt_off, const int64_t* p2g,
+                    const float* pw, const int* level_desc, int nlvl, int B, int num_classes, float alpha,
+                    float gamma, float loss_bbox_weight, float giou_eps, const float* grad_scale, float* losses,
+                    float* dcls, int dcls_ld, float* dreg_u, int dreg_ld, float* diou, int diou_ld, float* dscales,
+                    int64_t* labels_out, float* bbox_targets_out, int* ws, void* stream);
+/* bbox_pred = relu(reg_u * scale_level) materialised for the module API (atss_head.py:143, radet_head.py:29) */
+int radet_scale_relu(const float* reg_u, const float* scales, float* out, const int* level_desc, int nlvl, int B,
+                     void* stream);
+
+/* ---- inference: threshold / per-level top-k / TBLR decode (radet_head.py:55-146, atss_head.py:325-387) */
+/* For each image b: candidates written to cand_* [B, cap] (cap = nlvl * nms_pre), count in cand_count[b].
+ * Per level: scores = sigmoid(cls) > score_thr, top nms_pre by score (ties: lower flat index first),
+ * boxes decoded with clamp to (img_h, img_w) and divided by scale_factor[b] (4 floats per image). */
+size_t radet_decode_ws_bytes(int B, int nlvl, int nms_pre);
+int radet_decode_candidates(const float* cls, const float* reg_u, const float* iou, const float* scales,
+                            const int* level_desc, int nlvl, int B, int num_classes, float score_thr, int nms_pre,
+                            const float* img_hw /*[B,2]*/, const float* scale_factor /*[B,4] or NULL*/,
+                            float* cand_boxes, float* cand_scores, float* cand_ctr, int64_t* cand_labels,
+                            int* cand_count, void* ws, void* stream);
+
+/* ---- NMS family (radet/ops/vote/vote_ext.cpp:70-353, radet/ops/cluster/cluster_ext.cpp:4-87,
+ *      mmcv.ops.batched_nms as used at radet_head.py:160). Batched over images: inputs [B, cap] with
+ *      counts[b] valid entries.  mode: 0 vote, 1 global_vote, 2 cluster (ids), 3 hard batched NMS.
+ *      Outputs (capacity max_out per image, heads in descending cluster score):
+ *        out_boxes [B,max_out,4], out_scores [B,max_out], out_labels i64 [B,max_out], out_count [B];
+ *      mode 2: instance_id i64 [B,cap], cluster_num i64 [B,cap]; mode 3: keep i64 [B,max_out] (input index).
+ *      ws: workspace of radet_nms_ws_bytes(B, cap) bytes. cap <= 8192. */
+size_t radet_nms_ws_bytes(int B, int cap);
+int radet_nms(const float* boxes, const float* cluster_scores, const float* vote_scores, const int64_t* labels,
+              const int* counts, int B, int cap, int mode, float iou_thr, int iou_enable, float sigma, int max_out,
+              float* out_boxes, float* out_scores, int64_t* out_labels, int* out_count, int64_t* aux0, int64_t* aux1,
+              void* ws, void* stream);
+
+/* ---- visibility-guided positive-sample assigner (radet/datasets/pipelines/label_assignment.py:57-201).
+ *      One image per workgroup.  masks u8 [sumG, H, W]; uniforms f64 [B, U] = the image's
+ *      RandomState.random_sample() stream; out p2g i64 [B,N], pw f32 [B,N], used i32 [B] (uniforms
+ *      consumed; -1 = stream exhausted, -2 = more than 256 gts).  ws: radet_assign_ws_bytes(B, N) bytes. */
+size_t radet_assign_ws_bytes(int B, int N);
+int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
+                        const double* uniforms, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
+                        int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw, int* used,
+                        void* ws, void* stream);
+
+/* ---- anchors (core/anchor/anchor_generator.py:206-271): [sum h*w, 4], centre (j*stride, i*stride), side 8*stride */
+int radet_grid_anchors(float* out, const int* level_desc, int nlvl, int octave_base_scale, void* stream);
+
+/* ---- optimiser step on flat arenas: global L2 grad-norm clip + AdamW (torch.optim.AdamW +
+ *      clip_grad_norm_ as driven by mmcv OptimizerHook; configs/base/default_runtime.py:1-19) */
+int radet_sqnorm_partials(const float* g, size_t n, float* partials, int npartials, void* stream);
+int radet_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float max_norm, float grad_div,
+                     const float* partials, int npartials, float* grad_norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of libradet_hip.so (the C ABI declared in include/radet_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the import
+of the compute path fails loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C radet_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradet_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+
+
+class RadetConvDesc(C.Structure):
+    """Mirror of `struct RadetConvDesc` (include/radet_hip.h)."""
+    _fields_ = [("w", _p), ("bias", _p), ("bn_gamma", _p), ("bn_beta", _p), ("bn_mean", _p), ("bn_var", _p),
+                ("wf", _p), ("wft", _p), ("bias_f", _p), ("dwf_slabs", _p), ("dbias_partials", _p),
+                ("dw", _p), ("dbias", _p), ("dgamma", _p), ("dbeta", _p),
+                ("cout", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("nsplit", _i), ("eps", _f),
+                ("wft_ld", _i), ("wft_off", _i)]
+
+
+# name -> (restype, argtypes); must list every function of include/radet_hip.h
+SIGNATURES = {
+    "radet_conv2d_igemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
+    "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "radet_fold_weights": (_i, [_p, _i, _p]),
+    "radet_unfold_grads": (_i, [_p, _i, _i, _p]),
+    "radet_stem_conv_bn_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "radet_maxpool3x3s2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "radet_gn_workspace_floats": (_i, [_i, _p, _i]),
+    "radet_gn_relu_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "radet_upsample_add": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_upsample_add_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_relu_bwd": (_i, [_p, _p, _p, _p, _sz, _p]),
+    "radet_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "radet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "radet_head_loss_ws_ints": (_i, [_i]),
+    "radet_head_loss": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _i, _p,
+                             _i, _p, _i, _p, _p, _p, _p, _p]),
+    "radet_scale_relu": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "radet_decode_ws_bytes": (_sz, [_i, _i, _i]),
+    "radet_decode_candidates": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "radet_nms_ws_bytes": (_sz, [_i, _i]),
+    "radet_nms": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "radet_assign_ws_bytes": (_sz, [_i, _i]),
+    "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_grid_anchors": (_i, [_p, _p, _i, _i, _p]),
+    "radet_sqnorm_partials": (_i, [_p, _sz, _p, _i, _p]),
+    "radet_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _i, _p, _p]),
+}
+
+_lib = None
+
+
+class RadetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises RadetHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RadetHipError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `make -C radet_amd/csrc` "
+            "(or __graft_entry__.build()). radet_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RadetHipError(f"libradet_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RadetHipError(f"{name} failed with code {rc} (-1 bad argument, -2 launch failure)")
+
+
+def call(name, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise RadetHipError(f"{name} failed with code {rc} (-1 bad argument, -2 launch failure)")

@@ -1,0 +1,486 @@
+// fp32 implicit-GEMM convolution on CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), NHWC.
+//
+//   forward / dgrad :  Y[m, n] = sum_{tap, c} X[gather(m, tap), c] * W[n, tap, c]   (+ fused epilogue)
+//   wgrad           :  dW[o, tap, c] = sum_{m in split} dY[m, o] * X[gather(m, tap), c]   (per-split slabs)
+//
+// m runs over the rows of a row-concatenated multi-level NHWC buffer (RadetSegs), so the five
+// pyramid levels that share the head's weights are ONE launch.  Replaces the cuDNN / torch conv
+// calls behind radet/models/backbones/resnet.py:260-299, necks/fpn.py:170-221 and
+// dense_heads/atss_head.py:118-145 of the reference.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 16 (one tap, 16 channels), LDS rows
+// padded to 20 floats so that the 16-byte fragment reads are bank-conflict free.  A lane (i = l&31,
+// h = l>>5) fetches 4 consecutive k for its row with one ds_read_b128 and feeds 4 MFMAs; the
+// K order inside a step is permuted (lower half-wave takes k 0-3 / 8-11, upper 4-7 / 12-15), which
+// is legal because A and B use the same permutation.  Global->LDS is register-staged and
+// double-buffered: one barrier per K step, next step's loads in flight under 8*TM*TN MFMAs.
+#include "common.h"
+
+struct ConvArgs {
+    const float* x;       // input rows [*, Cin]
+    const float* w;       // [Cout][KH*KW][Cin]
+    const float* bias;    // [Cout] or null
+    const float* addend;  // [M][Cout] or null (added before relu / mask)
+    const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
+    float* y;             // [M][Cout]
+    int M, Cin, Cout, KH, KW;
+    int so, sr, off, div;  // input coord = o*so + r*sr + off ; must divide by div ; then / div
+    int relu;
+    RadetSegs segs;
+};
+
+__device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
+    int l = 0;
+#pragma unroll
+    for (int i = 0; i < RADET_MAX_SEG - 1; ++i)
+        if (i < s.nseg - 1 && m >= s.s[i].row_end) l = i + 1;
+    return l;
+}
+
+struct PixCtx {  // decoded output pixel, ready for the per-tap gather
+    int by, bx;  // oy*so + off, ox*so + off
+    int Hi, Wi;  // Hi == 0 marks an out-of-range row
+    int base;    // input row of (n, 0, 0)
+};
+
+__device__ __forceinline__ PixCtx decode_pixel(const RadetSegs& segs, int m, int M, int so, int off) {
+    PixCtx p;
+    p.Hi = 0; p.Wi = 0; p.by = 0; p.bx = 0; p.base = 0;
+    if (m < M) {
+        const int l = find_seg(segs, m);
+        const RadetSeg& sg = segs.s[l];
+        const int local = m - sg.row_begin;
+        const int hw = sg.Ho * sg.Wo;
+        const int n = local / hw;
+        const int rem = local - n * hw;
+        const int oy = rem / sg.Wo;
+        const int ox = rem - oy * sg.Wo;
+        p.by = oy * so + off;
+        p.bx = ox * so + off;
+        p.Hi = sg.Hi;
+        p.Wi = sg.Wi;
+        p.base = sg.in_row_off + n * sg.Hi * sg.Wi;
+    }
+    return p;
+}
+
+// returns the input row index for (pixel, tap) or -1
+__device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr, int div) {
+    int iy = p.by + r * sr, ix = p.bx + q * sr;
+    if (div > 1) {
+        if ((iy % div) != 0 || (ix % div) != 0) return -1;
+        iy /= div;
+        ix /= div;
+    }
+    if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) return -1;
+    return p.base + iy * p.Wi + ix;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BK = 16, LD = 20;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_UNITS = (BM * 4) / 256;
+    constexpr int B_UNITS = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(A_UNITS >= 1, "BM >= 64");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesN = (a.Cout + BN - 1) / BN;
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
+    const int m0 = (id / tilesN) * BM;
+    const int n0 = (id % tilesN) * BN;
+
+    PixCtx pc[A_UNITS];
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) pc[u] = decode_pixel(a.segs, m0 + ((tid + u * 256) >> 2), a.M, a.so, a.off);
+    const int k4 = (tid & 3) * 4;
+
+    const int cpt = a.Cin / BK;  // channel chunks per tap
+    const int KT = a.KH * a.KW;
+    const int nK = KT * cpt;
+
+    float4 ra[A_UNITS], rb[B_UNITS];
+    auto load_stage = [&](int it) {
+        const int tap = it / cpt;
+        const int c0 = (it - tap * cpt) * BK;
+        const int r = tap / a.KW, q = tap - r * a.KW;
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const int row = gather_row(pc[u], r, q, a.sr, a.div);
+            ra[u] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (size_t)row * a.Cin + c0 + k4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            const int n = n0 + (unit >> 2);
+            const bool ok = (unit < BN * 4) && (n < a.Cout);
+            rb[u] = ok ? *reinterpret_cast<const float4*>(a.w + ((size_t)n * KT + tap) * a.Cin + c0 + k4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u)
+            *reinterpret_cast<float4*>(&As[buf][((tid + u * 256) >> 2) * LD + k4]) = ra[u];
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            if (unit < BN * 4) *reinterpret_cast<float4*>(&Bs[buf][(unit >> 2) * LD + k4]) = rb[u];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int a_row0 = (wm * TM * 32 + li) * LD + 4 * lh;
+    const int b_row0 = (wn * TN * 32 + li) * LD + 4 * lh;
+
+    for (int it = 0; it < nK; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nK) load_stage(it + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const float4*>(&As[buf][a_row0 + i * 32 * LD + 8 * s]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_row0 + j * 32 * LD + 8 * s]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (it + 1 < nK) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (col >= a.Cout) continue;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= a.M) continue;
+                const size_t o = (size_t)row * a.Cout + col;
+                float v = acc[i][j][r] + bv;
+                if (a.addend) v += a.addend[o];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+                a.y[o] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+    const float* dy;  // [M][Cout]
+    const float* x;   // input rows [*, Cin]
+    float* slabs;     // [S][Cout][KH*KW][Cin]
+    float* dbias_partials;  // [S][Cout] column sums of dy (bias / BN-shift gradient) or null
+    int M, Cin, Cout, KH, KW;
+    int ld_dy;        // row stride of dy (>= Cout; padded gradient buffers)
+    int so, sr, off, div;
+    int S;            // pixel splits
+    int chunks_per_split;  // 16-pixel chunks per split
+    RadetSegs segs;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int BP = 16;  // pixels per stage
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_UNITS = (BP * BM / 4 + 255) / 256;
+    constexpr int B_UNITS = (BP * BN / 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BP * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int KT = a.KH * a.KW;
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = (a.Cin + BN - 1) / BN;
+    const int tilesPerSplit = tilesO * KT * tilesC;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO;
+    id /= tilesO;
+    const int tc = id % tilesC;
+    const int tap = id / tilesC;
+    const int o0 = to * BM, c0 = tc * BN;
+    const int r = tap / a.KW, q = tap - r * a.KW;
+
+    const int p_begin = split * a.chunks_per_split * BP;
+    int p_end = p_begin + a.chunks_per_split * BP;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    float4 ra[A_UNITS], rb[B_UNITS];
+    float4 bsum[A_UNITS];
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) bsum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_stage = [&](int it) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            const int j = unit / (BM / 4), o = o0 + (unit % (BM / 4)) * 4;
+            const int m = p0 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (unit < BP * BM / 4 && m < p_end) {
+                const float* src = a.dy + (size_t)m * a.ld_dy + o;
+                if (o + 3 < a.Cout && (a.ld_dy & 3) == 0) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    if (o < a.Cout) v.x = src[0];
+                    if (o + 1 < a.Cout) v.y = src[1];
+                    if (o + 2 < a.Cout) v.z = src[2];
+                    if (o + 3 < a.Cout) v.w = src[3];
+                }
+            }
+            ra[u] = v;
+            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            const int j = unit / (BN / 4), c = c0 + (unit % (BN / 4)) * 4;
+            const int m = p0 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (unit < BP * BN / 4 && m < p_end && c < a.Cin) {
+                const PixCtx pc = decode_pixel(a.segs, m, a.M, a.so, a.off);
+                const int row = gather_row(pc, r, q, a.sr, a.div);
+                if (row >= 0) v = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.Cin + c);
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[buf][unit * 4]) = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            if (unit < BP * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = rb[u];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    if (nIt > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) load_stage(it + 1);
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nIt) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (a.dbias_partials && tap == 0 && tc == 0) {  // fused column sums of dy over this split's pixels
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const int unit = tid + u * 256;
+            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[0][unit * 4]) = bsum[u];
+        }
+        __syncthreads();
+        if (tid < BM && o0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < BP; ++j) t += As[0][j * BM + tid];
+            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
+        }
+    }
+
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + (wn * TN + j) * 32 + li;
+            if (c >= a.Cin) continue;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int o = o0 + (wm * TM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (o >= a.Cout) continue;
+                out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int out_is_o) {
+    // seg_desc: nseg x 6 ints: {Hi, Wi, Ho, Wo, in_row_off, out_row_off}; rows per level = B*Ho*Wo
+    if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
+    out->nseg = nseg;
+    for (int l = 0; l < nseg; ++l) {
+        const int* d = seg_desc + 6 * l;
+        RadetSeg& s = out->s[l];
+        s.Hi = d[0]; s.Wi = d[1]; s.Ho = d[2]; s.Wo = d[3];
+        s.in_row_off = d[4];
+        s.row_begin = d[5];
+        s.row_end = d[5] + B * d[2] * d[3];
+        if (l > 0 && s.row_begin != out->s[l - 1].row_end) return RADET_ERR_ARG;
+    }
+    (void)out_is_o;
+    return RADET_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_igemm(const ConvArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+}
+
+// efficiency model: wave quantisation over 256 CUs x tile padding waste x intrinsic tile efficiency
+static double tile_score(int M, int N, int bm, int bn, double intrinsic) {
+    const long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn;
+    const long blocks = tm * tn;
+    const double quant = (double)blocks / (256.0 * ((blocks + 255) / 256));
+    const double pad = ((double)M * N) / ((double)tm * bm * tn * bn);
+    return quant * pad * intrinsic;
+}
+
+extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend,
+                                  const float* mask, float* y, int B, int Cin, int Cout, int KH, int KW,
+                                  int so, int sr, int off, int div, int relu, const int* seg_desc, int nseg,
+                                  int tile_override, void* stream) {
+    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0) return RADET_ERR_ARG;
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.mask = mask; a.y = y;
+    a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
+    a.so = so; a.sr = sr; a.off = off; a.div = div; a.relu = relu;
+    int rc = fill_segs(&a.segs, seg_desc, nseg, B, 1);
+    if (rc) return rc;
+    a.M = a.segs.s[nseg - 1].row_end;
+    if (a.segs.s[0].row_begin != 0) return RADET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int choice = tile_override;
+    if (choice <= 0) {
+        if (Cout <= 32) choice = 4;
+        else {
+            const double s1 = tile_score(a.M, Cout, 128, 128, 1.00);
+            const double s2 = tile_score(a.M, Cout, 128, 64, 0.96);
+            const double s3 = tile_score(a.M, Cout, 64, 64, 0.90);
+            choice = 1;
+            double best = s1;
+            if (s2 > best) { best = s2; choice = 2; }
+            if (s3 > best) { best = s3; choice = 3; }
+        }
+    }
+    switch (choice) {
+        case 1: launch_igemm<128, 128, 2, 2>(a, st); break;
+        case 2: launch_igemm<128, 64, 2, 2>(a, st); break;
+        case 3: launch_igemm<64, 64, 2, 2>(a, st); break;
+        case 4: launch_igemm<128, 32, 4, 1>(a, st); break;
+        default: return RADET_ERR_ARG;
+    }
+    return radet_check_launch();
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+}
+
+static void wgrad_tile(int Cout, int Cin, int* bm, int* bn) {
+    if (Cout <= 32) { *bm = 32; *bn = 128; }
+    else if (Cout <= 64 || Cin <= 64) { *bm = 64; *bn = 64; }
+    else { *bm = 128; *bn = 128; }
+}
+
+// Number of pixel splits the wgrad launcher will use (callers size the slab buffer with it).
+extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW) {
+    int bm, bn;
+    wgrad_tile(Cout, Cin, &bm, &bn);
+    const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
+    const int chunks = (M + 15) / 16;
+    long S = (1024 + tiles - 1) / tiles;        // aim for >= 4 blocks per CU
+    const long maxS = (chunks + 7) / 8;          // at least 8 stages (128 pixels) per block
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    return (int)S;
+}
+
+extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, int B,
+                                  int Cin, int Cout, int ld_dy, int KH, int KW, int so, int sr, int off, int div,
+                                  const int* seg_desc, int nseg, int S, void* stream) {
+    if (Cin % 4 != 0 || S < 1 || ld_dy < Cout) return RADET_ERR_ARG;
+    WgradArgs a;
+    a.ld_dy = ld_dy;
+    a.dy = dy; a.x = x; a.slabs = slabs; a.dbias_partials = dbias_partials;
+    a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
+    a.so = so; a.sr = sr; a.off = off; a.div = div;
+    int rc = fill_segs(&a.segs, seg_desc, nseg, B, 1);
+    if (rc) return rc;
+    a.M = a.segs.s[nseg - 1].row_end;
+    a.S = S;
+    const int chunks = (a.M + 15) / 16;
+    a.chunks_per_split = (chunks + S - 1) / S;
+    hipStream_t st = (hipStream_t)stream;
+    int bm, bn;
+    wgrad_tile(Cout, Cin, &bm, &bn);
+    if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
+    else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
+    else launch_wgrad<128, 128, 2, 2>(a, st);
+    return radet_check_launch();
+}

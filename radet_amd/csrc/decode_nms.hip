@@ -1,0 +1,520 @@
+// Inference post-processing on the GPU (the reference copies candidates to the host and runs a
+// single-threaded C++ loop: radet_head.py:149-153, ops/vote/vote_ext.cpp).
+//
+//  radet_decode_candidates : per (level, image) workgroup: sigmoid > thr, exact top-k by 3-pass radix
+//                            select on the score bits, ordered wave-ballot compaction, TBLR decode + clamp.
+//  radet_nms               : per image workgroup (1024 threads): LDS bitonic sort on 64-bit keys
+//                            (label | score desc | index), per-label greedy clustering by one wavefront
+//                            each (64 IoUs per step, in the reference's fp32 operation order), second
+//                            sort of the cluster heads, then the score-weighted 1-sigma box vote with
+//                            strictly sequential fp32 sums (bit-exact w.r.t. vote_ext.cpp).
+//  Modes: 0 vote_nms, 1 global_vote_nms (vote_ext.cpp:70-353), 2 cluster_nms (cluster_ext.cpp:4-87),
+//         3 class-aware hard NMS with mmcv.ops.batched_nms semantics.
+#include "common.h"
+#include "../../include/radet_hip.h"
+
+struct DecLevels {
+    int n;
+    int h[RADET_MAX_SEG], w[RADET_MAX_SEG], stride[RADET_MAX_SEG];
+    int row_off[RADET_MAX_SEG + 1];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ordered compaction helper: returns the exclusive prefix of `flag` over the 1024-thread block and the total
+__device__ __forceinline__ int block_excl_scan_1024(int flag, int* s_wave, int& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long b = __ballot(flag);
+    const int within = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int v = s_wave[i];
+        if (i < wave) base += v;
+        tot += v;
+    }
+    total = tot;
+    return base + within;
+}
+
+__global__ __launch_bounds__(1024) void decode_kernel(const float* __restrict__ cls, const float* __restrict__ reg_u,
+                                                      const float* __restrict__ iou, const float* __restrict__ scales,
+                                                      const DecLevels L, int B, int C, float score_thr, int nms_pre,
+                                                      const float* __restrict__ img_hw,
+                                                      const float* __restrict__ scale_factor,
+                                                      float* __restrict__ lv_boxes, float* __restrict__ lv_scores,
+                                                      float* __restrict__ lv_ctr, int64_t* __restrict__ lv_labels,
+                                                      int* __restrict__ lv_count) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int hw = L.h[l] * L.w[l];
+    const int r0 = L.row_off[l] + b * hw;
+    const int total = hw * C;
+    const float* s_in = cls + (size_t)r0 * C;
+    __shared__ int hist[2048];
+    __shared__ int s_wave[16];
+    __shared__ int s_sel[4];
+
+    // ---- count candidates
+    int cnt = 0;
+    for (int i = tid; i < total; i += 1024) cnt += sigmoidf_(s_in[i]) > score_thr ? 1 : 0;
+    int tot;
+    {
+        // reuse the scan helper for a block sum
+        __syncthreads();
+        int c = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0) s_wave[tid >> 6] = c;
+        __syncthreads();
+        tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += s_wave[i];
+        __syncthreads();
+    }
+    const int k = tot < nms_pre ? tot : nms_pre;
+    // ---- exact k-th largest score by radix select on the (positive) float bits
+    unsigned thr_bits = 0u;   // select bits > thr_bits, plus the first `need_eq` with bits == thr_bits
+    int need_eq = 0;
+    if (tot > nms_pre) {
+        unsigned prefix = 0u, pmask = 0u;
+        int remaining = k;
+        const int shifts[3] = {21, 10, 0};
+        const int widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const int sh = shifts[pass];
+            const unsigned bm = (1u << widths[pass]) - 1u;
+            for (int i = tid; i < total; i += 1024) {
+                const float s = sigmoidf_(s_in[i]);
+                if (s > score_thr) {
+                    const unsigned u = __float_as_uint(s);
+                    if ((u & pmask) == prefix) atomicAdd(&hist[(u >> sh) & bm], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0, bin = (int)bm;
+                for (; bin >= 0; --bin) {
+                    if (acc + hist[bin] >= remaining) break;
+                    acc += hist[bin];
+                }
+                s_sel[0] = bin;
+                s_sel[1] = remaining - acc;
+            }
+            __syncthreads();
+            prefix |= ((unsigned)s_sel[0]) << sh;
+            pmask |= bm << sh;
+            remaining = s_sel[1];
+            __syncthreads();
+        }
+        thr_bits = prefix;
+        need_eq = remaining;
+    }
+    // ---- ordered compaction + decode
+    const float stride = (float)L.stride[l];
+    const float sc = scales[l];
+    const float H = img_hw[b * 2 + 0], W = img_hw[b * 2 + 1];
+    const size_t obase = ((size_t)b * L.n + l) * nms_pre;
+    int written = 0, eq_taken = 0;
+    for (int c0 = 0; c0 < total; c0 += 1024) {
+        const int i = c0 + tid;
+        float s = 0.f;
+        int sel = 0, is_eq = 0;
+        if (i < total) {
+            s = sigmoidf_(s_in[i]);
+            if (s > score_thr) {
+                if (tot <= nms_pre) sel = 1;
+                else {
+                    const unsigned u = __float_as_uint(s);
+                    if (u > thr_bits) sel = 1;
+                    else if (u == thr_bits) is_eq = 1;
+                }
+            }
+        }
+        if (tot > nms_pre) {
+            int teq;
+            const int eq_rank = block_excl_scan_1024(is_eq, s_wave, teq);
+            if (is_eq && eq_taken + eq_rank < need_eq) sel = 1;
+            eq_taken += teq;
+        }
+        int tsel;
+        const int pos = block_excl_scan_1024(sel, s_wave, tsel);
+        if (sel) {
+            const int pt = i / C, c = i - pt * C;
+            const int iy = pt / L.w[l], ix = pt - iy * L.w[l];
+            const float cx = (float)(ix * L.stride[l]), cy = (float)(iy * L.stride[l]);
+            const float4 u4 = *reinterpret_cast<const float4*>(reg_u + (size_t)(r0 + pt) * 4);
+            const float hw8 = 8.f * stride;
+            const float top = fmaxf(u4.x * sc, 0.f) * 0.125f * hw8, bottom = fmaxf(u4.y * sc, 0.f) * 0.125f * hw8;
+            const float left = fmaxf(u4.z * sc, 0.f) * 0.125f * hw8, right = fmaxf(u4.w * sc, 0.f) * 0.125f * hw8;
+            float x1 = cx - left, y1 = cy - top, x2 = cx + right, y2 = cy + bottom;
+            x1 = fminf(fmaxf(x1, 0.f), W); x2 = fminf(fmaxf(x2, 0.f), W);
+            y1 = fminf(fmaxf(y1, 0.f), H); y2 = fminf(fmaxf(y2, 0.f), H);
+            if (scale_factor) {
+                x1 /= scale_factor[b * 4 + 0]; y1 /= scale_factor[b * 4 + 1];
+                x2 /= scale_factor[b * 4 + 2]; y2 /= scale_factor[b * 4 + 3];
+            }
+            const size_t o = obase + written + pos;
+            *reinterpret_cast<float4*>(lv_boxes + o * 4) = make_float4(x1, y1, x2, y2);
+            lv_scores[o] = s;
+            lv_ctr[o] = sigmoidf_(iou[r0 + pt]);
+            lv_labels[o] = c;
+        }
+        written += tsel;
+    }
+    if (tid == 0) lv_count[b * L.n + l] = written;
+}
+
+// concatenate the per-level regions of every image into one compact candidate list
+__global__ __launch_bounds__(256) void compact_levels_kernel(const float* __restrict__ lv_boxes,
+                                                             const float* __restrict__ lv_scores,
+                                                             const float* __restrict__ lv_ctr,
+                                                             const int64_t* __restrict__ lv_labels,
+                                                             const int* __restrict__ lv_count, int nlvl, int nms_pre,
+                                                             float* __restrict__ boxes, float* __restrict__ scores,
+                                                             float* __restrict__ ctr, int64_t* __restrict__ labels,
+                                                             int* __restrict__ count) {
+    const int b = blockIdx.x;
+    const int cap = nlvl * nms_pre;
+    int off = 0;
+    for (int l = 0; l < nlvl; ++l) {
+        const int n = lv_count[b * nlvl + l];
+        const size_t src = ((size_t)b * nlvl + l) * nms_pre, dst = (size_t)b * cap + off;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            *reinterpret_cast<float4*>(boxes + (dst + i) * 4) = *reinterpret_cast<const float4*>(lv_boxes + (src + i) * 4);
+            scores[dst + i] = lv_scores[src + i];
+            ctr[dst + i] = lv_ctr[src + i];
+            labels[dst + i] = lv_labels[src + i];
+        }
+        off += n;
+    }
+    if (threadIdx.x == 0) count[b] = off;
+}
+
+extern "C" size_t radet_decode_ws_bytes(int B, int nlvl, int nms_pre) {
+    const size_t n = (size_t)B * nlvl * nms_pre;
+    return n * (16 + 4 + 4 + 8) + (size_t)B * nlvl * 4 + 256;
+}
+
+extern "C" int radet_decode_candidates(const float* cls, const float* reg_u, const float* iou, const float* scales,
+                                       const int* level_desc, int nlvl, int B, int num_classes, float score_thr,
+                                       int nms_pre, const float* img_hw, const float* scale_factor, float* cand_boxes,
+                                       float* cand_scores, float* cand_ctr, int64_t* cand_labels, int* cand_count,
+                                       void* ws, void* stream) {
+    if (nlvl < 1 || nlvl > RADET_MAX_SEG || nms_pre < 1) return RADET_ERR_ARG;
+    DecLevels L;
+    L.n = nlvl;
+    int row = 0;
+    for (int l = 0; l < nlvl; ++l) {
+        L.h[l] = level_desc[3 * l]; L.w[l] = level_desc[3 * l + 1]; L.stride[l] = level_desc[3 * l + 2];
+        L.row_off[l] = row;
+        row += B * L.h[l] * L.w[l];
+    }
+    L.row_off[nlvl] = row;
+    const size_t n = (size_t)B * nlvl * nms_pre;
+    char* p = (char*)ws;
+    float* lv_boxes = (float*)p; p += n * 16;
+    int64_t* lv_labels = (int64_t*)p; p += n * 8;
+    float* lv_scores = (float*)p; p += n * 4;
+    float* lv_ctr = (float*)p; p += n * 4;
+    int* lv_count = (int*)p;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(decode_kernel, dim3(nlvl, B), dim3(1024), 0, st, cls, reg_u, iou, scales, L, B, num_classes,
+                       score_thr, nms_pre, img_hw, scale_factor, lv_boxes, lv_scores, lv_ctr, lv_labels, lv_count);
+    hipLaunchKernelGGL(compact_levels_kernel, dim3(B), dim3(256), 0, st, lv_boxes, lv_scores, lv_ctr, lv_labels, lv_count,
+                       nlvl, nms_pre, cand_boxes, cand_scores, cand_ctr, cand_labels, cand_count);
+    return radet_check_launch();
+}
+
+// ================================================================================================ NMS
+__device__ __forceinline__ unsigned sortable_desc(float f) {
+    unsigned u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending order-preserving map
+    return ~u;                                         // descending
+}
+
+// bitonic sort of m (power of two) 64-bit keys in LDS, ascending; 1024 threads
+__device__ void bitonic_sort_u64(unsigned long long* keys, int m) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (m >> 1); t += 1024) {
+                const int i = ((t / j) * (j << 1)) + (t % j);
+                const int p = i + j;
+                const bool up = ((i & k) == 0);
+                const unsigned long long a = keys[i], b = keys[p];
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ float iou_ref(float x1i, float y1i, float x2i, float y2i, float area_i, float x1j,
+                                         float y1j, float x2j, float y2j) {
+    const float xl = fmaxf(x1j, x1i), yt = fmaxf(y1j, y1i);
+    const float xr = fminf(x2j, x2i), yb = fminf(y2j, y2i);
+    const float iw = fmaxf(0.f, xr - xl), ih = fmaxf(0.f, yb - yt);
+    const float inter = iw * ih;
+    const float area_j = (x2j - x1j) * (y2j - y1j);
+    return inter / (area_j + area_i - inter);
+}
+
+struct NmsWs {   // per-image global workspace (cap entries each)
+    float* bx;   // [4][cap] sorted coordinates (mode 3: offset coordinates)
+    float* vs;   // adjusted vote scores
+    float* cs;   // cluster scores
+    int* lab;    // labels
+    int* oidx;   // original indices
+    int* head;   // head position of each sorted position (-1: dropped)
+    int* hpos;   // head positions in output order
+};
+
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ cscores,
+                                                   const float* __restrict__ vscores, const int64_t* __restrict__ labels,
+                                                   const int* __restrict__ counts, int cap, int mode, float thr,
+                                                   int iou_enable, float sigma, int max_out, float* __restrict__ out_boxes,
+                                                   float* __restrict__ out_scores, int64_t* __restrict__ out_labels,
+                                                   int* __restrict__ out_count, int64_t* __restrict__ aux0,
+                                                   int64_t* __restrict__ aux1, char* __restrict__ ws_all,
+                                                   size_t ws_per_image) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts[b];
+    int m = 1;
+    while (m < n) m <<= 1;
+    if (m < 2) m = 2;
+    volatile unsigned char* sup = smem + (size_t)8192 * 8;        // [8192] suppressed flags
+    int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8 + 8192);    // [64]
+    int* seg_start = s_misc + 64;                        // [<= 8192 + 1] label-segment starts
+
+    char* w = ws_all + (size_t)b * ws_per_image;
+    NmsWs ws;
+    ws.bx = (float*)w; w += (size_t)cap * 16;
+    ws.vs = (float*)w; w += (size_t)cap * 4;
+    ws.cs = (float*)w; w += (size_t)cap * 4;
+    ws.lab = (int*)w; w += (size_t)cap * 4;
+    ws.oidx = (int*)w; w += (size_t)cap * 4;
+    ws.head = (int*)w; w += (size_t)cap * 4;
+    ws.hpos = (int*)w;
+
+    const float* bsrc = boxes + (size_t)b * cap * 4;
+    const float* csrc = cscores + (size_t)b * cap;
+    const float* vsrc = vscores + (size_t)b * cap;
+    const int64_t* lsrc = labels + (size_t)b * cap;
+
+    // ---- mode 3: class offset = label * (max coordinate + 1)
+    float offs_unit = 0.f;
+    if (mode == 3) {
+        float mx = -INFINITY;
+        for (int i = tid; i < n * 4; i += 1024) mx = fmaxf(mx, bsrc[i]);
+        mx = wave_max(mx);
+        __shared__ float s_mx[16];
+        if (lane == 0) s_mx[wave] = mx;
+        __syncthreads();
+        mx = s_mx[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_mx[i]);
+        offs_unit = mx + 1.0f;
+        __syncthreads();
+    }
+
+    // ---- sort by (label asc, score desc, index asc)
+    for (int i = tid; i < m; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            const unsigned long long lab = (unsigned long long)(lsrc[i] & 0x7FFF);
+            key = (lab << 48) | ((unsigned long long)sortable_desc(csrc[i]) << 16) | (unsigned long long)i;
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, m);
+    for (int i = tid; i < n; i += 1024) {
+        const int o = (int)(keys[i] & 0xFFFFull);
+        const int lab = (int)lsrc[o];
+        const float4 bb = *reinterpret_cast<const float4*>(bsrc + (size_t)o * 4);
+        float off = 0.f;
+        if (mode == 3) off = (float)lab * offs_unit;
+        ws.bx[0 * cap + i] = bb.x + off; ws.bx[1 * cap + i] = bb.y + off;
+        ws.bx[2 * cap + i] = bb.z + off; ws.bx[3 * cap + i] = bb.w + off;
+        ws.vs[i] = vsrc[o];
+        ws.cs[i] = csrc[o];
+        ws.lab[i] = lab;
+        ws.oidx[i] = o;
+        ws.head[i] = -1;
+        sup[i] = 0;
+    }
+    __syncthreads();
+    // ---- label segments
+    {
+        int nseg_total = 0;
+        for (int c0 = 0; c0 < n; c0 += 1024) {
+            const int i = c0 + tid;
+            const int is_start = (i < n) && (i == 0 || ws.lab[i] != ws.lab[i - 1]);
+            int t;
+            const int pos = block_excl_scan_1024(is_start, s_misc, t);
+            if (is_start) seg_start[nseg_total + pos] = i;
+            nseg_total += t;
+        }
+        __syncthreads();
+        if (tid == 0) { seg_start[nseg_total] = n; s_misc[32] = nseg_total; }
+        __syncthreads();
+    }
+    const int nseg = s_misc[32];
+    // ---- greedy clustering, one wavefront per label segment
+    for (int s = wave; s < nseg; s += 16) {
+        const int p0 = seg_start[s], p1 = seg_start[s + 1];
+        bool label_done = false;
+        for (int i = p0; i < p1; ++i) {
+            if (sup[i]) continue;
+            if (mode == 1 && label_done) { if (lane == 0) sup[i] = 1; continue; }
+            const float x1 = ws.bx[i], y1 = ws.bx[cap + i], x2 = ws.bx[2 * cap + i], y2 = ws.bx[3 * cap + i];
+            const float area_i = (x2 - x1) * (y2 - y1);
+            if (lane == 0) { sup[i] = 1; ws.head[i] = i; }
+            label_done = true;
+            for (int j = i + 1 + lane; j < p1; j += 64) {
+                if (sup[j]) continue;
+                const float iou = iou_ref(x1, y1, x2, y2, area_i, ws.bx[j], ws.bx[cap + j], ws.bx[2 * cap + j],
+                                          ws.bx[3 * cap + j]);
+                if (iou > thr) {
+                    sup[j] = 1;
+                    ws.head[j] = i;
+                    if (iou_enable && mode <= 1) {
+                        const float f = -(1 - iou) * (1 - iou) / sigma;
+                        ws.vs[j] = ws.vs[j] * expf(f);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- order the heads: (score desc, original index asc)
+    for (int i = tid; i < m; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < n && ws.head[i] == i)
+            key = ((unsigned long long)sortable_desc(ws.cs[i]) << 32) | ((unsigned long long)ws.oidx[i] << 16) |
+                  (unsigned long long)i;
+        keys[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_u64(keys, m);
+    {
+        int c = 0;
+        for (int i = tid; i < n; i += 1024) c += keys[i] != ~0ull ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) s_misc[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int i = 0; i < 16; ++i) t += s_misc[i];
+            s_misc[33] = t;
+        }
+        __syncthreads();
+    }
+    const int nheads = s_misc[33];
+    const int K = (max_out > 0 && nheads > max_out) ? max_out : nheads;
+    if (tid == 0) out_count[b] = K;
+    for (int r = tid; r < nheads; r += 1024) ws.hpos[r] = (int)(keys[r] & 0xFFFFull);
+    __syncthreads();
+
+    if (mode == 2) {
+        // instance ids (rank of the head) for every box, cluster size at the head
+        int64_t* inst = aux0 + (size_t)b * cap;
+        int64_t* num = aux1 + (size_t)b * cap;
+        for (int i = tid; i < n; i += 1024) num[ws.oidx[i]] = 0;
+        __syncthreads();
+        for (int r = tid; r < nheads; r += 1024) {
+            const int h = ws.hpos[r];
+            int p1 = h + 1;
+            while (p1 < n && ws.lab[p1] == ws.lab[h]) ++p1;
+            int cntm = 0;
+            for (int j = h; j < p1; ++j)
+                if (ws.head[j] == h) { inst[ws.oidx[j]] = r; ++cntm; }
+            num[ws.oidx[h]] = cntm;
+        }
+        return;
+    }
+    if (mode == 3) {
+        int64_t* keep = aux0 + (size_t)b * max_out;
+        for (int r = tid; r < K; r += 1024) {
+            const int h = ws.hpos[r];
+            const int o = ws.oidx[h];
+            const float4 bb = *reinterpret_cast<const float4*>(bsrc + (size_t)o * 4);
+            *reinterpret_cast<float4*>(out_boxes + ((size_t)b * max_out + r) * 4) = bb;
+            out_scores[(size_t)b * max_out + r] = ws.cs[h];
+            out_labels[(size_t)b * max_out + r] = ws.lab[h];
+            keep[r] = o;
+        }
+        return;
+    }
+    // ---- vote: one thread per (head, coordinate); strictly sequential fp32 sums in member order
+    const int out_cap = max_out > 0 ? max_out : cap;
+    for (int t = tid; t < K * 4; t += 1024) {
+        const int r = t >> 2, d = t & 3;
+        const int h = ws.hpos[r];
+        const int lab = ws.lab[h];
+        const float* xs = ws.bx + (size_t)d * cap;
+        float ssum = 0.f, v = 0.f;
+        int p1 = h;
+        for (int j = h; j < n && ws.lab[j] == lab; ++j) {
+            p1 = j + 1;
+            if (ws.head[j] != h) continue;
+            ssum += ws.vs[j];
+            v += ws.vs[j] * xs[j];
+        }
+        v = v / ssum;
+        float sig = 0.f;
+        for (int j = h; j < p1; ++j) {
+            if (ws.head[j] != h) continue;
+            sig += ws.vs[j] * (xs[j] - v) * (xs[j] - v);
+        }
+        sig = sqrtf(sig / ssum);
+        float fs = 0.f, fv = 0.f, mx = -INFINITY;
+        for (int j = h; j < p1; ++j) {
+            if (ws.head[j] != h) continue;
+            const float x = xs[j];
+            if ((v - sig <= x) & (x <= v + sig)) { fv += ws.vs[j] * x; fs += ws.vs[j]; }
+            mx = fmaxf(mx, ws.cs[j]);
+        }
+        out_boxes[((size_t)b * out_cap + r) * 4 + d] = fv / fs;
+        if (d == 0) {
+            out_scores[(size_t)b * out_cap + r] = mx;
+            out_labels[(size_t)b * out_cap + r] = lab;
+        }
+    }
+}
+
+static size_t nms_ws_per_image(int cap) { return ((size_t)cap * (16 + 4 * 6) + 255) / 256 * 256; }
+
+extern "C" size_t radet_nms_ws_bytes(int B, int cap) { return (size_t)B * nms_ws_per_image(cap); }
+
+extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const float* vote_scores,
+                         const int64_t* labels, const int* counts, int B, int cap, int mode, float iou_thr,
+                         int iou_enable, float sigma, int max_out, float* out_boxes, float* out_scores,
+                         int64_t* out_labels, int* out_count, int64_t* aux0, int64_t* aux1, void* ws, void* stream) {
+    if (cap < 1 || cap > 8192 || mode < 0 || mode > 3 || B < 1) return RADET_ERR_ARG;
+    if (mode == 3 && max_out <= 0) return RADET_ERR_ARG;
+    const size_t smem = (size_t)8192 * 8 + 8192 + 64 * 4 + (8192 + 8) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return RADET_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), smem, (hipStream_t)stream, boxes, cluster_scores, vote_scores,
+                       labels, counts, cap, mode, iou_thr, iou_enable, sigma, max_out, out_boxes, out_scores, out_labels,
+                       out_count, aux0, aux1, (char*)ws, nms_ws_per_image(cap));
+    return radet_check_launch();
+}

@@ -1,0 +1,613 @@
+// Non-GEMM layers of the conv stack (HBM-bound; coalesced 16-byte accesses, LDS reductions):
+//   stem 7x7/2 conv + folded BN + ReLU (NCHW image in -> NHWC out)      resnet.py:558-570,622-630
+//   maxpool 3x3/2                                                          resnet.py:570,630
+//   weight fold (BN scale into OHWI weights, + transposed copy for dgrad) / grad unfold
+//   GroupNorm(32)+ReLU forward / backward over multi-level buffers         atss_head.py:60-76
+//   nearest upsample-add forward / backward (FPN top-down path)            fpn.py:182-191
+#include "common.h"
+#include "../../include/radet_hip.h"
+
+// ------------------------------------------------------------------------------------------ stem
+// One block = 16x16 output pixels of one image; each thread owns one output pixel and all 64
+// output channels (64 fp32 accumulators).  Input patch (37x37x3) and weights (147x64) sit in LDS.
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wf,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int H,
+                                                   int W, int Ho, int Wo) {
+    constexpr int TO = 16, TI = 2 * TO + 5;  // 37
+    __shared__ float sw[147 * 64];           // [tap*3+c][o]
+    __shared__ float sx[3][TI][TI + 1];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TO, ox0 = blockIdx.x * TO;
+    // wf is [o][r][q][c] (OHWI, folded). Transpose into [k][o].
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int o = i / 147, k = i - o * 147;
+        sw[k * 64 + o] = wf[i];
+    }
+    const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+    for (int i = tid; i < 3 * TI * TI; i += 256) {
+        const int c = i / (TI * TI);
+        const int rem = i - c * TI * TI;
+        const int yy = rem / TI, xx = rem - yy * TI;
+        const int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((size_t)(n * 3 + c) * H + iy) * W + ix];
+        sx[c][yy][xx] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[64];
+#pragma unroll
+    for (int o = 0; o < 64; ++o) acc[o] = 0.f;
+    for (int r = 0; r < 7; ++r)
+        for (int q = 0; q < 7; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float xv = sx[c][ty * 2 + r][tx * 2 + q];
+                const float4* wrow = reinterpret_cast<const float4*>(&sw[((r * 7 + q) * 3 + c) * 64]);
+#pragma unroll
+                for (int o4 = 0; o4 < 16; ++o4) {
+                    const float4 wv = wrow[o4];
+                    acc[o4 * 4 + 0] = fmaf(xv, wv.x, acc[o4 * 4 + 0]);
+                    acc[o4 * 4 + 1] = fmaf(xv, wv.y, acc[o4 * 4 + 1]);
+                    acc[o4 * 4 + 2] = fmaf(xv, wv.z, acc[o4 * 4 + 2]);
+                    acc[o4 * 4 + 3] = fmaf(xv, wv.w, acc[o4 * 4 + 3]);
+                }
+            }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < Ho && ox < Wo) {
+        float4* dst = reinterpret_cast<float4*>(y + ((size_t)(n * Ho + oy) * Wo + ox) * 64);
+#pragma unroll
+        for (int o4 = 0; o4 < 16; ++o4) {
+            float4 v;
+            v.x = fmaxf(acc[o4 * 4 + 0] + bias[o4 * 4 + 0], 0.f);
+            v.y = fmaxf(acc[o4 * 4 + 1] + bias[o4 * 4 + 1], 0.f);
+            v.z = fmaxf(acc[o4 * 4 + 2] + bias[o4 * 4 + 2], 0.f);
+            v.w = fmaxf(acc[o4 * 4 + 3] + bias[o4 * 4 + 3], 0.f);
+            dst[o4] = v;
+        }
+    }
+}
+
+extern "C" int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc,
+                                       int B, int H, int W, void* stream) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B);
+    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, (hipStream_t)stream, img_nchw, wf_ohwi, bias, y_nhwc, H, W, Ho,
+                       Wo);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ maxpool
+__global__ void maxpool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int C4,
+                               int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * 2 - 1 + r;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ix = ox * 2 - 1 + q;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = x[((size_t)(n * H + iy) * W + ix) * C4 + c];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        y[i] = m;
+    }
+}
+
+extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, B,
+                       H, W, C / 4, Ho, Wo);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ fold / unfold
+// fold: for every conv in the table, s[o] = gamma*rsqrt(var+eps) (1 without BN):
+//   wf[o][t][c] = s[o] * w[o][c][t] ; wft[c][t][o] = same value ; bias_f[o] = beta - mean*s | conv bias | 0
+__global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restrict__ table) {
+    const RadetConvDesc d = table[blockIdx.y];
+    const int KT = d.kh * d.kw;
+    const size_t total = (size_t)d.cout * d.cin * KT;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        // i indexes the OHWI output (coalesced writes); reads of OIHW are strided but L2-resident
+        const int c = (int)(i % d.cin);
+        const size_t oc = i / d.cin;
+        const int t = (int)(oc % KT);
+        const int o = (int)(oc / KT);
+        float s = 1.f;
+        if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+        const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
+        d.wf[i] = v;
+        if (d.wft) d.wft[((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o] = v;
+    }
+    if (blockIdx.x == 0 && d.bias_f) {
+        for (int o = threadIdx.x; o < d.cout; o += 256) {
+            float b = 0.f;
+            if (d.bn_gamma) {
+                const float s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+                b = d.bn_beta[o] - d.bn_mean[o] * s;
+            } else if (d.bias) b = d.bias[o];
+            d.bias_f[o] = b;
+        }
+    }
+}
+
+extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {
+    if (nconv <= 0) return RADET_OK;
+    hipLaunchKernelGGL(fold_kernel, dim3(128, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
+    return radet_check_launch();
+}
+
+// unfold: one block per (conv, o).  dwf_sum[o][t][c] = sum over wgrad splits; then
+//   dw[o][c][t] = s[o]*dwf_sum ; ds[o] = <dwf_sum[o], w[o]> ; db[o] = sum of bias partials
+//   BN: dgamma = rstd*(ds - db*mean) ; dbeta = db.  plain bias: dbias = db.
+__global__ __launch_bounds__(256) void unfold_kernel(const RadetConvDesc* __restrict__ table) {
+    const RadetConvDesc d = table[blockIdx.y];
+    const int o = blockIdx.x;
+    if (o >= d.cout || d.dw == nullptr) return;
+    const int KT = d.kh * d.kw;
+    const int K = d.cin * KT;
+    const size_t slab = (size_t)d.cout * K;
+    float s = 1.f, rstd = 0.f;
+    if (d.bn_gamma) {
+        rstd = 1.0f / sqrtf(d.bn_var[o] + d.eps);
+        s = d.bn_gamma[o] * rstd;
+    }
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) {  // i = t*cin + c (OHWI inner index, coalesced slab reads)
+        const int t = i / d.cin, c = i - t * d.cin;
+        float g = 0.f;
+        for (int sp = 0; sp < d.nsplit; ++sp) g += d.dwf_slabs[sp * slab + (size_t)o * K + i];
+        const size_t wi = ((size_t)o * d.cin + c) * KT + t;
+        dot += g * d.w[wi];
+        d.dw[wi] = g * s;
+    }
+    __shared__ float red[4];
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ds = (red[0] + red[1]) + (red[2] + red[3]);
+        float db = 0.f;
+        if (d.dbias_partials)
+            for (int sp = 0; sp < d.nsplit; ++sp) db += d.dbias_partials[sp * d.cout + o];
+        if (d.bn_gamma) {
+            if (d.dgamma) d.dgamma[o] = rstd * (ds - db * d.bn_mean[o]);
+            if (d.dbeta) d.dbeta[o] = db;
+        } else if (d.dbias) d.dbias[o] = db;
+    }
+}
+
+extern "C" int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, void* stream) {
+    if (nconv <= 0) return RADET_OK;
+    hipLaunchKernelGGL(unfold_kernel, dim3(max_cout, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// Work unit = chunk of up to GN_CH pixels of one (level, image).  C = 256 channels, 32 groups of 8.
+// A block (256 threads) covers 4 pixel rows x 64 float4 columns per step.
+#define GN_CH 64
+
+struct GnChunk { int seg, n, first_pix, npix, row0, chunk_in_img, nchunks_img, part_base; };
+
+__device__ __forceinline__ GnChunk gn_decode(const RadetSegs& segs, int B, int bid) {
+    GnChunk c;
+    int base = 0, pbase = 0;
+    c.seg = 0; c.n = 0; c.first_pix = 0; c.npix = 0; c.row0 = 0; c.chunk_in_img = 0; c.nchunks_img = 1; c.part_base = 0;
+    for (int l = 0; l < segs.nseg; ++l) {
+        const int hw = segs.s[l].Ho * segs.s[l].Wo;
+        const int nch = (hw + GN_CH - 1) / GN_CH;
+        if (bid < base + B * nch) {
+            const int local = bid - base;
+            c.seg = l;
+            c.n = local / nch;
+            c.chunk_in_img = local - c.n * nch;
+            c.nchunks_img = nch;
+            c.first_pix = c.chunk_in_img * GN_CH;
+            c.npix = min(GN_CH, hw - c.first_pix);
+            c.row0 = segs.s[l].row_begin + c.n * hw + c.first_pix;
+            c.part_base = pbase + c.n * nch;
+            return c;
+        }
+        base += B * nch;
+        pbase += B * nch;
+    }
+    return c;
+}
+
+static int gn_total_chunks(const RadetSegs& segs, int B) {
+    int t = 0;
+    for (int l = 0; l < segs.nseg; ++l) t += B * ((segs.s[l].Ho * segs.s[l].Wo + GN_CH - 1) / GN_CH);
+    return t;
+}
+
+// partial[chunk][32 groups][2] = (sum, sumsq) over the chunk's pixels x 8 channels
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ z, float* __restrict__ partial,
+                                                       const RadetSegs segs, int B) {
+    const GnChunk c = gn_decode(segs, B, blockIdx.x);
+    const int tid = threadIdx.x;
+    const int col = tid & 63, prow = tid >> 6;
+    float s = 0.f, ss = 0.f;
+    for (int p = prow; p < c.npix; p += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(z + (size_t)(c.row0 + p) * 256 + col * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    // the two float4 columns of a group are neighbouring lanes
+    s += __shfl_xor(s, 1, 64);
+    ss += __shfl_xor(ss, 1, 64);
+    __shared__ float red[4][32][2];
+    if ((col & 1) == 0) { red[prow][col >> 1][0] = s; red[prow][col >> 1][1] = ss; }
+    __syncthreads();
+    if (tid < 64) {
+        const int g = tid >> 1, k = tid & 1;
+        partial[((size_t)blockIdx.x * 32 + g) * 2 + k] = (red[0][g][k] + red[1][g][k]) + (red[2][g][k] + red[3][g][k]);
+    }
+}
+
+// y = relu?((z - mean) * rstd * gamma + beta); the chunk-0 block of each image also publishes (mean, rstd)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ z, const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, float* __restrict__ stats,
+                                                       const RadetSegs segs, int B, float eps, int relu) {
+    const GnChunk c = gn_decode(segs, B, blockIdx.x);
+    const int tid = threadIdx.x;
+    __shared__ float sm[32], sr[32];
+    if (tid < 32) {
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < c.nchunks_img; ++k) {
+            s += (double)partial[((size_t)(c.part_base + k) * 32 + tid) * 2 + 0];
+            ss += (double)partial[((size_t)(c.part_base + k) * 32 + tid) * 2 + 1];
+        }
+        const double cnt = (double)segs.s[c.seg].Ho * segs.s[c.seg].Wo * 8.0;
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        sm[tid] = (float)mean;
+        sr[tid] = rstd;
+    }
+    __syncthreads();
+    const int col = tid & 63, prow = tid >> 6;
+    const int g = col >> 1;
+    const float mean = sm[g], rstd = sr[g];
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
+    for (int p = prow; p < c.npix; p += 4) {
+        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
+        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        float4 r;
+        r.x = (v.x - mean) * rstd * gm.x + bt.x;
+        r.y = (v.y - mean) * rstd * gm.y + bt.y;
+        r.z = (v.z - mean) * rstd * gm.z + bt.z;
+        r.w = (v.w - mean) * rstd * gm.w + bt.w;
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        *reinterpret_cast<float4*>(y + o) = r;
+    }
+    if (c.chunk_in_img == 0 && tid < 32) {
+        // stats layout: [(seg, n)][32][2]; (seg, n) linear id = sum_{l<seg} B + n
+        int lin = c.n;
+        for (int l = 0; l < c.seg; ++l) lin += B;
+        stats[((size_t)lin * 32 + tid) * 2 + 0] = sm[tid];
+        stats[((size_t)lin * 32 + tid) * 2 + 1] = sr[tid];
+    }
+}
+
+extern "C" int radet_gn_relu_fwd(const float* z, const float* gamma, const float* beta, float* y, float* stats,
+                                 float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                                 int nseg, void* stream) {
+    if (C != 256 || groups != 32) return RADET_ERR_ARG;
+    RadetSegs segs;
+    if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
+    segs.nseg = nseg;
+    for (int l = 0; l < nseg; ++l) {
+        const int* d = seg_desc + 6 * l;
+        segs.s[l].Hi = d[0]; segs.s[l].Wi = d[1]; segs.s[l].Ho = d[2]; segs.s[l].Wo = d[3];
+        segs.s[l].in_row_off = d[4]; segs.s[l].row_begin = d[5]; segs.s[l].row_end = d[5] + B * d[2] * d[3];
+    }
+    const int chunks = gn_total_chunks(segs, B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(256), 0, st, z, partial_ws, segs, B);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(256), 0, st, z, partial_ws, gamma, beta, y, stats, segs, B,
+                       eps, relu);
+    return radet_check_launch();
+}
+
+extern "C" int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg) {
+    int t = 0;
+    for (int l = 0; l < nseg; ++l) t += B * ((seg_desc[6 * l + 2] * seg_desc[6 * l + 3] + GN_CH - 1) / GN_CH);
+    return t * (64 + 512);  // group partials (fwd/bwd) + per-channel partials (bwd)
+}
+
+// backward pass 1: g = dy * [y > 0] (y recomputed);  per chunk: group sums (sum g*gamma, sum g*gamma*xhat),
+// channel sums (sum g*xhat -> dgamma, sum g -> dbeta)
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ gpart,
+                                                           float* __restrict__ cpart, const RadetSegs segs, int B,
+                                                           int relu) {
+    const GnChunk c = gn_decode(segs, B, blockIdx.x);
+    const int tid = threadIdx.x;
+    const int col = tid & 63, prow = tid >> 6;
+    const int g = col >> 1;
+    int lin = c.n;
+    for (int l = 0; l < c.seg; ++l) lin += B;
+    const float mean = stats[((size_t)lin * 32 + g) * 2 + 0];
+    const float rstd = stats[((size_t)lin * 32 + g) * 2 + 1];
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
+    float s1 = 0.f, s2 = 0.f;
+    float4 cg = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = prow; p < c.npix; p += 4) {
+        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
+        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        float4 d = *reinterpret_cast<const float4*>(dy + o);
+        float4 xh;
+        xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
+        if (relu) {
+            if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
+            if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
+            if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
+            if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+        }
+        cg.x += d.x * xh.x; cg.y += d.y * xh.y; cg.z += d.z * xh.z; cg.w += d.w * xh.w;
+        cb.x += d.x; cb.y += d.y; cb.z += d.z; cb.w += d.w;
+        const float a0 = d.x * gm.x, a1 = d.y * gm.y, a2 = d.z * gm.z, a3 = d.w * gm.w;
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (a0 * xh.x + a1 * xh.y) + (a2 * xh.z + a3 * xh.w);
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s2 += __shfl_xor(s2, 1, 64);
+    __shared__ float red[4][32][2];
+    __shared__ float4 cred[4][64][2];
+    if ((col & 1) == 0) { red[prow][g][0] = s1; red[prow][g][1] = s2; }
+    cred[prow][col][0] = cg;
+    cred[prow][col][1] = cb;
+    __syncthreads();
+    if (tid < 64) {
+        const int gg = tid >> 1, k = tid & 1;
+        gpart[((size_t)blockIdx.x * 32 + gg) * 2 + k] = (red[0][gg][k] + red[1][gg][k]) + (red[2][gg][k] + red[3][gg][k]);
+    }
+    if (tid < 128) {
+        const int cc = tid & 63, k = tid >> 6;
+        float4 a = cred[0][cc][k], b = cred[1][cc][k], c2 = cred[2][cc][k], d2 = cred[3][cc][k];
+        float4 r;
+        r.x = (a.x + b.x) + (c2.x + d2.x); r.y = (a.y + b.y) + (c2.y + d2.y);
+        r.z = (a.z + b.z) + (c2.z + d2.z); r.w = (a.w + b.w) + (c2.w + d2.w);
+        // cpart[chunk][2][256]
+        *reinterpret_cast<float4*>(cpart + ((size_t)blockIdx.x * 2 + k) * 256 + cc * 4) = r;
+    }
+}
+
+// backward pass 2: dz = rstd * (g*gamma - m1 - xhat*m2), m1/m2 = group means of g*gamma, g*gamma*xhat
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ gpart, float* __restrict__ dz,
+                                                           const RadetSegs segs, int B, int relu) {
+    const GnChunk c = gn_decode(segs, B, blockIdx.x);
+    const int tid = threadIdx.x;
+    __shared__ float m1s[32], m2s[32];
+    if (tid < 32) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < c.nchunks_img; ++k) {
+            a += (double)gpart[((size_t)(c.part_base + k) * 32 + tid) * 2 + 0];
+            b += (double)gpart[((size_t)(c.part_base + k) * 32 + tid) * 2 + 1];
+        }
+        const double cnt = (double)segs.s[c.seg].Ho * segs.s[c.seg].Wo * 8.0;
+        m1s[tid] = (float)(a / cnt);
+        m2s[tid] = (float)(b / cnt);
+    }
+    __syncthreads();
+    const int col = tid & 63, prow = tid >> 6;
+    const int g = col >> 1;
+    int lin = c.n;
+    for (int l = 0; l < c.seg; ++l) lin += B;
+    const float mean = stats[((size_t)lin * 32 + g) * 2 + 0];
+    const float rstd = stats[((size_t)lin * 32 + g) * 2 + 1];
+    const float m1 = m1s[g], m2 = m2s[g];
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
+    for (int p = prow; p < c.npix; p += 4) {
+        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
+        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        float4 d = *reinterpret_cast<const float4*>(dy + o);
+        float4 xh;
+        xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
+        if (relu) {
+            if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
+            if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
+            if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
+            if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+        }
+        float4 r;
+        r.x = rstd * (d.x * gm.x - m1 - xh.x * m2);
+        r.y = rstd * (d.y * gm.y - m1 - xh.y * m2);
+        r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
+        r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
+        *reinterpret_cast<float4*>(dz + o) = r;
+    }
+}
+
+// final per-channel reduce over chunks: dgamma[c], dbeta[c]
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ cpart, int nchunks,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = threadIdx.x;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        a += cpart[((size_t)k * 2 + 0) * 256 + c];
+        b += cpart[((size_t)k * 2 + 1) * 256 + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
+extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* stats, const float* gamma,
+                                 const float* beta, float* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
+                                 int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
+    if (C != 256 || groups != 32) return RADET_ERR_ARG;
+    RadetSegs segs;
+    if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
+    segs.nseg = nseg;
+    for (int l = 0; l < nseg; ++l) {
+        const int* d = seg_desc + 6 * l;
+        segs.s[l].Hi = d[0]; segs.s[l].Wi = d[1]; segs.s[l].Ho = d[2]; segs.s[l].Wo = d[3];
+        segs.s[l].in_row_off = d[4]; segs.s[l].row_begin = d[5]; segs.s[l].row_end = d[5] + B * d[2] * d[3];
+    }
+    const int chunks = gn_total_chunks(segs, B);
+    float* gpart = partial_ws;
+    float* cpart = partial_ws + (size_t)chunks * 64;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
+                       segs, B, relu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
+                       B, relu);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(1), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ upsample-add
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+// dst[n, oy, ox, :] += src[n, nearest(oy), nearest(ox), :]      (F.interpolate(mode='nearest', size=...))
+__global__ void upsample_add_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int B, int Ho, int Wo,
+                                    int Hi, int Wi, int C4, float sy, float sx) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const int iy = nearest_src(oy, sy, Hi), ix = nearest_src(ox, sx, Wi);
+        const float4 s = src[((size_t)(n * Hi + iy) * Wi + ix) * C4 + c];
+        float4 d = dst[i];
+        d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+        dst[i] = d;
+    }
+}
+
+// dsrc[n, iy, ix, :] += sum over dst pixels that read (iy, ix)
+__global__ void upsample_add_bwd_kernel(float4* __restrict__ dsrc, const float4* __restrict__ ddst, int B, int Ho,
+                                        int Wo, int Hi, int Wi, int C4, float sy, float sx) {
+    const size_t total = (size_t)B * Hi * Wi * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int ix = (int)(p % Wi);
+        p /= Wi;
+        const int iy = (int)(p % Hi);
+        const int n = (int)(p / Hi);
+        const int oy_lo = max(0, (int)((float)iy / sy) - 2), oy_hi = min(Ho - 1, (int)((float)(iy + 1) / sy) + 2);
+        const int ox_lo = max(0, (int)((float)ix / sx) - 2), ox_hi = min(Wo - 1, (int)((float)(ix + 1) / sx) + 2);
+        float4 a = dsrc[i];
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (nearest_src(oy, sy, Hi) != iy) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (nearest_src(ox, sx, Wi) != ix) continue;
+                const float4 d = ddst[((size_t)(n * Ho + oy) * Wo + ox) * C4 + c];
+                a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+            }
+        }
+        dsrc[i] = a;
+    }
+}
+
+extern "C" int radet_upsample_add(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                  void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dst,
+                       (const float4*)src, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return radet_check_launch();
+}
+
+extern "C" int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                      void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const size_t total = (size_t)B * Hi * Wi * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dsrc,
+                       (const float4*)ddst, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ relu backward
+// dx = (dy (+ addend)) * [act > 0]
+__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ addend,
+                                const float4* __restrict__ act, float4* __restrict__ dx, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = dy[i];
+        if (addend) { const float4 a = addend[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        const float4 m = act[i];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        dx[i] = v;
+    }
+}
+extern "C" int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream) {
+    if (n % 4) return RADET_ERR_ARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dy,
+                       (const float4*)addend, (const float4*)act, (float4*)dx, n4);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ layout helpers
+// NCHW <-> NHWC for the drop-in module API (the fast path never needs them except for the image,
+// which the stem reads directly).
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int hw = (int)(p % HW);
+        const int n = (int)(p / HW);
+        y[i] = x[((size_t)n * C + c) * HW + hw];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+    const size_t total = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW);
+        size_t p = i / HW;
+        const int c = (int)(p % C);
+        const int n = (int)(p / C);
+        y[i] = x[((size_t)n * HW + hw) * C + c];
+    }
+}
+extern "C" int radet_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    const size_t total = (size_t)B * C * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C, H * W);
+    return radet_check_launch();
+}
+extern "C" int radet_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    const size_t total = (size_t)B * C * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, C, H * W);
+    return radet_check_launch();
+}

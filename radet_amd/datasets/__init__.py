@@ -1,0 +1,3 @@
+from .pipelines import PIPELINES, GenerateDistanceMap, LabelAssignment, build_pipeline
+
+__all__ = ["PIPELINES", "LabelAssignment", "GenerateDistanceMap", "build_pipeline"]

@@ -1,0 +1,463 @@
+"""Static execution plan of the detector hot path on one MI355X.
+
+The network structure is fixed (ResNet bottlenecks -> FPN -> shared-weight head), so instead of a
+tracing compiler or per-op autograd nodes the engine holds an explicit forward program and a
+hand-written reverse program over pre-allocated NHWC buffers; every step is a fixed sequence of
+HIP launches on the current stream (hipGraph-capturable: no allocation, no host sync).
+
+Layout decisions (MI355X-first):
+  * activations: fp32 NHWC rows [B*H*W, C]; the five pyramid levels live in ONE row-concatenated
+    buffer so that each shared-weight head conv / GroupNorm is a single launch over B*6400 rows;
+  * parameters: torch Parameters in state-dict layout (OIHW) are folded once per step into OHWI
+    (+ BN scale) and a transposed copy for dgrad by one batched kernel; wgrad writes split-K slabs
+    that a second batched kernel reduces, un-folds (BN gamma/beta grads) and re-lays-out to OIHW.
+
+Reference call sites this replaces: ResNet.forward (radet/models/backbones/resnet.py:622-637),
+FPN.forward (necks/fpn.py:170-221), ATSSHead.forward / RADetHead.forward_single
+(dense_heads/atss_head.py:100-145, radet_head.py:27-30) and their autograd backward.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import kernels as K
+from .kernels import ConvGeom, Levels
+
+ARCH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+def conv_out_hw(h, w, k, s, p):
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+class Conv:
+    """One convolution layer: parameters by name, folded buffers, geometry-bound slabs."""
+
+    def __init__(self, name, cin, cout, k, stride, pad, bn=None, bias=False, trainable=True, dgrad=True):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.bn, self.bias, self.trainable, self.need_dgrad = bn, bias, trainable, dgrad
+        self.wft_ld, self.wft_off, self.wft_shared = 0, 0, None
+        self.geom = None
+        self.wf = self.wft = self.bias_f = self.slabs = self.dbias_partials = None
+
+    @property
+    def wsize(self):
+        return self.cout * self.cin * self.k * self.k
+
+
+class Engine:
+    def __init__(self, params, grads, depth=50, num_classes=21, frozen_stages=1, strides=(8, 16, 32, 64, 128),
+                 stacked_convs=4, feat=256):
+        """params / grads: dict name -> device tensor (reference state-dict names; grads only for
+        trainable parameters, same shapes)."""
+        self.p, self.g = params, grads
+        self.depth, self.num_classes, self.frozen_stages = depth, num_classes, frozen_stages
+        self.strides, self.stacked_convs, self.feat = tuple(strides), stacked_convs, feat
+        self.dev = next(iter(params.values())).device
+        self.convs = []
+        self._build_layers()
+        self._alloc_folded()
+        self.geo_key = None
+        self.table = None
+
+    # ------------------------------------------------------------------ structure
+    def _add(self, conv):
+        self.convs.append(conv)
+        return conv
+
+    def _build_layers(self):
+        fs = self.frozen_stages
+        self.stem = self._add(Conv("backbone.conv1", 3, 64, 7, 2, 3, bn="backbone.bn1", trainable=fs < 0, dgrad=False))
+        self.stages = []
+        inpl = 64
+        for li, nb in enumerate(ARCH[self.depth]):
+            planes = 64 * 2 ** li
+            train = (li + 1) > fs
+            blocks = []
+            for b in range(nb):
+                pfx = f"backbone.layer{li + 1}.{b}"
+                stride = 2 if (b == 0 and li > 0) else 1
+                # gradient w.r.t. the block input is needed unless that input comes from a frozen stage / the stem
+                in_dgrad = train and not (b == 0 and li <= fs)
+                blk = dict(
+                    c1=self._add(Conv(pfx + ".conv1", inpl, planes, 1, 1, 0, bn=pfx + ".bn1", trainable=train, dgrad=in_dgrad)),
+                    c2=self._add(Conv(pfx + ".conv2", planes, planes, 3, stride, 1, bn=pfx + ".bn2", trainable=train, dgrad=train)),
+                    c3=self._add(Conv(pfx + ".conv3", planes, planes * 4, 1, 1, 0, bn=pfx + ".bn3", trainable=train, dgrad=train)),
+                    ds=None, stride=stride, train=train)
+                if b == 0:
+                    blk["ds"] = self._add(Conv(pfx + ".downsample.0", inpl, planes * 4, 1, stride, 0, bn=pfx + ".downsample.1",
+                                               trainable=train, dgrad=in_dgrad))
+                inpl = planes * 4
+                blocks.append(blk)
+            self.stages.append(blocks)
+        f = self.feat
+        self.lat = [self._add(Conv(f"neck.lateral_convs.{i}.conv", c, f, 1, 1, 0, bias=True)) for i, c in enumerate((512, 1024, 2048))]
+        self.fpn = [self._add(Conv(f"neck.fpn_convs.{i}.conv", f, f, 3, 1 if i < 3 else 2, 1, bias=True)) for i in range(5)]
+        self.cls_tower = [self._add(Conv(f"bbox_head.cls_convs.{i}.conv", f, f, 3, 1, 1)) for i in range(self.stacked_convs)]
+        self.reg_tower = [self._add(Conv(f"bbox_head.reg_convs.{i}.conv", f, f, 3, 1, 1)) for i in range(self.stacked_convs)]
+        self.pred_cls = self._add(Conv("bbox_head.atss_cls", f, self.num_classes, 3, 1, 1, bias=True))
+        self.pred_reg = self._add(Conv("bbox_head.atss_reg", f, 4, 3, 1, 1, bias=True))
+        self.pred_iou = self._add(Conv("bbox_head.atss_centerness", f, 1, 3, 1, 1, bias=True))
+        # dgrad of the small predictors runs on zero-padded K (GEMM K must be a multiple of 16)
+        self.cls_pad = ((self.num_classes + 15) // 16) * 16
+        self.pred_cls.wft_ld, self.pred_cls.wft_off = self.cls_pad, 0
+        self.pred_reg.wft_ld, self.pred_reg.wft_off = 16, 0
+        self.pred_iou.wft_ld, self.pred_iou.wft_off = 16, 4
+        self.pred_iou.wft_shared = self.pred_reg
+
+    def _alloc_folded(self):
+        dev = self.dev
+        n_wf = sum(c.wsize for c in self.convs)
+        n_b = sum(c.cout for c in self.convs)
+        self.wf_arena = torch.zeros(n_wf, device=dev)
+        self.bias_arena = torch.zeros(n_b, device=dev)
+        n_wft = 0
+        for c in self.convs:
+            if c.need_dgrad and c.wft_shared is None:
+                ld = c.wft_ld or c.cout
+                n_wft += c.cin * c.k * c.k * ld
+        self.wft_arena = torch.zeros(n_wft, device=dev)
+        o_w = o_b = o_t = 0
+        for c in self.convs:
+            c.wf = self.wf_arena[o_w:o_w + c.wsize]
+            o_w += c.wsize
+            c.bias_f = self.bias_arena[o_b:o_b + c.cout]
+            o_b += c.cout
+            if c.need_dgrad:
+                if c.wft_shared is not None:
+                    c.wft = c.wft_shared.wft
+                else:
+                    n = c.cin * c.k * c.k * (c.wft_ld or c.cout)
+                    c.wft = self.wft_arena[o_t:o_t + n]
+                    o_t += n
+
+    # ------------------------------------------------------------------ geometry-dependent plan
+    def prepare(self, B, H, W):
+        key = (B, H, W)
+        if self.geo_key == key:
+            return
+        self.geo_key = key
+        dev = self.dev
+        self.B, self.H, self.W = B, H, W
+        h1, w1 = conv_out_hw(H, W, 7, 2, 3)
+        h2, w2 = conv_out_hw(h1, w1, 3, 2, 1)
+        self.stem_hw, self.pool_hw = (h1, w1), (h2, w2)
+        self.buf = {}
+
+        def new(name, rows, ch):
+            t = torch.empty(rows, ch, device=dev)
+            self.buf[name] = t
+            return t
+
+        new("stem", B * h1 * w1, 64)
+        new("pool", B * h2 * w2, 64)
+        lv = Levels([(h2, w2)], B)
+        for li, blocks in enumerate(self.stages):
+            for b, blk in enumerate(blocks):
+                pfx = f"l{li + 1}.{b}"
+                blk["lin"] = lv
+                blk["c1"].geom = ConvGeom(lv, blk["c1"].cin, blk["c1"].cout, 1, 1, 0)
+                blk["c2"].geom = ConvGeom(lv, blk["c2"].cin, blk["c2"].cout, 3, blk["stride"], 1)
+                lo = blk["c2"].geom.lout
+                blk["c3"].geom = ConvGeom(lo, blk["c3"].cin, blk["c3"].cout, 1, 1, 0)
+                if blk["ds"] is not None:
+                    blk["ds"].geom = ConvGeom(lv, blk["ds"].cin, blk["ds"].cout, 1, blk["stride"], 0)
+                    new(pfx + ".idt", lo.rows, blk["ds"].cout)
+                    if blk["ds"].need_dgrad:
+                        new(pfx + ".tmp_in", lv.rows, blk["ds"].cin)
+                blk["lout"] = lo
+                new(pfx + ".o1", lv.rows, blk["c1"].cout)
+                new(pfx + ".o2", lo.rows, blk["c2"].cout)
+                new(pfx + ".out", lo.rows, blk["c3"].cout)
+                if blk["train"]:
+                    new(pfx + ".d_o1", lv.rows, blk["c1"].cout)
+                    new(pfx + ".d_o2", lo.rows, blk["c2"].cout)
+                    new(pfx + ".d_pre", lo.rows, blk["c3"].cout)
+                lv = lo
+        # FPN on C3..C5
+        c_lv = [self.stages[i][-1]["lout"] for i in (1, 2, 3)]
+        f = self.feat
+        for i in range(3):
+            self.lat[i].geom = ConvGeom(c_lv[i], self.lat[i].cin, f, 1, 1, 0)
+            new(f"lat{i}", c_lv[i].rows, f)
+            new(f"d_lat{i}", c_lv[i].rows, f)
+            new(f"d_c{i}", c_lv[i].rows, self.lat[i].cin)
+        hw = [c_lv[i].hw[0] for i in range(3)]
+        hw.append(conv_out_hw(*hw[-1], 3, 2, 1))
+        hw.append(conv_out_hw(*hw[-1], 3, 2, 1))
+        self.plv = Levels(hw, B)
+        for i in range(3):
+            self.fpn[i].geom = ConvGeom(c_lv[i], f, f, 3, 1, 1)
+        self.fpn[3].geom = ConvGeom(self.plv.sub(2), f, f, 3, 2, 1)
+        self.fpn[4].geom = ConvGeom(self.plv.sub(3), f, f, 3, 2, 1)
+        R = self.plv.rows
+        self.R = R
+        new("P", R, f)
+        new("dP", R, f)
+        new("dP_tmp", R, f)
+        for t in ("cls", "reg"):
+            for i in range(self.stacked_convs):
+                new(f"{t}.z{i}", R, f)
+                new(f"{t}.y{i}", R, f)
+                self.buf[f"{t}.stats{i}"] = torch.empty(len(hw) * B * 64, device=dev)
+            new(f"{t}.dy", R, f)
+            new(f"{t}.dz", R, f)
+        for c in self.cls_tower + self.reg_tower:
+            c.geom = ConvGeom(self.plv, f, f, 3, 1, 1)
+        for c in (self.pred_cls, self.pred_reg, self.pred_iou):
+            c.geom = ConvGeom(self.plv, f, c.cout, 3, 1, 1)
+        new("cls", R, self.num_classes)
+        new("reg_u", R, 4)
+        new("iou", R, 1)
+        self.buf["dcls"] = torch.zeros(R, self.cls_pad, device=dev)
+        self.buf["dregiou"] = torch.zeros(R, 16, device=dev)
+        self.gn_ws = torch.empty(K.gn_ws_floats(self.plv), device=dev)
+        self.ldesc, self.nlvl = K.level_desc(self.plv, self.strides)
+        self.loss_ws = torch.zeros(K.head_loss_ws_ints(R), dtype=torch.int32, device=dev)
+        self.losses = torch.zeros(3, device=dev)
+        self.dscales = torch.zeros(len(hw), device=dev)
+        # wgrad slabs / bias partials + descriptor table
+        n_slab = sum(c.geom.nsplit * c.wsize for c in self.convs if c.trainable)
+        n_bp = sum(c.geom.nsplit * c.cout for c in self.convs if c.trainable)
+        self.slab_arena = torch.empty(n_slab, device=dev)
+        self.bp_arena = torch.zeros(n_bp, device=dev)
+        o_s = o_b = 0
+        for c in self.convs:
+            if c.trainable:
+                n = c.geom.nsplit * c.wsize
+                c.slabs = self.slab_arena[o_s:o_s + n]
+                o_s += n
+                n = c.geom.nsplit * c.cout
+                c.dbias_partials = self.bp_arena[o_b:o_b + n]
+                o_b += n
+        self._build_table()
+
+    def _build_table(self):
+        n = len(self.convs)
+        arr = (_lib.RadetConvDesc * n)()
+
+        def ptr(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        for d, c in zip(arr, self.convs):
+            p, g = self.p, self.g
+            d.w = ptr(p[c.name + ".weight"])
+            d.bias = ptr(p.get(c.name + ".bias")) if c.bias else None
+            if c.bn:
+                d.bn_gamma, d.bn_beta = ptr(p[c.bn + ".weight"]), ptr(p[c.bn + ".bias"])
+                d.bn_mean, d.bn_var = ptr(p[c.bn + ".running_mean"]), ptr(p[c.bn + ".running_var"])
+            d.wf, d.wft, d.bias_f = ptr(c.wf), ptr(c.wft) if c.need_dgrad else None, ptr(c.bias_f)
+            d.cout, d.cin, d.kh, d.kw = c.cout, c.cin, c.k, c.k
+            d.eps = 1e-5
+            d.wft_ld, d.wft_off = c.wft_ld, c.wft_off
+            d.nsplit = c.geom.nsplit if c.geom is not None else 1
+            if c.trainable and c.geom is not None:
+                d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
+                d.dw = ptr(g[c.name + ".weight"])
+                if c.bias:
+                    d.dbias = ptr(g[c.name + ".bias"])
+                if c.bn:
+                    d.dgamma, d.dbeta = ptr(g[c.bn + ".weight"]), ptr(g[c.bn + ".bias"])
+        raw = bytes(arr)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.dev)
+        self._table_keepalive = arr
+        self.max_cout = max(c.cout for c in self.convs)
+
+    # ------------------------------------------------------------------ per-step parameter transforms
+    def fold(self):
+        K.fold_weights(self.table, len(self.convs))
+
+    def unfold(self):
+        K.unfold_grads(self.table, len(self.convs), self.max_cout)
+
+    # ------------------------------------------------------------------ forward
+    def backbone_forward(self, img):
+        B, H, W = self.B, self.H, self.W
+        b = self.buf
+        K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
+        K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
+        x = b["pool"]
+        outs = []
+        for li, blocks in enumerate(self.stages):
+            for bi, blk in enumerate(blocks):
+                pfx = f"l{li + 1}.{bi}"
+                blk["x"] = x
+                o1, o2, out = b[pfx + ".o1"], b[pfx + ".o2"], b[pfx + ".out"]
+                K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
+                K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
+                if blk["ds"] is not None:
+                    idt = b[pfx + ".idt"]
+                    K.conv_fwd(blk["ds"].geom, x, blk["ds"].wf, blk["ds"].bias_f, idt)
+                else:
+                    idt = x
+                K.conv_fwd(blk["c3"].geom, o2, blk["c3"].wf, blk["c3"].bias_f, out, addend=idt, relu=True)
+                x = out
+            outs.append(x)
+        return outs  # C2..C5 row buffers
+
+    def neck_forward(self, feats):
+        b, B = self.buf, self.B
+        c = feats[1:]
+        for i in range(3):
+            K.conv_fwd(self.lat[i].geom, c[i], self.lat[i].wf, self.lat[i].bias_f, b[f"lat{i}"])
+        hw = self.plv.hw
+        for i in (2, 1):
+            K.upsample_add(b[f"lat{i - 1}"], b[f"lat{i}"], B, hw[i - 1][0], hw[i - 1][1], hw[i][0], hw[i][1], self.feat)
+        P = b["P"]
+        for i in range(3):
+            r0, r1 = self.plv.level_rows(i)
+            K.conv_fwd(self.fpn[i].geom, b[f"lat{i}"], self.fpn[i].wf, self.fpn[i].bias_f, P[r0:r1])
+        for i in (3, 4):
+            s0, s1 = self.plv.level_rows(i - 1)
+            r0, r1 = self.plv.level_rows(i)
+            K.conv_fwd(self.fpn[i].geom, P[s0:s1], self.fpn[i].wf, self.fpn[i].bias_f, P[r0:r1])
+        return P
+
+    def head_forward(self, P):
+        b, p = self.buf, self.p
+        for t, tower in (("cls", self.cls_tower), ("reg", self.reg_tower)):
+            x = P
+            for i, c in enumerate(tower):
+                z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
+                K.conv_fwd(c.geom, x, c.wf, None, z)
+                gn = f"bbox_head.{t}_convs.{i}.gn"
+                K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], self.gn_ws)
+                x = y
+        yc, yr = b[f"cls.y{self.stacked_convs - 1}"], b[f"reg.y{self.stacked_convs - 1}"]
+        K.conv_fwd(self.pred_cls.geom, yc, self.pred_cls.wf, self.pred_cls.bias_f, b["cls"])
+        K.conv_fwd(self.pred_reg.geom, yr, self.pred_reg.wf, self.pred_reg.bias_f, b["reg_u"])
+        K.conv_fwd(self.pred_iou.geom, yr, self.pred_iou.wf, self.pred_iou.bias_f, b["iou"])
+        return b["cls"], b["reg_u"], b["iou"]
+
+    def scales_tensor(self):
+        """The five learnable Scale scalars as one contiguous device vector (views a flat arena when the
+        owner laid them out contiguously, else packs them)."""
+        names = [f"bbox_head.scales.{i}.scale" for i in range(len(self.strides))]
+        ts = [self.p[n] for n in names]
+        base = ts[0].data_ptr()
+        if all(t.data_ptr() == base + 4 * i for i, t in enumerate(ts)):
+            return torch.as_strided(ts[0], (len(ts),), (1,))
+        return torch.stack([t.reshape(()) for t in ts]).contiguous()
+
+    def loss(self, gt_boxes, gt_labels, gt_off, p2g, pw, grad_scale=None, alpha=0.25, gamma=2.0, lbw=2.0,
+             labels_out=None, tgt_out=None):
+        b = self.buf
+        dri = b["dregiou"]
+        K.head_loss(b["cls"], b["reg_u"], b["iou"], self.scales_tensor(), gt_boxes, gt_labels, gt_off, p2g, pw, self.ldesc,
+                    self.nlvl, self.B, self.num_classes, alpha, gamma, lbw, 1e-6, grad_scale, self.losses, b["dcls"],
+                    self.cls_pad, dri, 16, dri.view(-1)[4:], 16, self.dscales, self.loss_ws, labels_out, tgt_out)
+        return self.losses
+
+    # ------------------------------------------------------------------ backward
+    def head_backward(self):
+        """Consumes buf['dcls'] / buf['dregiou'] (written by loss()); leaves dL/dP in buf['dP']."""
+        b, p, g = self.buf, self.p, self.g
+        n = self.stacked_convs
+        dP = b["dP"]
+        first = True
+        for t, tower in (("cls", self.cls_tower), ("reg", self.reg_tower)):
+            ylast = b[f"{t}.y{n - 1}"]
+            dy, dz = b[f"{t}.dy"], b[f"{t}.dz"]
+            if t == "cls":
+                pc = self.pred_cls
+                K.conv_wgrad(pc.geom, b["dcls"], ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
+                K.conv_dgrad(pc.geom, b["dcls"], pc.wft, dy, k_channels=self.cls_pad)
+            else:
+                pr, pi = self.pred_reg, self.pred_iou
+                dri = b["dregiou"]
+                K.conv_wgrad(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=16)
+                K.conv_wgrad(pi.geom, dri.view(-1)[4:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=16)
+                K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=16)
+            for i in range(n - 1, -1, -1):
+                c = tower[i]
+                gn = f"bbox_head.{t}_convs.{i}.gn"
+                K.gn_relu_bwd(self.plv, dy, b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"], p[gn + ".bias"], dz,
+                              g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
+                x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
+                K.conv_wgrad(c.geom, dz, x, c.slabs, None)
+                if i > 0:
+                    K.conv_dgrad(c.geom, dz, c.wft, dy)
+                else:
+                    K.conv_dgrad(c.geom, dz, c.wft, dP, addend=None if first else dP)
+            first = False
+        # Scale gradients
+        for i in range(len(self.strides)):
+            g[f"bbox_head.scales.{i}.scale"].copy_(self.dscales[i])
+        return dP
+
+    def neck_backward(self, dP):
+        b, B, f = self.buf, self.B, self.feat
+        P = b["P"]
+        lr = [self.plv.level_rows(i) for i in range(5)]
+        sl = lambda t, i: t[lr[i][0]:lr[i][1]]  # noqa: E731
+        tmp = b["dP_tmp"]
+        # P7 = conv4(P6); P6 = conv3(P5)
+        c4, c3 = self.fpn[4], self.fpn[3]
+        K.conv_wgrad(c4.geom, sl(dP, 4), sl(P, 3), c4.slabs, c4.dbias_partials)
+        K.conv_dgrad(c4.geom, sl(dP, 4), c4.wft, sl(tmp, 3), addend=sl(dP, 3))
+        K.conv_wgrad(c3.geom, sl(tmp, 3), sl(P, 2), c3.slabs, c3.dbias_partials)
+        K.conv_dgrad(c3.geom, sl(tmp, 3), c3.wft, sl(tmp, 2), addend=sl(dP, 2))
+        srcs = [sl(dP, 0), sl(dP, 1), sl(tmp, 2)]
+        for i in range(3):
+            c = self.fpn[i]
+            K.conv_wgrad(c.geom, srcs[i], b[f"lat{i}"], c.slabs, c.dbias_partials)
+            K.conv_dgrad(c.geom, srcs[i], c.wft, b[f"d_lat{i}"])
+        hw = self.plv.hw
+        for i in (1, 2):
+            K.upsample_add_bwd(b[f"d_lat{i}"], b[f"d_lat{i - 1}"], B, hw[i - 1][0], hw[i - 1][1], hw[i][0], hw[i][1], f)
+        feats = [self.stages[i][-1] for i in (1, 2, 3)]
+        for i in range(3):
+            c = self.lat[i]
+            x = b[f"l{i + 2}.{len(self.stages[i + 1]) - 1}.out"]
+            K.conv_wgrad(c.geom, b[f"d_lat{i}"], x, c.slabs, c.dbias_partials)
+            K.conv_dgrad(c.geom, b[f"d_lat{i}"], c.wft, b[f"d_c{i}"])
+        del feats
+        return [b["d_c0"], b["d_c1"], b["d_c2"]]
+
+    def backbone_backward(self, d_feats, after_stage=None):
+        """d_feats: gradients w.r.t. C3, C4, C5 coming from the neck. `after_stage(li)` is called once
+        all weight gradients of stage li are complete (bucketed unfold / all-reduce hook)."""
+        b = self.buf
+        d_next_pre = None     # d_pre of the block after the current one (same stage or next stage's first block)
+        nxt = None            # that block
+        for li in range(len(self.stages) - 1, -1, -1):
+            blocks = self.stages[li]
+            if not blocks[0]["train"]:
+                break
+            for bi in range(len(blocks) - 1, -1, -1):
+                blk = blocks[bi]
+                pfx = f"l{li + 1}.{bi}"
+                out, o1, o2 = b[pfx + ".out"], b[pfx + ".o1"], b[pfx + ".o2"]
+                d_pre, d_o1, d_o2 = b[pfx + ".d_pre"], b[pfx + ".d_o1"], b[pfx + ".d_o2"]
+                # ---- gradient w.r.t. this block's (post-ReLU) output -> d_pre = grad * [out > 0]
+                last_of_stage = bi == len(blocks) - 1
+                ext = d_feats[li - 1] if (last_of_stage and li >= 1) else None   # FPN taps C3..C5 (stages 2..4)
+                if nxt is None:
+                    # top of the network: only the FPN gradient reaches C5
+                    K.relu_bwd(ext, None, out, d_pre)
+                elif nxt["ds"] is not None:
+                    # next block is the first of the next stage: conv1 + downsample both read `out`
+                    t = nxt["tmp_in"]
+                    K.conv_dgrad(nxt["ds"].geom, nxt["d_pre"], nxt["ds"].wft, t, addend=ext)
+                    K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pre, addend=t, mask=out)
+                else:
+                    # identity shortcut: d_out = dgrad_conv1(next) + d_pre(next)
+                    K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pre, addend=nxt["d_pre"], mask=out)
+                blk["d_pre"], blk["d_o1"] = d_pre, d_o1
+                # ---- inside the block
+                c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+                K.conv_wgrad(c3.geom, d_pre, o2, c3.slabs, c3.dbias_partials)
+                K.conv_dgrad(c3.geom, d_pre, c3.wft, d_o2, mask=o2)
+                K.conv_wgrad(c2.geom, d_o2, o1, c2.slabs, c2.dbias_partials)
+                K.conv_dgrad(c2.geom, d_o2, c2.wft, d_o1, mask=o1)
+                K.conv_wgrad(c1.geom, d_o1, blk["x"], c1.slabs, c1.dbias_partials)
+                if ds is not None:
+                    K.conv_wgrad(ds.geom, d_pre, blk["x"], ds.slabs, ds.dbias_partials)
+                    if ds.need_dgrad:
+                        blk["tmp_in"] = b[pfx + ".tmp_in"]
+                nxt = blk
+            if after_stage is not None:
+                after_stage(li)
+        return None
+

@@ -1,0 +1,214 @@
+"""Thin Python launchers over the C ABI (include/radet_hip.h): torch tensors are used only as device
+buffers (data_ptr) and for the current HIP stream.  No arithmetic happens in PyTorch here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "HIP kernels need contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Levels:
+    """Row-concatenated multi-level NHWC geometry: level l = B images of h_l x w_l pixels."""
+
+    def __init__(self, hw, B):
+        self.hw = [(int(h), int(w)) for h, w in hw]
+        self.B = int(B)
+        self.offsets = []
+        r = 0
+        for h, w in self.hw:
+            self.offsets.append(r)
+            r += self.B * h * w
+        self.rows = r
+
+    def __len__(self):
+        return len(self.hw)
+
+    def conv_out(self, k, stride, pad):
+        return Levels([((h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1) for h, w in self.hw], self.B)
+
+    def level_rows(self, l):
+        h, w = self.hw[l]
+        return self.offsets[l], self.offsets[l] + self.B * h * w
+
+    def sub(self, l):
+        return Levels([self.hw[l]], self.B)
+
+
+def _desc(pairs):
+    """pairs: list of (Hi, Wi, Ho, Wo, in_off, out_off) -> ctypes int array"""
+    flat = [int(v) for p in pairs for v in p]
+    return (C.c_int * len(flat))(*flat), len(pairs)
+
+
+class ConvGeom:
+    """Geometry of one convolution over a multi-level input (same weights on every level)."""
+
+    def __init__(self, lin, cin, cout, k, stride, pad):
+        self.lin, self.cin, self.cout, self.k, self.stride, self.pad = lin, cin, cout, k, stride, pad
+        self.lout = lin.conv_out(k, stride, pad)
+        self.B = lin.B
+        f, b = [], []
+        for (hi, wi), (ho, wo), io, oo in zip(lin.hw, self.lout.hw, lin.offsets, self.lout.offsets):
+            f.append((hi, wi, ho, wo, io, oo))
+            b.append((ho, wo, hi, wi, oo, io))   # dgrad: rows over the conv INPUT grid, gather from dy
+        self.fwd_desc, self.nseg = _desc(f)
+        self.bwd_desc, _ = _desc(b)
+        self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
+
+
+def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0):
+    _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), g.B, g.cin,
+              g.cout, g.k, g.k, g.stride, 1, -g.pad, 1, int(relu), g.fwd_desc, g.nseg, tile, _stream())
+
+
+def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0):
+    """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
+    kc = g.cout if k_channels is None else k_channels
+    _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), g.B, kc, g.cin, g.k,
+              g.k, 1, -1, g.pad, g.stride, 0, g.bwd_desc, g.nseg, tile, _stream())
+
+
+def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
+    co = g.cout if cout is None else cout
+    _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), g.B, g.cin, co,
+              co if ld_dy is None else ld_dy, g.k, g.k, g.stride, 1, -g.pad, 1, g.fwd_desc, g.nseg, g.nsplit, _stream())
+
+
+def fold_weights(table_dev, n):
+    _lib.call("radet_fold_weights", _ptr(table_dev), n, _stream())
+
+
+def unfold_grads(table_dev, n, max_cout):
+    _lib.call("radet_unfold_grads", _ptr(table_dev), n, max_cout, _stream())
+
+
+def stem(img, wf, bias, y, B, H, W):
+    _lib.call("radet_stem_conv_bn_relu", _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream())
+
+
+def maxpool(x, y, B, H, W, Cch):
+    _lib.call("radet_maxpool3x3s2", _ptr(x), _ptr(y), B, H, W, Cch, _stream())
+
+
+def gn_ws_floats(levels):
+    d, n = _desc([(h, w, h, w, o, o) for (h, w), o in zip(levels.hw, levels.offsets)])
+    return _lib.load().radet_gn_workspace_floats(levels.B, d, n)
+
+
+def _gn_desc(levels):
+    return _desc([(h, w, h, w, o, o) for (h, w), o in zip(levels.hw, levels.offsets)])
+
+
+def gn_relu_fwd(levels, z, gamma, beta, y, stats, ws, eps=1e-5, relu=True):
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_fwd", _ptr(z), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), levels.B, 256, 32,
+              eps, int(relu), d, n, _stream())
+
+
+def gn_relu_bwd(levels, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws, relu=True):
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_bwd", _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr(dgamma),
+              _ptr(dbeta), _ptr(ws), levels.B, 256, 32, int(relu), d, n, _stream())
+
+
+def upsample_add(dst, src, B, ho, wo, hi, wi, ch):
+    _lib.call("radet_upsample_add", _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _stream())
+
+
+def upsample_add_bwd(dsrc, ddst, B, ho, wo, hi, wi, ch):
+    _lib.call("radet_upsample_add_bwd", _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _stream())
+
+
+def relu_bwd(dy, addend, act, dx):
+    _lib.call("radet_relu_bwd", _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _stream())
+
+
+def nchw_to_nhwc(x, y, B, ch, H, W):
+    _lib.call("radet_nchw_to_nhwc", _ptr(x), _ptr(y), B, ch, H, W, _stream())
+
+
+def nhwc_to_nchw(x, y, B, ch, H, W):
+    _lib.call("radet_nhwc_to_nchw", _ptr(x), _ptr(y), B, ch, H, W, _stream())
+
+
+def level_desc(levels, strides):
+    flat = []
+    for (h, w), s in zip(levels.hw, strides):
+        flat += [h, w, int(s)]
+    return (C.c_int * len(flat))(*flat), len(levels.hw)
+
+
+def head_loss_ws_ints(R):
+    return _lib.load().radet_head_loss_ws_ints(R)
+
+
+def head_loss(cls, reg_u, iou, scales, gt_boxes, gt_labels, gt_off, p2g, pw, ldesc, nlvl, B, num_classes, alpha, gamma,
+              lbw, giou_eps, grad_scale, losses, dcls, dcls_ld, dreg, dreg_ld, diou, diou_ld, dscales, ws,
+              labels_out=None, tgt_out=None):
+    _lib.call("radet_head_loss", _ptr(cls), _ptr(reg_u), _ptr(iou), _ptr(scales), _ptr(gt_boxes), _ptr(gt_labels),
+              _ptr(gt_off), _ptr(p2g), _ptr(pw), ldesc, nlvl, B, num_classes, alpha, gamma, lbw, giou_eps,
+              _ptr(grad_scale), _ptr(losses), _ptr(dcls), dcls_ld, _ptr(dreg), dreg_ld, _ptr(diou), diou_ld,
+              _ptr(dscales), _ptr(labels_out), _ptr(tgt_out), _ptr(ws), _stream())
+
+
+def scale_relu(reg_u, scales, out, ldesc, nlvl, B):
+    _lib.call("radet_scale_relu", _ptr(reg_u), _ptr(scales), _ptr(out), ldesc, nlvl, B, _stream())
+
+
+def grid_anchors(out, ldesc, nlvl, base_scale=8):
+    _lib.call("radet_grid_anchors", _ptr(out), ldesc, nlvl, base_scale, _stream())
+
+
+def sqnorm_partials(g, n, partials):
+    _lib.call("radet_sqnorm_partials", _ptr(g), C.c_size_t(n), _ptr(partials), partials.numel(), _stream())
+
+
+def adamw_step(p, g, m, v, n, lr, betas, eps, wd, step, max_norm, grad_div, partials, grad_norm_out):
+    _lib.call("radet_adamw_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_size_t(n), lr, betas[0], betas[1], eps, wd,
+              step, max_norm, grad_div, _ptr(partials), partials.numel(), _ptr(grad_norm_out), _stream())
+
+
+def decode_ws_bytes(B, nlvl, nms_pre):
+    return int(_lib.load().radet_decode_ws_bytes(B, nlvl, nms_pre))
+
+
+def decode_candidates(cls, reg_u, iou, scales, ldesc, nlvl, B, num_classes, score_thr, nms_pre, img_hw, scale_factor,
+                      cand_boxes, cand_scores, cand_ctr, cand_labels, cand_count, ws):
+    _lib.call("radet_decode_candidates", _ptr(cls), _ptr(reg_u), _ptr(iou), _ptr(scales), ldesc, nlvl, B, num_classes,
+              score_thr, nms_pre, _ptr(img_hw), _ptr(scale_factor), _ptr(cand_boxes), _ptr(cand_scores), _ptr(cand_ctr),
+              _ptr(cand_labels), _ptr(cand_count), _ptr(ws), _stream())
+
+
+def nms_ws_bytes(B, cap):
+    return int(_lib.load().radet_nms_ws_bytes(B, cap))
+
+
+NMS_MODES = dict(vote=0, global_vote=1, cluster=2, nms=3)
+
+
+def nms(boxes, cluster_scores, vote_scores, labels, counts, B, cap, mode, iou_thr, iou_enable, sigma, max_out, out_boxes,
+        out_scores, out_labels, out_count, aux0, aux1, ws):
+    _lib.call("radet_nms", _ptr(boxes), _ptr(cluster_scores), _ptr(vote_scores), _ptr(labels), _ptr(counts), B, cap, mode,
+              iou_thr, int(iou_enable), sigma, max_out, _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels),
+              _ptr(out_count), _ptr(aux0), _ptr(aux1), _ptr(ws), _stream())
+
+
+def assign_ws_bytes(B, N):
+    return int(_lib.load().radet_assign_ws_bytes(B, N))
+
+
+def assign_points(gt_boxes, gt_off, masks, H, W, uniforms, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
+                  ws):
+    _lib.call("radet_assign_points", _ptr(gt_boxes), _ptr(gt_off), _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges,
+              nlvl, B, positive_num, neg_thr, _ptr(p2g), _ptr(pw), _ptr(used), _ptr(ws), _stream())

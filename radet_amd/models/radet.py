@@ -1,0 +1,116 @@
+"""RADet single-stage detector: same constructor, call signatures and outputs as
+radet/models/detectors/{base.py:65-253, single_stage.py:17-124, radet.py:8-32}."""
+import weakref
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from ..core import bbox2result
+from ..utils import to_config_dict
+from .builder import DETECTORS, build_backbone, build_head, build_neck
+
+
+@DETECTORS.register_module()
+class RADet(nn.Module):
+    def __init__(self, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        train_cfg, test_cfg = to_config_dict(train_cfg), to_config_dict(test_cfg)
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        bbox_head = dict(bbox_head)
+        bbox_head.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.fp16_enabled = False
+        self._runtime = None
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return self.neck is not None
+
+    @property
+    def with_bbox(self):
+        return self.bbox_head is not None
+
+    def init_weights(self, pretrained=None):
+        if pretrained is not None and not str(pretrained).startswith("torchvision://"):
+            sd = torch.load(pretrained, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            self.load_state_dict(sd, strict=False)
+        # 'torchvision://resnet50' needs network access; weights then come from load_state_dict by the caller
+
+    # ------------------------------------------------------------------ runtime
+    def runtime(self):
+        from ..runtime import DetectorRuntime
+        rt = self._runtime
+        if rt is None or not rt.flat.still_bound():
+            rt = DetectorRuntime(self, depth=self.backbone.depth, num_classes=self.bbox_head.num_classes,
+                                 frozen_stages=self.backbone.frozen_stages, strides=self.bbox_head.strides,
+                                 stacked_convs=self.bbox_head.stacked_convs)
+            object.__setattr__(self, "_runtime", rt)
+            ref = weakref.ref(rt)
+            for m in (self.backbone, self.neck, self.bbox_head):
+                object.__setattr__(m, "_runtime_ref", ref)
+            rt.owner = weakref.ref(self)
+        return rt
+
+    # ------------------------------------------------------------------ reference API
+    def extract_feat(self, img):
+        return self.runtime().extract_feat_api(img)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, points_to_gt_index, points_weight,
+                      gt_bboxes_ignore=None):
+        batch_input_shape = tuple(img[0].size()[-2:])
+        for m in img_metas:
+            m["batch_input_shape"] = batch_input_shape
+        return self.runtime().losses_autograd(img, gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        if not isinstance(imgs, list):
+            imgs, img_metas = [imgs], [img_metas]
+        if len(imgs) != len(img_metas):
+            raise ValueError(f"num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})")
+        if len(imgs) != 1:
+            raise NotImplementedError("test-time augmentation is out of scope (flip=False in the BOP configs)")
+        for m in img_metas[0]:
+            m["batch_input_shape"] = tuple(imgs[0].size()[-2:])
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
+    def simple_test(self, img, img_metas, rescale=False):
+        dets = self.runtime().detect(img, img_metas, self.test_cfg, rescale)
+        return [bbox2result(b, l, self.bbox_head.num_classes) for b, l in dets]
+
+    def _parse_losses(self, losses):
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f"{name} is not a tensor or list of tensors")
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["loss"] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["img_metas"]))
+
+    def val_step(self, data, optimizer):
+        return self.train_step(data, optimizer)

@@ -1,0 +1,416 @@
+"""Per-detector device runtime: flat parameter / gradient / optimiser-state arenas, the HIP Engine,
+target packing, the native train step (forward + hand-written backward + RCCL all-reduce overlapped
+with backward + fused clip/AdamW) and inference (decode + NMS).
+
+Replaces what the reference obtains from torch autograd + mmcv's DDP wrapper / OptimizerHook
+(radet/apis/train.py:73-126, radet/models/detectors/base.py:185-253).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from . import kernels as K
+from .engine import Engine
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """Re-points every floating-point parameter / buffer of `module` into flat fp32 arenas.
+
+    Trainable parameters (module order: backbone -> neck -> head, which is also the order of the
+    engine's conv table) form one arena with a same-layout gradient arena; the rest (frozen
+    parameters, BN running statistics) a second one."""
+
+    def __init__(self, module, device):
+        named = [(n, p) for n, p in module.named_parameters()]
+        train = [(n, p) for n, p in named if p.requires_grad]
+        frozen = [(n, p) for n, p in named if not p.requires_grad]
+        bufs = [(n, b) for n, b in module.named_buffers() if b.is_floating_point()]
+        self.train_names = [n for n, _ in train]
+        self.offsets = {}
+        off = 0
+        for n, p in train:
+            if p.numel() >= 4:
+                off = _align(off)
+            self.offsets[n] = off
+            off += p.numel()
+        self.n_train = _align(off)
+        self.params = torch.zeros(self.n_train, device=device)
+        self.grads = torch.zeros(self.n_train, device=device)
+        self.p, self.g = {}, {}
+        for n, p in train:
+            o = self.offsets[n]
+            v = self.params[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.p[n] = v
+            self.g[n] = self.grads[o:o + p.numel()].view(p.shape)
+        off = 0
+        foffs = {}
+        for n, t in frozen + bufs:
+            off = _align(off)
+            foffs[n] = off
+            off += t.numel()
+        self.frozen = torch.zeros(_align(off), device=device)
+        for n, p in frozen:
+            v = self.frozen[foffs[n]:foffs[n] + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            self.p[n] = v
+        for n, b in bufs:
+            v = self.frozen[foffs[n]:foffs[n] + b.numel()].view(b.shape)
+            v.copy_(b)
+            mod, _, leaf = n.rpartition(".")
+            owner = module.get_submodule(mod) if mod else module
+            owner._buffers[leaf] = v
+            self.p[n] = v
+        self._probe = train[0][1] if train else None
+
+    def group_ranges(self, prefixes):
+        """Contiguous [begin, end) ranges of the trainable arena per name-prefix group (in arena order)."""
+        out = []
+        for pf in prefixes:
+            names = [n for n in self.train_names if n.startswith(pf)]
+            if not names:
+                continue
+            b = self.offsets[names[0]]
+            last = names[-1]
+            e = self.offsets[last] + self.p[last].numel()
+            out.append((pf, b, e))
+        return out
+
+    def still_bound(self):
+        p = self._probe
+        return p is None or (p.data_ptr() == self.p[self.train_names[0]].data_ptr())
+
+
+class DetectorRuntime:
+    def __init__(self, det, depth, num_classes, frozen_stages, strides, stacked_convs=4):
+        dev = next(det.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.RadetHipError(
+                "radet_amd runs on MI355X only: move the detector to a HIP device (model.cuda()) first; "
+                "there is no CPU / PyTorch fallback path.")
+        _lib.load()
+        self.dev = dev
+        self.flat = FlatParams(det, dev)
+        self.engine = Engine(self.flat.p, self.flat.g, depth=depth, num_classes=num_classes,
+                             frozen_stages=frozen_stages, strides=strides, stacked_convs=stacked_convs)
+        self.num_classes, self.strides = num_classes, tuple(strides)
+        self.opt_state = None
+        self.step_count = 0
+        self.comm_stream = None
+        # conv-table ranges per gradient bucket, in backward order
+        names = [c.name for c in self.engine.convs]
+
+        def rng(pf):
+            idx = [i for i, n in enumerate(names) if n.startswith(pf)]
+            return (idx[0], idx[-1] + 1) if idx else None
+
+        self.buckets = []
+        for pf in ("bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2.",
+                   "backbone.layer1.", "backbone.conv1"):
+            r = rng(pf)
+            if r is None:
+                continue
+            tr = [c for c in self.engine.convs[r[0]:r[1]] if c.trainable]
+            if not tr:
+                continue
+            arena = self.flat.group_ranges([pf if pf != "backbone.conv1" else "backbone.conv1"])
+            if pf == "backbone.conv1":
+                arena = self.flat.group_ranges(["backbone.conv1", "backbone.bn1"])
+            b = min(a[1] for a in arena)
+            e = max(a[2] for a in arena)
+            self.buckets.append(dict(prefix=pf, convs=r, arena=(b, e)))
+
+    # ------------------------------------------------------------------ inputs
+    def pack_targets(self, gt_bboxes, gt_labels, points_to_gt_index, points_weight):
+        """list-per-image tensors (the reference's DataContainer layout) -> flat device tensors."""
+        dev = self.dev
+        B = len(gt_bboxes)
+        counts = [int(b.shape[0]) for b in gt_bboxes]
+        off = np.zeros(B + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        boxes = torch.cat([b.reshape(-1, 4).float() for b in gt_bboxes]) if sum(counts) else torch.zeros(0, 4)
+        labels = torch.cat([l.reshape(-1).long() for l in gt_labels]) if sum(counts) else torch.zeros(0, dtype=torch.long)
+        boxes = boxes.to(dev).contiguous()
+        labels = labels.to(dev).contiguous()
+        if boxes.shape[0] == 0:   # keep valid device pointers
+            boxes = torch.zeros(1, 4, device=dev)
+            labels = torch.zeros(1, dtype=torch.long, device=dev)
+        p2g = torch.stack([t.reshape(-1).long() for t in points_to_gt_index]).to(dev).contiguous()
+        pw = torch.stack([t.reshape(-1).float() for t in points_weight]).to(dev).contiguous()
+        return dict(boxes=boxes, labels=labels, off=torch.from_numpy(off).to(dev), p2g=p2g, pw=pw, B=B)
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, img, fold=True):
+        """img: NCHW fp32 device tensor. Runs fold -> backbone -> neck -> head. Returns engine buffers."""
+        assert img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3
+        img = img.contiguous()
+        e = self.engine
+        e.prepare(img.shape[0], img.shape[2], img.shape[3])
+        if fold:
+            e.fold()
+        feats = e.backbone_forward(img)
+        P = e.neck_forward(feats)
+        return e.head_forward(P)
+
+    def loss(self, tg, grad_scale=None, labels_out=None, tgt_out=None):
+        hp = getattr(self, "loss_hparams", None) or dict(alpha=0.25, gamma=2.0, lbw=2.0)
+        return self.engine.loss(tg["boxes"], tg["labels"], tg["off"], tg["p2g"], tg["pw"], grad_scale=grad_scale,
+                                labels_out=labels_out, tgt_out=tgt_out, **hp)
+
+    def backward(self, bucket_hook=None):
+        """Reverse program. After each parameter group's wgrads are done its slabs are reduced /
+        un-folded into the gradient arena and `bucket_hook(bucket)` may start its all-reduce."""
+        e = self.engine
+        table, sz = e.table, torch.tensor([], dtype=torch.uint8).element_size()
+        import ctypes as C
+        desc_bytes = C.sizeof(_lib.RadetConvDesc)
+
+        def unfold(bucket):
+            a, b = bucket["convs"]
+            K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
+            if bucket_hook is not None:
+                bucket_hook(bucket)
+
+        bk = {b["prefix"]: b for b in self.buckets}
+        dP = e.head_backward()
+        unfold(bk["bbox_head."])
+        d_feats = e.neck_backward(dP)
+        unfold(bk["neck."])
+        e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk[f"backbone.layer{li + 1}."]))
+        del sz
+
+    # ------------------------------------------------------------------ optimiser
+    def init_optimizer(self, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0):
+        n = self.flat.n_train
+        self.opt_state = dict(m=torch.zeros(n, device=self.dev), v=torch.zeros(n, device=self.dev), lr=lr, betas=betas,
+                              eps=eps, wd=weight_decay, max_norm=max_norm,
+                              partials=torch.zeros(1024, device=self.dev), grad_norm=torch.zeros(1, device=self.dev))
+        self.step_count = 0
+
+    def optimizer_step(self, lr=None, grad_div=1.0):
+        st = self.opt_state
+        self.step_count += 1
+        K.sqnorm_partials(self.flat.grads, self.flat.n_train, st["partials"])
+        K.adamw_step(self.flat.params, self.flat.grads, st["m"], st["v"], self.flat.n_train, st["lr"] if lr is None else lr,
+                     st["betas"], st["eps"], st["wd"], self.step_count, st["max_norm"], grad_div, st["partials"],
+                     st["grad_norm"])
+
+    # ------------------------------------------------------------------ data-parallel train step
+    def train_step(self, img, tg, lr=None):
+        """One optimisation step. With torch.distributed initialised (backend nccl = RCCL) gradients
+        are summed across ranks per bucket on a side stream while the backward of earlier layers is
+        still running; the mean (1/world) is folded into the fused clip+AdamW kernel."""
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.forward(img)
+        self.loss(tg)
+        if world > 1:
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream()
+            works = []
+
+            def hook(bucket):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                b, e = bucket["arena"]
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    works.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+            self.backward(hook)
+            for w in works:
+                w.wait()
+            main.wait_stream(self.comm_stream)
+        else:
+            self.backward()
+        self.optimizer_step(lr=lr, grad_div=float(world))
+        return self.engine.losses
+
+
+# ---------------------------------------------------------------------- autograd bridge (drop-in API)
+class _DetectorLossFn(torch.autograd.Function):
+    """losses = f(img, params): forward = engine forward + fused loss; backward = the engine's reverse
+    program. Gradients come back as clones of the gradient-arena views (autograd accumulates them)."""
+
+    @staticmethod
+    def forward(ctx, rt, img, tg, weights, *params):
+        rt.forward(img)
+        losses = rt.loss(tg)
+        ctx.rt, ctx.tg, ctx.weights = rt, tg, weights
+        out = losses * weights
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        rt = ctx.rt
+        gs = (torch.stack([g0.reshape(()), g1.reshape(()), g2.reshape(())]).float() * ctx.weights).contiguous()
+        rt.loss(ctx.tg, grad_scale=gs)       # head-output gradients scaled by the upstream gradients
+        rt.backward()
+        grads = tuple(rt.flat.g[n].clone() for n in rt.flat.train_names)
+        return (None, None, None, None) + grads
+
+
+def _losses_autograd(self, img, gt_bboxes, gt_labels, points_to_gt_index, points_weight):
+    det = self.owner()
+    head = det.bbox_head
+    tg = self.pack_targets(gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+    self.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
+                             lbw=float(head.loss_bbox.loss_weight))
+    weights = torch.tensor([head.loss_cls.loss_weight, 1.0, head.loss_iou.loss_weight], device=self.dev)
+    named = dict(det.named_parameters())
+    plist = [named[n] for n in self.flat.train_names]
+    l0, l1, l2 = _DetectorLossFn.apply(self, img.to(self.dev), tg, weights, *plist)
+    return dict(loss_cls=l0, loss_bbox=l1, loss_iou=l2)
+
+
+DetectorRuntime.losses_autograd = _losses_autograd
+
+
+def standalone_forward(module, part, x):
+    rt = getattr(module, "_runtime_ref", None)
+    if rt is None or rt() is None:
+        raise RuntimeError(f"{type(module).__name__} executes through its detector's MI355X runtime: build the "
+                           "detector with build_detector(cfg).cuda() and call it (or detector.extract_feat)")
+    rt = rt()
+    if part == "backbone":
+        return rt.backbone_api(x)
+    return rt.neck_api(x)
+
+
+# ---------------------------------------------------------------------- inference + module-level API
+def _detect(self, img, img_metas, test_cfg, rescale=False):
+    """simple_test: forward -> per-level threshold/top-k/decode -> NMS, all on the GPU, batched over
+    images; returns [(dets f32[K,5], labels i64[K])] per image on the device."""
+    with torch.no_grad():
+        self.forward(img.to(self.dev))
+        return self._postprocess(img_metas, test_cfg, rescale)
+
+
+def _postprocess(self, img_metas, test_cfg, rescale):
+    e = self.engine
+    B = e.B
+    b = e.buf
+    nlvl = e.nlvl
+    nms_pre = int(test_cfg.get("nms_pre", -1))
+    if nms_pre <= 0:
+        nms_pre = max(h * w for h, w in e.plv.hw) * self.num_classes
+    cap = nlvl * nms_pre
+    if cap > 8192:
+        raise NotImplementedError(f"nms_pre={nms_pre}: more than 8192 candidates per image exceed the on-chip NMS sort")
+    key = ("post", B, nms_pre)
+    if getattr(self, "_post_key", None) != key:
+        dev = self.dev
+        self._post = dict(
+            boxes=torch.empty(B, cap, 4, device=dev), scores=torch.empty(B, cap, device=dev),
+            ctr=torch.empty(B, cap, device=dev), labels=torch.empty(B, cap, dtype=torch.long, device=dev),
+            count=torch.zeros(B, dtype=torch.int32, device=dev), cscore=torch.empty(B, cap, device=dev),
+            dws=torch.empty(K.decode_ws_bytes(B, nlvl, nms_pre), dtype=torch.uint8, device=dev),
+            nws=torch.empty(K.nms_ws_bytes(B, cap), dtype=torch.uint8, device=dev),
+            aux0=torch.zeros(B, cap, dtype=torch.long, device=dev), aux1=torch.zeros(B, cap, dtype=torch.long, device=dev))
+        self._post_key = key
+    p = self._post
+    hw = torch.tensor([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], device=self.dev)
+    sf = None
+    if rescale:
+        sf = torch.tensor(np.stack([np.asarray(m["scale_factor"], np.float32).reshape(4) for m in img_metas]), device=self.dev)
+    K.decode_candidates(b["cls"], b["reg_u"], b["iou"], e.scales_tensor(), e.ldesc, nlvl, B, self.num_classes,
+                        float(test_cfg["score_thr"]), nms_pre, hw, sf, p["boxes"], p["scores"], p["ctr"], p["labels"],
+                        p["count"], p["dws"])
+    ncfg = dict(test_cfg["nms"])
+    typ = ncfg.get("type")
+    max_per_img = int(test_cfg.get("max_per_img", 100))
+    k = max_per_img if max_per_img > 0 else cap
+    ob = torch.zeros(B, k, 4, device=self.dev)
+    osc = torch.zeros(B, k, device=self.dev)
+    ol = torch.zeros(B, k, dtype=torch.long, device=self.dev)
+    oc = torch.zeros(B, dtype=torch.int32, device=self.dev)
+    if typ in ("vote", "global_vote"):
+        ctype, vtype = ncfg.get("cluster_score", "cls"), ncfg.get("vote_score", "iou")
+        prod = None
+
+        def pick(t):
+            nonlocal prod
+            if isinstance(t, (list, tuple)):
+                if prod is None:
+                    prod = p["cscore"]
+                    torch.mul(p["scores"], p["ctr"], out=prod)   # elementwise product of two sigmoid outputs (plumbing)
+                return prod
+            return p["scores"] if t == "cls" else p["ctr"]
+        K.nms(p["boxes"], pick(ctype), pick(vtype), p["labels"], p["count"], B, cap, K.NMS_MODES[typ],
+              float(ncfg.get("iou_threshold", 0.6)), bool(ncfg.get("iou_enable", False)), float(ncfg.get("sigma", 0.025)),
+              max_per_img, ob, osc, ol, oc, p["aux0"], p["aux1"], p["nws"])
+    else:
+        torch.mul(p["scores"], p["ctr"], out=p["cscore"])
+        K.nms(p["boxes"], p["cscore"], p["cscore"], p["labels"], p["count"], B, cap, 3,
+              float(ncfg.get("iou_threshold", 0.5)), False, 0.0, k, ob, osc, ol, oc, p["aux0"], p["aux1"], p["nws"])
+    counts = oc.cpu().numpy()
+    out = []
+    for i in range(B):
+        kk = int(counts[i])
+        out.append((torch.cat([ob[i, :kk], osc[i, :kk, None]], -1), ol[i, :kk]))
+    return out
+
+
+def _rows_to_nchw(self, rows, levels, ch):
+    """Row-major NHWC level slices -> list of NCHW tensors (module-API outputs)."""
+    outs = []
+    for i, (h, w) in enumerate(levels.hw):
+        r0, r1 = levels.level_rows(i)
+        t = torch.empty(levels.B, ch, h, w, device=self.dev)
+        K.nhwc_to_nchw(rows[r0:r1], t, levels.B, ch, h, w)
+        outs.append(t)
+    return outs
+
+
+def _extract_feat_api(self, img):
+    with torch.no_grad():
+        img = img.to(self.dev).contiguous()
+        e = self.engine
+        e.prepare(img.shape[0], img.shape[2], img.shape[3])
+        e.fold()
+        P = e.neck_forward(e.backbone_forward(img))
+        return tuple(_rows_to_nchw(self, P, e.plv, e.feat))
+
+
+def _backbone_api(self, img):
+    with torch.no_grad():
+        img = img.to(self.dev).contiguous()
+        e = self.engine
+        e.prepare(img.shape[0], img.shape[2], img.shape[3])
+        e.fold()
+        feats = e.backbone_forward(img)
+        outs = []
+        for li, f in enumerate(feats):
+            lv = e.stages[li][-1]["lout"]
+            outs.append(_rows_to_nchw(self, f, lv, f.shape[1])[0])
+        return tuple(outs)
+
+
+def _head_forward_api(self, feats):
+    """feats: tuple of NCHW P3..P7 (as produced by extract_feat). Returns (cls_scores, bbox_preds, iou_preds)
+    lists of NCHW tensors, bbox_preds already Scale'd + ReLU'd like RADetHead.forward_single."""
+    with torch.no_grad():
+        e = self.engine
+        B = feats[0].shape[0]
+        P = e.buf["P"]
+        for i, f in enumerate(feats):
+            r0, r1 = e.plv.level_rows(i)
+            K.nchw_to_nhwc(f.to(self.dev).contiguous(), P[r0:r1], B, e.feat, f.shape[2], f.shape[3])
+        cls, reg_u, iou = e.head_forward(P)
+        reg = torch.empty_like(reg_u)
+        K.scale_relu(reg_u, e.scales_tensor(), reg, e.ldesc, e.nlvl, B)
+        return (_rows_to_nchw(self, cls, e.plv, self.num_classes), _rows_to_nchw(self, reg, e.plv, 4),
+                _rows_to_nchw(self, iou, e.plv, 1))
+
+
+DetectorRuntime.detect = _detect
+DetectorRuntime._postprocess = _postprocess
+DetectorRuntime.extract_feat_api = _extract_feat_api
+DetectorRuntime.backbone_api = _backbone_api
+DetectorRuntime.head_forward_api = _head_forward_api

@@ -1,0 +1,437 @@
+"""GPU parity tests (pytest -m gpu): every HIP kernel is called through the C ABI and compared with
+the oracle / golden vectors (ints bit-exact, fp32 within the stated tolerance)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: fp32 boxes / scores within 1e-4
+
+
+@pytest.fixture(scope="module")
+def K():
+    from radet_amd import kernels
+    return kernels
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def to_rows(x):   # NCHW -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def from_rows(r, B, H, W):
+    return r.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def fold_w(w):    # OIHW -> [O][kh*kw][I]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, w.shape[1]).contiguous()
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, tile
+    (2, 64, 64, 20, 24, 1, 1, 0),
+    (2, 64, 256, 20, 24, 1, 1, 0),
+    (1, 128, 128, 17, 23, 3, 1, 0),
+    (2, 128, 128, 18, 22, 3, 2, 0),
+    (2, 256, 512, 15, 20, 1, 2, 0),
+    (1, 256, 21, 15, 20, 3, 1, 0),
+    (1, 256, 4, 9, 11, 3, 1, 0),
+    (1, 256, 1, 9, 11, 3, 1, 0),
+    (2, 256, 256, 30, 40, 3, 1, 1),
+    (2, 256, 256, 30, 40, 3, 1, 2),
+    (2, 256, 256, 30, 40, 3, 1, 3),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(K, case):
+    B, Cin, Cout, H, W, k, s, tile = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y_ref = F.conv2d(xd, wd, bias.double(), stride=s, padding=pad)
+    Ho, Wo = y_ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g)
+    out_ref = F.relu(y_ref + res.double())
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    gx, gw = torch.autograd.grad(y_ref, (xd, wd), dy.double())
+
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
+    y = torch.empty(B * Ho * Wo, Cout, device=dev)
+    K.conv_fwd(geom, xr, wf, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)
+    assert rel_err(from_rows(y, B, Ho, Wo), out_ref) < 2e-6
+    # dgrad (needs K = Cout multiple of 16 -> pad like the engine does for the small predictors)
+    kc = (Cout + 15) // 16 * 16
+    dyr = torch.zeros(B * Ho * Wo, kc, device=dev)
+    dyr[:, :Cout] = to_rows(dy).to(dev)
+    wft = torch.zeros(Cin, k * k, kc, device=dev)
+    wft[:, :, :Cout] = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).to(dev)
+    dx = torch.empty(B * H * W, Cin, device=dev)
+    mask = to_rows(torch.randn(B, Cin, H, W, generator=g)).to(dev)
+    K.conv_dgrad(geom, dyr, wft.contiguous(), dx, mask=mask, k_channels=kc, tile=tile)
+    gx_m = gx * (from_rows(mask.cpu(), B, H, W) > 0)
+    assert rel_err(from_rows(dx, B, H, W), gx_m) < 2e-6
+    # wgrad + fused bias partials
+    S = geom.nsplit
+    slabs = torch.empty(S, Cout, k * k, Cin, device=dev)
+    bp = torch.empty(S, Cout, device=dev)
+    K.conv_wgrad(geom, dyr, xr, slabs, bp, cout=Cout, ld_dy=kc)
+    gw_mine = slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(gw_mine, gw) < 5e-6
+    assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 5e-6
+
+
+def test_conv_multilevel(K):
+    """Five pyramid levels in one launch == per-level convs."""
+    B, Cch = 2, 256
+    hw = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(Cch, Cch, 3, 3, generator=g) / (Cch * 9) ** 0.5
+    xs = [torch.randn(B, Cch, h, ww, generator=g) for h, ww in hw]
+    lv = K.Levels(hw, B)
+    geom = K.ConvGeom(lv, Cch, Cch, 3, 1, 1)
+    xr = torch.cat([to_rows(x) for x in xs]).cuda()
+    y = torch.empty(lv.rows, Cch, device="cuda")
+    K.conv_fwd(geom, xr, fold_w(w).cuda(), None, y)
+    for i, x in enumerate(xs):
+        r0, r1 = lv.level_rows(i)
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        assert rel_err(from_rows(y[r0:r1], B, *hw[i]), ref) < 2e-6
+
+
+def test_stem_maxpool(K):
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 70, 90
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bias = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(img.double(), w.double(), bias.double(), stride=2, padding=3))
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty(B * Ho * Wo, 64, device="cuda")
+    K.stem(img.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), bias.cuda(), y, B, H, W)
+    assert rel_err(from_rows(y, B, Ho, Wo), ref) < 2e-6
+    pref = F.max_pool2d(ref, 3, 2, 1)
+    Hp, Wp = pref.shape[2:]
+    p = torch.empty(B * Hp * Wp, 64, device="cuda")
+    K.maxpool(y, p, B, Ho, Wo, 64)
+    assert rel_err(from_rows(p, B, Hp, Wp), F.max_pool2d(from_rows(y.cpu(), B, Ho, Wo).double(), 3, 2, 1)) == 0.0
+
+
+def test_groupnorm_fwd_bwd(K):
+    B, Cch = 2, 256
+    hw = [(9, 13), (5, 7), (3, 3), (2, 1), (1, 1)]
+    g = torch.Generator().manual_seed(2)
+    lv = K.Levels(hw, B)
+    xs = [(torch.randn(B, Cch, h, w, generator=g) * 2 + 0.5).double().requires_grad_(True) for h, w in hw]
+    gamma = (torch.rand(Cch, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(Cch, generator=g) * 0.3).double().requires_grad_(True)
+    ys = [F.relu(F.group_norm(x, 32, gamma, beta, 1e-5)) for x in xs]
+    dys = [torch.randn(B, Cch, h, w, generator=g) for h, w in hw]
+    grads = torch.autograd.grad(ys, xs + [gamma, beta], [d.double() for d in dys])
+    dev = "cuda"
+    z = torch.cat([to_rows(x.detach().float()) for x in xs]).to(dev)
+    y = torch.empty_like(z)
+    stats = torch.empty(len(hw) * B * 64, device=dev)
+    ws = torch.empty(K.gn_ws_floats(lv), device=dev)
+    gm, bt = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    K.gn_relu_fwd(lv, z, gm, bt, y, stats, ws)
+    for i in range(len(hw)):
+        r0, r1 = lv.level_rows(i)
+        assert rel_err(from_rows(y[r0:r1], B, *hw[i]), ys[i].detach()) < 1e-5
+    dy = torch.cat([to_rows(d) for d in dys]).to(dev)
+    dz = torch.empty_like(z)
+    dg, db = torch.empty(Cch, device=dev), torch.empty(Cch, device=dev)
+    K.gn_relu_bwd(lv, dy, z, stats, gm, bt, dz, dg, db, ws)
+    for i in range(len(hw)):
+        r0, r1 = lv.level_rows(i)
+        assert rel_err(from_rows(dz[r0:r1], B, *hw[i]), grads[i]) < 2e-5
+    assert rel_err(dg, grads[-2]) < 2e-5 and rel_err(db, grads[-1]) < 2e-5
+
+
+def test_upsample_add(K):
+    g = torch.Generator().manual_seed(3)
+    B, Cch = 2, 256
+    for (ho, wo), (hi, wi) in [((60, 80), (30, 40)), ((13, 13), (7, 7)), ((25, 25), (13, 13))]:
+        dst = torch.randn(B, Cch, ho, wo, generator=g)
+        src = torch.randn(B, Cch, hi, wi, generator=g).double().requires_grad_(True)
+        up = F.interpolate(src, size=(ho, wo), mode="nearest")
+        ref = dst.double() + up
+        d = to_rows(dst).cuda()
+        K.upsample_add(d, to_rows(src.detach().float()).cuda(), B, ho, wo, hi, wi, Cch)
+        assert rel_err(from_rows(d, B, ho, wo), ref.detach()) < 1e-6
+        dd = torch.randn(B, Cch, ho, wo, generator=g)
+        gs, = torch.autograd.grad(up, src, dd.double())
+        base = torch.randn(B, Cch, hi, wi, generator=g)
+        ds = to_rows(base).cuda()
+        K.upsample_add_bwd(ds, to_rows(dd).cuda(), B, ho, wo, hi, wi, Cch)
+        assert rel_err(from_rows(ds, B, hi, wi), base.double() + gs) < 1e-5
+
+
+LEVEL_HW = [(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)]
+STRIDES = (8, 16, 32, 64, 128)
+
+
+def synth_head_outputs(seed, B, cls_mean=-2.0):
+    g = torch.Generator().manual_seed(seed)
+    cls, reg, iou = [], [], []
+    for (h, w) in LEVEL_HW:
+        cls.append(torch.randn(B, 21, h, w, generator=g) * 1.5 + cls_mean)
+        reg.append(torch.relu(torch.randn(B, 4, h, w, generator=g) * 2.0 + 2.5))
+        iou.append(torch.randn(B, 1, h, w, generator=g))
+    return cls, reg, iou
+
+
+def flat(ts):
+    return torch.cat([to_rows(t) for t in ts])
+
+
+def pack_targets(golden, tags, dev):
+    a = golden("assigner")
+    boxes = [a[t + "_boxes"] for t in tags]
+    counts = [b.shape[0] for b in boxes]
+    off = np.zeros(len(tags) + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    return dict(boxes=torch.from_numpy(np.concatenate(boxes)).to(dev),
+                labels=torch.from_numpy(np.concatenate([a[t + "_labels"] for t in tags])).to(dev),
+                off=torch.from_numpy(off).to(dev),
+                p2g=torch.from_numpy(np.stack([a[t + "_p2g"].astype(np.int64) for t in tags])).to(dev),
+                pw=torch.from_numpy(np.stack([a[t + "_w"] for t in tags])).to(dev))
+
+
+def run_head_loss(K, cls, reg, iou, tg, B, scales=None, grad_scale=None, dumps=False):
+    dev = "cuda"
+    lv = K.Levels(LEVEL_HW, B)
+    ld, nl = K.level_desc(lv, STRIDES)
+    R = lv.rows
+    fc, fr, fi = flat(cls).to(dev), flat(reg).to(dev), flat(iou).reshape(-1).contiguous().to(dev)
+    sc = torch.ones(5, device=dev) if scales is None else scales
+    out = dict(losses=torch.zeros(3, device=dev), dcls=torch.zeros(R, 21, device=dev), dreg=torch.zeros(R, 4, device=dev),
+               diou=torch.zeros(R, device=dev), dsc=torch.zeros(5, device=dev))
+    ws = torch.zeros(K.head_loss_ws_ints(R), dtype=torch.int32, device=dev)
+    lab = torch.zeros(R, dtype=torch.long, device=dev) if dumps else None
+    tgt = torch.zeros(R, 4, device=dev) if dumps else None
+    K.head_loss(fc, fr, fi, sc, tg["boxes"], tg["labels"], tg["off"], tg["p2g"], tg["pw"], ld, nl, B, 21, 0.25, 2.0, 2.0,
+                1e-6, grad_scale, out["losses"], out["dcls"], 21, out["dreg"], 4, out["diou"], 1, out["dsc"], ws, lab, tgt)
+    out["labels"], out["tgt"], out["ws"] = lab, tgt, ws
+    return out
+
+
+def test_head_loss_vs_reference_golden(K, golden):
+    g = golden("head_loss")
+    cls, reg, iou = synth_head_outputs(7, 2)
+    tg = pack_targets(golden, ("g8", "g3"), "cuda")
+    o = run_head_loss(K, cls, reg, iou, tg, 2, dumps=True)
+    L = o["losses"].cpu().numpy()
+    for i, k in enumerate(("loss_cls", "loss_bbox", "loss_iou")):
+        assert abs(L[i] - float(g[k])) <= TOL * max(1.0, abs(float(g[k]))), (k, L[i], float(g[k]))
+    assert np.array_equal(o["labels"].cpu().numpy(), g["labels"].astype(np.int64))      # index parity: bit-exact
+    pos = torch.from_numpy(g["pos"])
+    P = int(o["ws"][0].item())
+    assert P == pos.numel() and np.array_equal(o["ws"][16:16 + P].cpu().numpy(), g["pos"])
+    assert np.array_equal(o["tgt"].cpu()[pos].numpy(), g["bbox_targets_pos"])             # TBLR targets: bit-exact
+    assert float(o["tgt"].abs().sum()) == float(np.abs(g["bbox_targets_pos"]).sum())
+    dc, dr, di = o["dcls"].cpu(), o["dreg"].cpu(), o["diou"].cpu()
+    assert np.allclose(dc[::7].numpy(), g["g_cls_rows"], rtol=TOL, atol=1e-9)
+    assert np.allclose(dc[pos].numpy(), g["g_cls_pos"], rtol=TOL, atol=1e-9)
+    assert np.allclose(dr[pos].numpy(), g["g_reg_pos"], rtol=TOL, atol=1e-8)
+    assert np.allclose(di[pos].numpy(), g["g_iou_pos"].reshape(-1), rtol=TOL, atol=1e-9)
+    assert np.isclose(dr.double().abs().sum().item(), float(g["g_reg_abs"]), rtol=TOL)   # zero outside positives
+    assert np.isclose(di.double().abs().sum().item(), float(g["g_iou_abs"]), rtol=TOL)
+
+
+def test_head_loss_no_gt_and_scales(K, golden):
+    g = golden("head_loss")
+    cls, reg, iou = synth_head_outputs(8, 2)
+    dev = "cuda"
+    tg = dict(boxes=torch.zeros(1, 4, device=dev), labels=torch.zeros(1, dtype=torch.long, device=dev),
+              off=torch.zeros(3, dtype=torch.int32, device=dev), p2g=torch.full((2, 6400), -1, dtype=torch.long, device=dev),
+              pw=torch.ones(2, 6400, device=dev))
+    o = run_head_loss(K, cls, reg, iou, tg, 2)
+    L = o["losses"].cpu().numpy()
+    assert abs(L[0] - float(g["e_loss_cls"])) <= TOL * float(g["e_loss_cls"]) and L[1] == 0.0 and L[2] == 0.0
+    assert float(o["dreg"].abs().sum()) == 0.0 and float(o["diou"].abs().sum()) == 0.0
+    assert np.isclose(o["dcls"].double().abs().sum().item(), float(g["e_g_cls_abs"]), rtol=TOL)
+    # Scale parameters + upstream gradient scaling vs the oracle (autograd through relu(scale * u))
+    from oracle import model as om
+    a = golden("assigner")
+    tags = ("g8", "g3")
+    cls, reg, iou = synth_head_outputs(11, 2)
+    gsc = torch.Generator().manual_seed(4)
+    reg_u = [torch.randn(r.shape, generator=gsc) * 2 + 1.5 for r in reg]
+    scales = torch.tensor([0.8, 1.1, 0.9, 1.3, 0.7], requires_grad=True)
+    for t in cls + reg_u + iou:
+        t.requires_grad_(True)
+    regs = [F.relu(u * scales[i]) for i, u in enumerate(reg_u)]
+    losses, _ = om.head_loss(cls, regs, iou, [torch.from_numpy(a[t + "_boxes"]) for t in tags],
+                             [torch.from_numpy(a[t + "_labels"]) for t in tags],
+                             [torch.from_numpy(a[t + "_p2g"].astype(np.int64)) for t in tags],
+                             [torch.from_numpy(a[t + "_w"]) for t in tags])
+    up = torch.tensor([0.5, 2.0, 3.0])
+    (losses["loss_cls"] * up[0] + losses["loss_bbox"] * up[1] + losses["loss_iou"] * up[2]).backward()
+    tg = pack_targets(golden, tags, dev)
+    o = run_head_loss(K, cls, reg_u, iou, tg, 2, scales=scales.detach().to(dev), grad_scale=up.to(dev))
+    assert np.allclose(o["losses"].cpu().numpy(), [losses[k].item() for k in ("loss_cls", "loss_bbox", "loss_iou")], rtol=TOL)
+    assert np.allclose(o["dsc"].cpu().numpy(), scales.grad.numpy(), rtol=5e-4, atol=1e-7)
+    assert rel_err(o["dreg"], flat([u.grad for u in reg_u])) < 5e-4
+    assert rel_err(o["dcls"], flat([c.grad for c in cls])) < 5e-4
+    assert rel_err(o["diou"], flat([c.grad for c in iou]).reshape(-1)) < 5e-4
+
+
+VOTE_CFG = dict(type="vote", iou_threshold=0.65, cluster_score=["cls", "iou"], vote_score=["iou", "cls"],
+                iou_enable=False, sima=0.025)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_nms_ops_bit_exact(golden, tag):
+    """radet.ops API on the GPU == the reference's C++ ops (golden), bit for bit."""
+    from radet_amd import ops
+    g = golden("nms")
+    bx, cl, ct, lb = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("boxes", "cls", "ctr", "labels"))
+    b, l = ops.vote_nms(bx, cl, lb, VOTE_CFG, score_factor=ct)
+    assert np.array_equal(l.numpy(), g[tag + "_vote_l"]) and np.array_equal(b.numpy(), g[tag + "_vote_b"])
+    b, l = ops.vote_nms(bx, cl, lb, VOTE_CFG, score_factor=ct, max_num=100)
+    assert np.array_equal(b.numpy(), g[tag + "_vote_b"][:100])
+    b, l = ops.global_vote_nms(bx, cl, lb, VOTE_CFG, score_factor=ct)
+    assert np.array_equal(l.numpy(), g[tag + "_gvote_l"]) and np.array_equal(b.numpy(), g[tag + "_gvote_b"])
+    ids, num = ops.cluster_nms(bx.numpy(), (cl * ct).numpy(), lb.numpy(), 0.65)
+    assert np.array_equal(ids.numpy(), g[tag + "_cl_ids"]) and np.array_equal(num.numpy(), g[tag + "_cl_num"])
+    from oracle import nms as onms
+    dets, keep = ops.batched_nms(bx, cl * ct, lb, dict(type="nms", iou_threshold=0.5))
+    odets, okeep = onms.batched_nms(bx.numpy(), (cl * ct).numpy(), lb.numpy(), 0.5)
+    assert np.array_equal(keep.numpy(), okeep) and np.array_equal(dets.numpy(), odets)
+
+
+def test_nms_edge_cases():
+    from radet_amd import ops
+    b, l = ops.vote_nms(torch.zeros(0, 4), torch.zeros(0), torch.zeros(0, dtype=torch.long), VOTE_CFG,
+                        score_factor=torch.zeros(0))
+    assert tuple(b.shape) == (0, 5) and tuple(l.shape) == (0,)
+    b, l = ops.vote_nms(torch.tensor([[1., 2., 30., 40.]]), torch.tensor([0.5]), torch.tensor([3]), VOTE_CFG,
+                        score_factor=torch.tensor([0.5]))
+    assert np.allclose(b.numpy(), [[1, 2, 30, 40, 0.25]]) and l.tolist() == [3]
+    # 8192 boxes (capacity), one label, identical boxes -> a single cluster
+    n = 8192
+    bx = torch.tensor([[10., 10., 50., 60.]]).repeat(n, 1)
+    sc = torch.linspace(0.9, 0.1, n)
+    b, l = ops.vote_nms(bx, sc, torch.zeros(n, dtype=torch.long), VOTE_CFG, score_factor=torch.ones(n))
+    assert b.shape[0] == 1 and np.allclose(b[0, :4].numpy(), [10, 10, 50, 60], atol=1e-3) and abs(b[0, 4].item() - 0.9) < 1e-6
+
+
+def test_decode_and_nms_vs_reference_golden(K, golden):
+    """radet_decode_candidates + radet_nms on synthetic head outputs == reference get_bboxes."""
+    g = golden("get_bboxes")
+    cls, reg, iou = synth_head_outputs(9, 2, cls_mean=-4.0)
+    dev = "cuda"
+    B = 2
+    lv = K.Levels(LEVEL_HW, B)
+    ld, nl = K.level_desc(lv, STRIDES)
+    fc, fr, fi = flat(cls).to(dev), flat(reg).to(dev), flat(iou).reshape(-1).contiguous().to(dev)
+    cap = 5000
+    boxes, scores, ctr = torch.empty(B, cap, 4, device=dev), torch.empty(B, cap, device=dev), torch.empty(B, cap, device=dev)
+    labels, count = torch.empty(B, cap, dtype=torch.long, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+    ws = torch.empty(K.decode_ws_bytes(B, 5, 1000), dtype=torch.uint8, device=dev)
+    hw = torch.tensor([[480., 640.]] * B, device=dev)
+    sf = torch.ones(B, 4, device=dev)
+    K.decode_candidates(fc, fr, fi, torch.ones(5, device=dev), ld, nl, B, 21, 0.05, 1000, hw, sf, boxes, scores, ctr, labels,
+                        count, ws)
+    n_ref = int((torch.cat([to_rows(c) for c in cls]).sigmoid() > 0.05).sum())
+    assert abs(int(count.sum()) - min(n_ref, int(count.sum()))) == 0 and int(count.sum()) > 2000
+    for mode, name in ((0, "vote"), (1, "global_vote")):
+        cs = (scores * ctr).contiguous()
+        ob, osc = torch.zeros(B, 100, 4, device=dev), torch.zeros(B, 100, device=dev)
+        ol, oc = torch.zeros(B, 100, dtype=torch.long, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+        a0 = torch.zeros(B, cap, dtype=torch.long, device=dev)
+        nws = torch.empty(K.nms_ws_bytes(B, cap), dtype=torch.uint8, device=dev)
+        K.nms(boxes, cs, cs, labels, count, B, cap, mode, 0.65, False, 0.025, 100, ob, osc, ol, oc, a0, a0.clone(), nws)
+        for i in range(B):
+            k = int(oc[i])
+            ref_b, ref_l = g[f"{name}_{i}_b"], g[f"{name}_{i}_l"]
+            assert k == ref_b.shape[0]
+            assert np.array_equal(ol[i, :k].cpu().numpy(), ref_l)
+            assert np.allclose(ob[i, :k].cpu().numpy(), ref_b[:, :4], rtol=TOL, atol=1e-3)
+            assert np.allclose(osc[i, :k].cpu().numpy(), ref_b[:, 4], rtol=TOL, atol=1e-7)
+
+
+ASSIGN_TAGS = ["g0", "g1", "g8", "g8b", "g20", "g3"]
+
+
+def test_assigner_bit_exact(golden):
+    """GPU assigner, whole batch in one launch, == reference LabelAssignment for the same NumPy seeds."""
+    from radet_amd.datasets import LabelAssignment
+    g = golden("assigner")
+    la = LabelAssignment(anchor_generator_cfg=None, neg_threshold=0.2, positive_num=10, adapt_positive_num=False,
+                         balance_sample=True)
+    boxes, masks, rngs = [], [], []
+    for t in ASSIGN_TAGS:
+        G = g[t + "_boxes"].shape[0]
+        boxes.append(g[t + "_boxes"])
+        masks.append(np.unpackbits(g[t + "_masks"], axis=1).reshape(G, 480, 640) if G else np.zeros((0, 480, 640), np.uint8))
+        rngs.append(np.random.RandomState(int(g[t + "_npseed"])))
+    p2g, pw = la.assign_batch(boxes, masks, (480, 640, 3), rngs=rngs)
+    p2g, pw = p2g.cpu().numpy(), pw.cpu().numpy()
+    for i, t in enumerate(ASSIGN_TAGS):
+        assert np.array_equal(p2g[i], g[t + "_p2g"].astype(np.int64)), t
+        assert np.array_equal(pw[i], g[t + "_w"]), t
+        # RNG left exactly where the reference leaves it
+        probe = np.random.RandomState(int(g[t + "_npseed"]))
+        probe.random_sample(int(g[t + "_used"]))
+        assert rngs[i].random_sample() == probe.random_sample()
+
+
+def test_assigner_all_masks_empty():
+    """No visible pixel: every candidate has p = 1e-8, sum needs NumPy's pairwise order; compare with the oracle."""
+    from oracle import assigner as oa
+    from radet_amd.datasets import LabelAssignment
+    boxes = np.array([[100, 80, 420, 400], [30, 30, 90, 100]], np.float32)
+    masks = np.zeros((2, 480, 640), np.uint8)
+    la = LabelAssignment(neg_threshold=0.2, positive_num=10, balance_sample=True)
+    p2g, pw = la.assign_batch([boxes], [masks], (480, 640, 3), rngs=[np.random.RandomState(77)])
+    rp, rw = oa.assign_points(boxes, np.zeros(2, np.int64), masks, (480, 640, 3), rng=np.random.RandomState(77))
+    assert np.array_equal(p2g[0].cpu().numpy(), rp) and np.array_equal(pw[0].cpu().numpy(), rw)
+
+
+def test_adamw_clip_step(K):
+    g = torch.Generator().manual_seed(9)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    ps = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ps], lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    dev = "cuda"
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    parts, gn = torch.zeros(256, device=dev), torch.zeros(1, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.05)
+        ps.grad = gr.clone().double()
+        tn = torch.nn.utils.clip_grad_norm_([ps], 35.0)
+        opt.step()
+        gd = gr.to(dev)
+        K.sqnorm_partials(gd, n, parts)
+        K.adamw_step(p, gd, m, v, n, 4e-4, (0.9, 0.999), 1e-8, 0.05, step, 35.0, 1.0, parts, gn)
+        assert abs(gn.item() - tn.item()) <= 1e-5 * tn.item()
+        assert rel_err(p, ps.detach()) < 1e-6
+
+
+def test_anchors(golden):
+    from radet_amd.core import build_anchor_generator
+    ag = build_anchor_generator(dict(type="AnchorGenerator", ratios=[1.0], octave_base_scale=8, scales_per_octave=1,
+                                     strides=[8, 16, 32, 64, 128]))
+    g = golden("anchors")
+    for tag in ("a480x640", "a800x800"):
+        sizes = [tuple(int(v) for v in s) for s in g[tag + "_sizes"]]
+        a = torch.cat(ag.grid_anchors(sizes, device="cuda")).cpu().numpy()
+        assert np.array_equal(a, g[tag])

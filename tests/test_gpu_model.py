@@ -1,0 +1,123 @@
+"""Whole-detector parity on the GPU against the reference's own outputs (tests/golden/model.npz):
+drop-in config -> build_detector -> forward_train / backward / simple_test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def det():
+    from oracle import synth
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    d = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(d.state_dict(), seed=0)
+    return d.cuda()
+
+
+def targets(golden, tags=("g8", "g3")):
+    a = golden("assigner")
+    return ([torch.from_numpy(a[t + "_boxes"]) for t in tags], [torch.from_numpy(a[t + "_labels"]) for t in tags],
+            [torch.from_numpy(a[t + "_p2g"].astype(np.int64)) for t in tags], [torch.from_numpy(a[t + "_w"]) for t in tags])
+
+
+def nchw_flat(ts):
+    return torch.cat([t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]) for t in ts])
+
+
+def test_features_and_head_outputs(det, golden):
+    from oracle import synth
+    g = golden("model")
+    img = synth.synth_images(0, 2).cuda()
+    det.eval()
+    cf = det.backbone(img)
+    for i, f in enumerate(cf):
+        v = f.reshape(-1)[torch.from_numpy(g[f"c{i + 2}_idx"]).cuda()].cpu().numpy()
+        assert np.allclose(v, g[f"c{i + 2}_val"], rtol=1e-4, atol=1e-4 * float(g[f"c{i + 2}_absmean"])), f"C{i + 2}"
+    pf = det.extract_feat(img)
+    for i, f in enumerate(pf):
+        v = f.reshape(-1)[torch.from_numpy(g[f"p{i + 3}_idx"]).cuda()].cpu().numpy()
+        assert np.allclose(v, g[f"p{i + 3}_val"], rtol=1e-4, atol=1e-4 * float(g[f"p{i + 3}_absmean"])), f"P{i + 3}"
+    outs = det.bbox_head(pf)
+    for nm, ts in zip(["cls", "reg", "iou"], outs):
+        v = nchw_flat(ts).reshape(-1)[torch.from_numpy(g[f"{nm}_idx"]).cuda()].cpu().numpy()
+        assert np.allclose(v, g[f"{nm}_val"], rtol=1e-4, atol=1e-4 * float(g[f"{nm}_absmean"])), nm
+
+
+def test_train_forward_backward(det, golden):
+    from oracle import synth
+    g = golden("model")
+    img = synth.synth_images(0, 2).cuda()
+    gt_b, gt_l, p2g, pw = targets(golden)
+    det.train()
+    det.zero_grad()
+    losses = det(img=img, img_metas=synth.img_metas(2), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - float(g[k])) <= 1e-4 * max(1.0, abs(float(g[k]))), (k, losses[k].item(), float(g[k]))
+    loss, log_vars = det._parse_losses(losses)
+    assert abs(log_vars["loss"] - float(g["loss"])) <= 1e-4 * float(g["loss"])
+    loss.backward()
+    named = dict(det.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(names) == sorted(n for n, p in named.items() if p.requires_grad)
+    mine = np.array([named[n].grad.double().norm().item() for n in names])
+    ref = g["grad_norms"]
+    bad = [(n, a, b) for n, a, b in zip(names, mine, ref) if abs(a - b) > 5e-4 * b + 1e-6 * float(g["total_grad_norm"])]
+    assert not bad, bad[:10]
+    assert all(named[n].grad is None for n in named if not named[n].requires_grad)
+
+
+def test_simple_test(det, golden):
+    from oracle import synth
+    g = golden("model")
+    img = synth.synth_images(0, 2).cuda()
+    det.eval()
+    with torch.no_grad():
+        results = det(img=[img], img_metas=[synth.img_metas(2)], return_loss=False, rescale=True)
+    assert len(results) == 2 and all(len(r) == 21 for r in results)
+    for i, per_cls in enumerate(results):
+        dets = np.concatenate([np.concatenate([d, np.full((d.shape[0], 1), c, np.float32)], 1) for c, d in enumerate(per_cls)], 0)
+        ref = g[f"det_{i}"]
+        assert dets.shape == ref.shape
+        o, r = np.argsort(-dets[:, 4], kind="stable"), np.argsort(-ref[:, 4], kind="stable")
+        assert np.array_equal(dets[o, 5], ref[r, 5])
+        assert np.allclose(dets[o, :5], ref[r, :5], rtol=1e-4, atol=2e-3)
+
+
+def test_native_train_step_matches_autograd(det, golden):
+    """runtime.train_step (no autograd, fused clip+AdamW) == autograd path + torch AdamW on a clone."""
+    import copy
+    from oracle import synth
+    img = synth.synth_images(0, 2).cuda()
+    gt_b, gt_l, p2g, pw = targets(golden)
+    a = copy.deepcopy(det).cuda()
+    a._runtime = None
+    b = copy.deepcopy(det).cuda()
+    b._runtime = None
+    a.train(); b.train()
+    opt = torch.optim.AdamW(a.parameters(), lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    rt = b.runtime()
+    rt.init_optimizer(lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0)
+    tg = rt.pack_targets(gt_b, gt_l, p2g, pw)
+    for _ in range(2):
+        opt.zero_grad()
+        losses = a(img=img, img_metas=synth.img_metas(2), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                   points_to_gt_index=p2g, points_weight=pw)
+        sum(losses.values()).backward()
+        torch.nn.utils.clip_grad_norm_([p for p in a.parameters() if p.requires_grad], 35.0)
+        opt.step()
+        lb = rt.train_step(img, tg)
+        assert np.allclose(lb.cpu().numpy(), [losses[k].item() for k in ("loss_cls", "loss_bbox", "loss_iou")], rtol=1e-4)
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    for n in pa:
+        d = (pa[n].detach() - pb[n].detach()).abs().max().item()
+        assert d <= 1e-5 + 1e-4 * pa[n].detach().abs().max().item(), (n, d)

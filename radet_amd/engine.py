@@ -61,6 +61,24 @@ class Engine:
         self.geo_key = None
         self.table = None
 
+    # ------------------------------------------------------------------ profiling hook
+    TOWER_TAG = 0x100   # own kernel symbol for the head-tower GEMM family (see conv_igemm.hip)
+    tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
+
+    def _tower_launch(self, fn, *args, **kw):
+        ev = self.tower_events
+        if ev is None:
+            return fn(*args, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn(*args, **kw)
+        e.record()
+        ev.append((s, e))
+
+    def tower_gemm_flops(self):
+        """Algorithmic FLOPs of ONE tower GEMM launch: 2 * (B * points) * 256 * (9 * 256)."""
+        return 2.0 * self.R * self.feat * 9 * self.feat
+
     # ------------------------------------------------------------------ structure
     def _add(self, conv):
         self.convs.append(conv)
@@ -320,7 +338,7 @@ class Engine:
             x = P
             for i, c in enumerate(tower):
                 z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
-                K.conv_fwd(c.geom, x, c.wf, None, z)
+                self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=self.TOWER_TAG)
                 gn = f"bbox_head.{t}_convs.{i}.gn"
                 K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], self.gn_ws)
                 x = y
@@ -377,9 +395,9 @@ class Engine:
                 x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
                 K.conv_wgrad(c.geom, dz, x, c.slabs, None)
                 if i > 0:
-                    K.conv_dgrad(c.geom, dz, c.wft, dy)
+                    self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dy, tile=self.TOWER_TAG)
                 else:
-                    K.conv_dgrad(c.geom, dz, c.wft, dP, addend=None if first else dP)
+                    self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dP, addend=None if first else dP, tile=self.TOWER_TAG)
             first = False
         # Scale gradients
         for i in range(len(self.strides)):

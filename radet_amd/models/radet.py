@@ -26,6 +26,9 @@ class RADet(nn.Module):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.fp16_enabled = False
         self._runtime = None
+        for m in (self.backbone, self.neck, self.bbox_head):     # module-level API reaches the runtime through the owner
+            if m is not None:
+                object.__setattr__(m, "_owner_ref", weakref.ref(self))
         self.init_weights(pretrained=pretrained)
 
     @property
@@ -52,9 +55,6 @@ class RADet(nn.Module):
                                  frozen_stages=self.backbone.frozen_stages, strides=self.bbox_head.strides,
                                  stacked_convs=self.bbox_head.stacked_convs)
             object.__setattr__(self, "_runtime", rt)
-            ref = weakref.ref(rt)
-            for m in (self.backbone, self.neck, self.bbox_head):
-                object.__setattr__(m, "_runtime_ref", ref)
             rt.owner = weakref.ref(self)
         return rt
 

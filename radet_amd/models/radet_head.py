@@ -67,11 +67,8 @@ class RADetHead(nn.Module):
 
     # ---- module API (routed through the owning detector's runtime)
     def _rt(self):
-        rt = getattr(self, "_runtime_ref", None)
-        if rt is None:
-            raise RuntimeError("RADetHead runs inside a RADet detector on MI355X (build_detector(cfg).cuda()); "
-                               "its kernels are driven by the detector runtime")
-        return rt()
+        from ..runtime import owner_runtime
+        return owner_runtime(self)
 
     def forward(self, feats):
         return self._rt().head_forward_api(feats)

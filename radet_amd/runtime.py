@@ -272,15 +272,39 @@ def _losses_autograd(self, img, gt_bboxes, gt_labels, points_to_gt_index, points
 DetectorRuntime.losses_autograd = _losses_autograd
 
 
-def standalone_forward(module, part, x):
-    rt = getattr(module, "_runtime_ref", None)
-    if rt is None or rt() is None:
+def owner_runtime(module):
+    ref = getattr(module, "_owner_ref", None)
+    det = ref() if ref is not None else None
+    if det is None:
         raise RuntimeError(f"{type(module).__name__} executes through its detector's MI355X runtime: build the "
                            "detector with build_detector(cfg).cuda() and call it (or detector.extract_feat)")
-    rt = rt()
+    return det.runtime()
+
+
+def standalone_forward(module, part, x):
+    rt = owner_runtime(module)
     if part == "backbone":
         return rt.backbone_api(x)
     return rt.neck_api(x)
+
+
+def _neck_api(self, inputs):
+    """inputs: NCHW C2..C5 (as returned by the backbone module). Returns NCHW P3..P7."""
+    with torch.no_grad():
+        e = self.engine
+        B = inputs[0].shape[0]
+        feats = [None]
+        for i, x in enumerate(inputs[1:]):
+            blk = e.stages[i + 1][-1]
+            rows = e.buf[f"l{i + 2}.{len(e.stages[i + 1]) - 1}.out"]
+            K.nchw_to_nhwc(x.to(self.dev).contiguous(), rows, B, x.shape[1], x.shape[2], x.shape[3])
+            feats.append(rows)
+            del blk
+        P = e.neck_forward(feats)
+        return tuple(_rows_to_nchw(self, P, e.plv, e.feat))
+
+
+DetectorRuntime.neck_api = _neck_api
 
 
 # ---------------------------------------------------------------------- inference + module-level API

@@ -88,6 +88,57 @@ class FlatParams:
         return p is None or (p.data_ptr() == self.p[self.train_names[0]].data_ptr())
 
 
+def compute_buckets(flat, conv_names, conv_trainable):
+    """Gradient buckets in backward order: (prefix, conv-table range, gradient-arena range).
+    Arena ranges are contiguous, disjoint and together cover every trainable parameter."""
+    def rng(pf):
+        idx = [i for i, n in enumerate(conv_names) if n.startswith(pf)]
+        return (idx[0], idx[-1] + 1) if idx else None
+
+    buckets = []
+    for pf in ("bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2.", "backbone.layer1.",
+               "backbone.conv1"):
+        r = rng(pf)
+        if r is None or not any(conv_trainable[r[0]:r[1]]):
+            continue
+        groups = ["backbone.conv1", "backbone.bn1"] if pf == "backbone.conv1" else [pf]
+        arena = flat.group_ranges(groups)
+        buckets.append(dict(prefix=pf, convs=r, arena=(min(a[1] for a in arena), max(a[2] for a in arena))))
+    return buckets
+
+
+class GradReducer:
+    """Sum-all-reduce of gradient-arena buckets as they become ready (RCCL over xGMI on the GPU box,
+    gloo in the CPU tests).  On a HIP device the collectives run on a side stream so that they overlap
+    the backward kernels still being issued on the main stream; the mean (1/world) is applied later,
+    inside the fused clip+AdamW kernel."""
+
+    def __init__(self, grads, device):
+        self.grads, self.device = grads, device
+        self.cuda = device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.works = []
+
+    def bucket_ready(self, bucket):
+        b, e = bucket["arena"]
+        view = self.grads[b:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class DetectorRuntime:
     def __init__(self, det, depth, num_classes, frozen_stages, strides, stacked_convs=4):
         dev = next(det.parameters()).device
@@ -104,28 +155,9 @@ class DetectorRuntime:
         self.opt_state = None
         self.step_count = 0
         self.comm_stream = None
-        # conv-table ranges per gradient bucket, in backward order
-        names = [c.name for c in self.engine.convs]
-
-        def rng(pf):
-            idx = [i for i, n in enumerate(names) if n.startswith(pf)]
-            return (idx[0], idx[-1] + 1) if idx else None
-
-        self.buckets = []
-        for pf in ("bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2.",
-                   "backbone.layer1.", "backbone.conv1"):
-            r = rng(pf)
-            if r is None:
-                continue
-            tr = [c for c in self.engine.convs[r[0]:r[1]] if c.trainable]
-            if not tr:
-                continue
-            arena = self.flat.group_ranges([pf if pf != "backbone.conv1" else "backbone.conv1"])
-            if pf == "backbone.conv1":
-                arena = self.flat.group_ranges(["backbone.conv1", "backbone.bn1"])
-            b = min(a[1] for a in arena)
-            e = max(a[2] for a in arena)
-            self.buckets.append(dict(prefix=pf, convs=r, arena=(b, e)))
+        self.buckets = compute_buckets(self.flat, [c.name for c in self.engine.convs],
+                                       [c.trainable for c in self.engine.convs])
+        self.reducer = None
 
     # ------------------------------------------------------------------ inputs
     def pack_targets(self, gt_bboxes, gt_labels, points_to_gt_index, points_weight):
@@ -211,22 +243,10 @@ class DetectorRuntime:
         self.forward(img)
         self.loss(tg)
         if world > 1:
-            if self.comm_stream is None:
-                self.comm_stream = torch.cuda.Stream(device=self.dev)
-            main = torch.cuda.current_stream()
-            works = []
-
-            def hook(bucket):
-                ev = torch.cuda.Event()
-                ev.record(main)
-                b, e = bucket["arena"]
-                with torch.cuda.stream(self.comm_stream):
-                    self.comm_stream.wait_event(ev)
-                    works.append(dist.all_reduce(self.flat.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
-            self.backward(hook)
-            for w in works:
-                w.wait()
-            main.wait_stream(self.comm_stream)
+            if self.reducer is None:
+                self.reducer = GradReducer(self.flat.grads, self.dev)
+            self.backward(self.reducer.bucket_ready)
+            self.reducer.finish()
         else:
             self.backward()
         self.optimizer_step(lr=lr, grad_div=float(world))

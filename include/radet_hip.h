@@ -46,18 +46,25 @@ typedef struct RadetConvDesc {
     int wft_off;           /* column offset inside that padded row */
 } RadetConvDesc;
 
-/* Implicit-GEMM conv on MFMA. Forward: (so, sr, off, div) = (stride, 1, -pad, 1), w = wf.
- * dgrad: x = dy, w = wft, Cin/Cout swapped, (so, sr, off, div) = (1, -1, pad, stride), segs swapped.
- * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0. */
+/* Gather table of one conv geometry: table[tap][Mp] = input row feeding (output row m, tap) or -1 (padding /
+ * stride hole); Mp = radet_gather_table_rows(M).  Forward / wgrad: (so, sr, off, div) = (stride, 1, -pad, 1) with
+ * seg_desc rows = conv outputs.  dgrad: (1, -1, pad, stride) with input/output roles of seg_desc swapped.
+ * Built once per (B, H, W); removes every integer division from the GEMM main loops. */
+int radet_gather_table_rows(int M);
+int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, int off, int div, const int* seg_desc,
+                             int nseg, void* stream);
+/* Implicit-GEMM conv on MFMA: y[m,n] = sum_{tap,c} x[table[tap][m], c] * w[n][tap][c].  Forward: w = wf.
+ * dgrad: x = dy, w = wft (Cin/Cout swapped, dgrad table).
+ * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0.
+ * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling). */
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
-                       float* y, int B, int Cin, int Cout, int KH, int KW, int so, int sr, int off, int div, int relu,
-                       const int* seg_desc, int nseg, int tile_override, void* stream);
-/* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[gather(m,tap),c];
+                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
+                       int tile_override, void* stream);
+/* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
-int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, int B, int Cin, int Cout,
-                       int ld_dy, int KH, int KW, int so, int sr, int off, int div, const int* seg_desc, int nseg,
-                       int S, void* stream);
+int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
+                       int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, void* stream);
 int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream);
 int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, void* stream);
 /* stem: 7x7/2 conv (3->64) + folded BN + ReLU, NCHW image in, NHWC out (resnet.py:558-570,627-629) */

@@ -27,9 +27,11 @@ class RadetConvDesc(C.Structure):
 
 # name -> (restype, argtypes); must list every function of include/radet_hip.h
 SIGNATURES = {
-    "radet_conv2d_igemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "radet_gather_table_rows": (_i, [_i]),
+    "radet_build_gather_table": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "radet_conv2d_igemm": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
-    "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_fold_weights": (_i, [_p, _i, _p]),
     "radet_unfold_grads": (_i, [_p, _i, _i, _p]),
     "radet_stem_conv_bn_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

@@ -23,10 +23,9 @@ struct ConvArgs {
     const float* addend;  // [M][Cout] or null (added before relu / mask)
     const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
     float* y;             // [M][Cout]
-    int M, Cin, Cout, KH, KW;
-    int so, sr, off, div;  // input coord = o*so + r*sr + off ; must divide by div ; then / div
+    const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
+    int M, Mp, Cin, Cout, KH, KW;
     int relu;
-    RadetSegs segs;
 };
 
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
@@ -100,33 +99,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
 
-    PixCtx pc[A_UNITS];
-#pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) pc[u] = decode_pixel(a.segs, m0 + ((tid + u * 256) >> 2), a.M, a.so, a.off);
     const int k4 = (tid & 3) * 4;
-
-    const int cpt = a.Cin / BK;  // channel chunks per tap
     const int KT = a.KH * a.KW;
-    const int nK = KT * cpt;
+    const int nK = KT * (a.Cin / BK);
+
+    // loop-carried load state: (tap, c0) of the NEXT stage to fetch, rows of the current tap
+    int ld_tap = 0, ld_c0 = 0;
+    int arow[A_UNITS];
+    const int* tabp = a.rowtab + m0 + (tid >> 2);
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) arow[u] = tabp[u * 64];
+    const float* wp[B_UNITS];
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+        const int unit = tid + u * 256;
+        const int n = n0 + (unit >> 2);
+        wp[u] = ((unit < BN * 4) && (n < a.Cout)) ? a.w + (size_t)n * KT * a.Cin + k4 : nullptr;
+    }
 
     float4 ra[A_UNITS], rb[B_UNITS];
-    auto load_stage = [&](int it) {
-        const int tap = it / cpt;
-        const int c0 = (it - tap * cpt) * BK;
-        const int r = tap / a.KW, q = tap - r * a.KW;
+    auto load_stage = [&]() {
 #pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const int row = gather_row(pc[u], r, q, a.sr, a.div);
-            ra[u] = row >= 0 ? *reinterpret_cast<const float4*>(a.x + (size_t)row * a.Cin + c0 + k4)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < A_UNITS; ++u)
+            ra[u] = arow[u] >= 0 ? *reinterpret_cast<const float4*>(a.x + (size_t)arow[u] * a.Cin + ld_c0 + k4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int woff = ld_tap * a.Cin + ld_c0;
 #pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            const int n = n0 + (unit >> 2);
-            const bool ok = (unit < BN * 4) && (n < a.Cout);
-            rb[u] = ok ? *reinterpret_cast<const float4*>(a.w + ((size_t)n * KT + tap) * a.Cin + c0 + k4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < B_UNITS; ++u)
+            rb[u] = wp[u] ? *reinterpret_cast<const float4*>(wp[u] + woff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ld_c0 += BK;
+        if (ld_c0 == a.Cin) {
+            ld_c0 = 0;
+            ++ld_tap;
+            if (ld_tap < KT) {
+#pragma unroll
+                for (int u = 0; u < A_UNITS; ++u) arow[u] = tabp[(size_t)ld_tap * a.Mp + u * 64];
+            }
         }
     };
     auto store_stage = [&](int buf) {
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_stage(0);
+    load_stage();
     store_stage(0);
     __syncthreads();
 
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     for (int it = 0; it < nK; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nK) load_stage(it + 1);
+        if (it + 1 < nK) load_stage();
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float4 af[TM], bf[TN];
@@ -209,12 +217,11 @@ struct WgradArgs {
     const float* x;   // input rows [*, Cin]
     float* slabs;     // [S][Cout][KH*KW][Cin]
     float* dbias_partials;  // [S][Cout] column sums of dy (bias / BN-shift gradient) or null
-    int M, Cin, Cout, KH, KW;
+    const int* rowtab;      // [KH*KW][Mp] gather table (same as the forward conv's)
+    int M, Mp, Cin, Cout, KH, KW;
     int ld_dy;        // row stride of dy (>= Cout; padded gradient buffers)
-    int so, sr, off, div;
     int S;            // pixel splits
     int chunks_per_split;  // 16-pixel chunks per split
-    RadetSegs segs;
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int tc = id % tilesC;
     const int tap = id / tilesC;
     const int o0 = to * BM, c0 = tc * BN;
-    const int r = tap / a.KW, q = tap - r * a.KW;
+    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
 
     const int p_begin = split * a.chunks_per_split * BP;
     int p_end = p_begin + a.chunks_per_split * BP;
@@ -283,8 +290,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int m = p0 + j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (unit < BP * BN / 4 && m < p_end && c < a.Cin) {
-                const PixCtx pc = decode_pixel(a.segs, m, a.M, a.so, a.off);
-                const int row = gather_row(pc, r, q, a.sr, a.div);
+                const int row = tab_tap[m];
                 if (row >= 0) v = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.Cin + c);
             }
             rb[u] = v;
@@ -367,6 +373,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ gather table
+__global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
+                                    int sr, int off, int div) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mp) return;
+    const PixCtx pc = decode_pixel(segs, m, M, so, off);
+    for (int t = 0; t < KH * KW; ++t) {
+        const int r = t / KW, q = t - r * KW;
+        tab[(size_t)t * Mp + m] = m < M ? gather_row(pc, r, q, sr, div) : -1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int out_is_o) {
     // seg_desc: nseg x 6 ints: {Hi, Wi, Ho, Wo, in_row_off, out_row_off}; rows per level = B*Ho*Wo
@@ -401,19 +419,32 @@ static double tile_score(int M, int N, int bm, int bn, double intrinsic) {
     return quant * pad * intrinsic;
 }
 
+extern "C" int radet_gather_table_rows(int M) { return (M + 127) / 128 * 128; }
+
+extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, int off, int div,
+                                        const int* seg_desc, int nseg, void* stream) {
+    RadetSegs segs;
+    int rc = fill_segs(&segs, seg_desc, nseg, B, 1);
+    if (rc) return rc;
+    if (segs.s[0].row_begin != 0) return RADET_ERR_ARG;
+    const int M = segs.s[nseg - 1].row_end;
+    const int Mp = radet_gather_table_rows(M);
+    hipLaunchKernelGGL(gather_table_kernel, dim3((Mp + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, segs, M, Mp,
+                       KH, KW, so, sr, off, div);
+    return radet_check_launch();
+}
+
 extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend,
-                                  const float* mask, float* y, int B, int Cin, int Cout, int KH, int KW,
-                                  int so, int sr, int off, int div, int relu, const int* seg_desc, int nseg,
-                                  int tile_override, void* stream) {
-    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0) return RADET_ERR_ARG;
+                                  const float* mask, float* y, const int* gather_table, int M, int Cin, int Cout,
+                                  int KH, int KW, int relu, int tile_override, void* stream) {
+    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr) return RADET_ERR_ARG;
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.mask = mask; a.y = y;
+    a.rowtab = gather_table;
     a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
-    a.so = so; a.sr = sr; a.off = off; a.div = div; a.relu = relu;
-    int rc = fill_segs(&a.segs, seg_desc, nseg, B, 1);
-    if (rc) return rc;
-    a.M = a.segs.s[nseg - 1].row_end;
-    if (a.segs.s[0].row_begin != 0) return RADET_ERR_ARG;
+    a.relu = relu;
+    a.M = M;
+    a.Mp = radet_gather_table_rows(M);
     hipStream_t st = (hipStream_t)stream;
     const int tag = (tile_override >> 8) & 1;
     int choice = tile_override & 0xFF;
@@ -457,7 +488,7 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
     wgrad_tile(Cout, Cin, &bm, &bn);
     const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
     const int chunks = (M + 15) / 16;
-    long S = (1024 + tiles - 1) / tiles;        // aim for >= 4 blocks per CU
+    long S = (512 + tiles / 2) / tiles;          // ~2 resident blocks per CU (256 CUs)
     const long maxS = (chunks + 7) / 8;          // at least 8 stages (128 pixels) per block
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -465,18 +496,17 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
     return (int)S;
 }
 
-extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, int B,
-                                  int Cin, int Cout, int ld_dy, int KH, int KW, int so, int sr, int off, int div,
-                                  const int* seg_desc, int nseg, int S, void* stream) {
-    if (Cin % 4 != 0 || S < 1 || ld_dy < Cout) return RADET_ERR_ARG;
+extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials,
+                                  const int* gather_table, int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S,
+                                  void* stream) {
+    if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || M <= 0 || gather_table == nullptr) return RADET_ERR_ARG;
     WgradArgs a;
     a.ld_dy = ld_dy;
     a.dy = dy; a.x = x; a.slabs = slabs; a.dbias_partials = dbias_partials;
+    a.rowtab = gather_table;
     a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
-    a.so = so; a.sr = sr; a.off = off; a.div = div;
-    int rc = fill_segs(&a.segs, seg_desc, nseg, B, 1);
-    if (rc) return rc;
-    a.M = a.segs.s[nseg - 1].row_end;
+    a.M = M;
+    a.Mp = radet_gather_table_rows(M);
     a.S = S;
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;

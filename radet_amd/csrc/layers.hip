@@ -447,17 +447,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// final per-channel reduce over chunks: dgamma[c], dbeta[c]
+// final per-channel reduce over chunks: dgamma[c], dbeta[c].  8 workgroups x (4 row groups x 64 columns)
+// over the [nchunks][2][256] partials, fixed summation order.
 __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ cpart, int nchunks,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = threadIdx.x;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        a += cpart[((size_t)k * 2 + 0) * 256 + c];
-        b += cpart[((size_t)k * 2 + 1) * 256 + c];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);   // 0..511 = k*256 + c
+    const int rg = threadIdx.x >> 6;
+    float a = 0.f;
+    for (int k = rg; k < nchunks; k += 4) a += cpart[(size_t)k * 512 + col];
+    __shared__ float red[4][64];
+    red[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0) {
+        const int c = threadIdx.x;
+        const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (col < 256) dgamma[col] = v; else dbeta[col - 256] = v;
     }
-    dgamma[c] = a;
-    dbeta[c] = b;
 }
 
 extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* stats, const float* gamma,
@@ -480,7 +485,7 @@ extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* s
                        segs, B, relu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
                        B, relu);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(1), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(8), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
 }
 

@@ -51,6 +51,22 @@ def _desc(pairs):
     return (C.c_int * len(flat))(*flat), len(pairs)
 
 
+_TABLE_CACHE = {}
+
+
+def _gather_table(key, B, k, so, sr, off, div, desc, nseg, rows):
+    """Device gather table for one conv geometry, shared by every conv with the same geometry."""
+    dev = torch.cuda.current_device()
+    key = (dev,) + key
+    t = _TABLE_CACHE.get(key)
+    if t is None:
+        mp = _lib.load().radet_gather_table_rows(rows)
+        t = torch.empty(k * k * mp, dtype=torch.int32, device=torch.device("cuda", dev))
+        _lib.call("radet_build_gather_table", _ptr(t), B, k, k, so, sr, off, div, desc, nseg, _stream())
+        _TABLE_CACHE[key] = t
+    return t
+
+
 class ConvGeom:
     """Geometry of one convolution over a multi-level input (same weights on every level)."""
 
@@ -64,25 +80,36 @@ class ConvGeom:
             b.append((ho, wo, hi, wi, oo, io))   # dgrad: rows over the conv INPUT grid, gather from dy
         self.fwd_desc, self.nseg = _desc(f)
         self.bwd_desc, _ = _desc(b)
+        self._key = (tuple(lin.hw), tuple(lin.offsets), lin.B, k, stride, pad)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
+
+    @property
+    def fwd_table(self):
+        return _gather_table(("f",) + self._key, self.B, self.k, self.stride, 1, -self.pad, 1, self.fwd_desc, self.nseg,
+                             self.lout.rows)
+
+    @property
+    def bwd_table(self):
+        return _gather_table(("b",) + self._key, self.B, self.k, 1, -1, self.pad, self.stride, self.bwd_desc, self.nseg,
+                             self.lin.rows)
 
 
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0):
-    _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), g.B, g.cin,
-              g.cout, g.k, g.k, g.stride, 1, -g.pad, 1, int(relu), g.fwd_desc, g.nseg, tile, _stream())
+    _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
+              g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _stream())
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels
-    _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), g.B, kc, g.cin, g.k,
-              g.k, 1, -1, g.pad, g.stride, 0, g.bwd_desc, g.nseg, tile, _stream())
+    _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
+              g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _stream())
 
 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
-    _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), g.B, g.cin, co,
-              co if ld_dy is None else ld_dy, g.k, g.k, g.stride, 1, -g.pad, 1, g.fwd_desc, g.nseg, g.nsplit, _stream())
+    _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
+              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, _stream())
 
 
 def fold_weights(table_dev, n):

@@ -56,10 +56,12 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
 /* Implicit-GEMM conv on MFMA: y[m,n] = sum_{tap,c} x[table[tap][m], c] * w[n][tap][c].  Forward: w = wf.
  * dgrad: x = dy, w = wft (Cin/Cout swapped, dgrad table).
  * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0.
- * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling). */
+ * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling); bits 12-15 force
+ * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats; when given, launches with too
+ * few tiles for 256 CUs split the K loop (<= 8 ways) into partial slabs reduced by a second, deterministic pass. */
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                        float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
-                       int tile_override, void* stream);
+                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);

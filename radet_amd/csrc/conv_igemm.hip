@@ -24,8 +24,10 @@ struct ConvArgs {
     const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
     float* y;             // [M][Cout]
     const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
+    float* partial;       // split-K: [sk][M][Cout] raw partial sums (epilogue applied by splitk_epilogue_kernel)
     int M, Mp, Cin, Cout, KH, KW;
     int relu;
+    int sk, it_per_split; // K-stage range of block z = blockIdx.y: [z*it_per_split, min(nK, (z+1)*it_per_split))
 };
 
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
@@ -101,14 +103,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     const int k4 = (tid & 3) * 4;
     const int KT = a.KH * a.KW;
-    const int nK = KT * (a.Cin / BK);
+    const int cpt = a.Cin / BK;
+    const int it0 = blockIdx.y * a.it_per_split;
+    int nK = KT * cpt - it0;
+    if (nK > a.it_per_split) nK = a.it_per_split;
 
     // loop-carried load state: (tap, c0) of the NEXT stage to fetch, rows of the current tap
-    int ld_tap = 0, ld_c0 = 0;
+    int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
     int arow[A_UNITS];
     const int* tabp = a.rowtab + m0 + (tid >> 2);
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) arow[u] = tabp[u * 64];
+    for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * 64] : -1;
     const float* wp[B_UNITS];
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             ++ld_tap;
             if (ld_tap < KT) {
 #pragma unroll
-                for (int u = 0; u < A_UNITS; ++u) arow[u] = tabp[(size_t)ld_tap * a.Mp + u * 64];
+                for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * 64] : -1;
             }
         }
     };
@@ -156,8 +161,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_stage();
-    store_stage(0);
+    if (nK > 0) {
+        load_stage();
+        store_stage(0);
+    }
     __syncthreads();
 
     const int a_row0 = (wm * TM * 32 + li) * LD + 4 * lh;
@@ -190,6 +197,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 
     // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (a.sk > 1) {   // split-K: raw partial sums, epilogue runs in splitk_epilogue_kernel
+        float* part = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+                if (col >= a.Cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < a.M) part[(size_t)row * a.Cout + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -209,6 +232,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 a.y[o] = v;
             }
         }
+}
+
+// split-K second pass: y = epilogue(sum_z partial[z])   (fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) {
+    const size_t total = (size_t)a.M * a.Cout;
+    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < a.sk; ++z) v += a.partial[(size_t)z * total + o];
+        const int col = (int)(o % a.Cout);
+        if (a.bias) v += a.bias[col];
+        if (a.addend) v += a.addend[o];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+        a.y[o] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -406,8 +444,20 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
 template <int BM, int BN, int WM, int WN>
 static void launch_igemm(const ConvArgs& a, hipStream_t st, int tag) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
+    if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    if (a.sk > 1) {
+        const size_t total = (size_t)a.M * a.Cout;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, a);
+    }
+}
+
+static long igemm_tiles(int M, int N, int choice) {
+    const int bm = choice == 3 ? 64 : 128;
+    const int bn = choice == 1 ? 128 : (choice == 4 ? 32 : 64);
+    return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
 // efficiency model: wave quantisation over 256 CUs x tile padding waste x intrinsic tile efficiency
@@ -436,7 +486,8 @@ extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int s
 
 extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend,
                                   const float* mask, float* y, const int* gather_table, int M, int Cin, int Cout,
-                                  int KH, int KW, int relu, int tile_override, void* stream) {
+                                  int KH, int KW, int relu, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
+                                  void* stream) {
     if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr) return RADET_ERR_ARG;
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.mask = mask; a.y = y;
@@ -460,6 +511,24 @@ extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* b
             if (s3 > best) { best = s3; choice = 3; }
         }
     }
+    // split-K for launches that cannot fill 256 CUs twice over (low-M stages): each split keeps >= 8 K stages
+    const int nK = KH * KW * (Cin / 16);
+    int sk = 1;
+    const int sk_force = (tile_override >> 12) & 0xF;
+    const long tiles = igemm_tiles(a.M, Cout, choice);
+    if (splitk_ws != nullptr) {
+        if (sk_force) sk = sk_force;
+        else if (tiles < 384) {
+            sk = (int)((512 + tiles - 1) / tiles);
+            if (sk > nK / 8) sk = nK / 8;
+            if (sk > 8) sk = 8;
+        }
+        while (sk > 1 && (size_t)sk * a.M * Cout > splitk_ws_floats) --sk;
+        if (sk < 1) sk = 1;
+    }
+    a.sk = sk;
+    a.it_per_split = (nK + sk - 1) / sk;
+    a.partial = splitk_ws;
     switch (choice) {
         case 1: launch_igemm<128, 128, 2, 2>(a, st, tag); break;
         case 2: launch_igemm<128, 64, 2, 2>(a, st, tag); break;

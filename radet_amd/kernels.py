@@ -94,16 +94,32 @@ class ConvGeom:
                              self.lin.rows)
 
 
-def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0):
+_SPLITK_WS = {}
+
+
+def splitk_ws():
+    """One split-K workspace per device (launches are stream-ordered, so it is shared by all convs)."""
+    dev = torch.cuda.current_device()
+    t = _SPLITK_WS.get(dev)
+    if t is None:
+        t = torch.empty(16 * 1024 * 1024, device=torch.device("cuda", dev))   # 64 MiB
+        _SPLITK_WS[dev] = t
+    return t
+
+
+def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
+    ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
-              g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _stream())
+              g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
+              _stream())
 
 
-def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0):
+def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels
+    ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
-              g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _stream())
+              g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
 
 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):

@@ -48,6 +48,9 @@ CONV_CASES = [
     (2, 256, 256, 30, 40, 3, 1, 1),
     (2, 256, 256, 30, 40, 3, 1, 2),
     (2, 256, 256, 30, 40, 3, 1, 3),
+    (1, 512, 512, 15, 20, 3, 1, 0x3003),     # forced split-K = 3, 64x64 tiles
+    (1, 1024, 256, 15, 20, 1, 1, 0x2000),    # forced split-K = 2, heuristic tile
+    (4, 2048, 512, 15, 20, 1, 1, 0),         # layer4 shape: heuristic picks split-K
 ]
 
 

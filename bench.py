@@ -189,7 +189,7 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "kernel": "conv_igemm_kernel<128,128,2,2,TAG=1> (head-tower 3x3 conv GEMM, fwd+dgrad)",
+                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32> (head-tower 3x3 conv GEMM, fwd+dgrad)",
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:

@@ -15,6 +15,7 @@
 // is legal because A and B use the same permutation.  Global->LDS is register-staged and
 // double-buffered: one barrier per K step, next step's loads in flight under 8*TM*TN MFMAs.
 #include "common.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const float* x;       // input rows [*, Cin]
@@ -79,14 +80,15 @@ __device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr,
 
 // TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
 // K = 2304) so that rocprofv3 --stats reports it on its own line (bench.py's roofline kernel).
-template <int BM, int BN, int WM, int WN, int TAG>
+template <int BM, int BN, int WM, int WN, int TAG, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int BK = 16, LD = 20;
+    constexpr int LD = BK + 4;            // 20 / 36 floats: conflict-free 16-byte fragment reads
+    constexpr int F4 = BK / 4;            // float4 per tile row
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_UNITS = (BM * 4) / 256;
-    constexpr int B_UNITS = (BN * 4 + 255) / 256;
+    constexpr int A_UNITS = (BM * F4) / 256;
+    constexpr int B_UNITS = (BN * F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
-    static_assert(A_UNITS >= 1, "BM >= 64");
+    static_assert(A_UNITS >= 1, "BM * BK >= 1024");
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
 
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
 
-    const int k4 = (tid & 3) * 4;
+    const int k4 = (tid % F4) * 4;
+    constexpr int RPU = 256 / F4;         // tile rows covered by one 256-thread load unit
     const int KT = a.KH * a.KW;
     const int cpt = a.Cin / BK;
     const int it0 = blockIdx.y * a.it_per_split;
@@ -111,15 +114,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     // loop-carried load state: (tap, c0) of the NEXT stage to fetch, rows of the current tap
     int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
     int arow[A_UNITS];
-    const int* tabp = a.rowtab + m0 + (tid >> 2);
+    const int* tabp = a.rowtab + m0 + (tid / F4);
 #pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * 64] : -1;
+    for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * RPU] : -1;
     const float* wp[B_UNITS];
 #pragma unroll
     for (int u = 0; u < B_UNITS; ++u) {
         const int unit = tid + u * 256;
-        const int n = n0 + (unit >> 2);
-        wp[u] = ((unit < BN * 4) && (n < a.Cout)) ? a.w + (size_t)n * KT * a.Cin + k4 : nullptr;
+        const int n = n0 + (unit / F4);
+        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? a.w + (size_t)n * KT * a.Cin + k4 : nullptr;
     }
 
     float4 ra[A_UNITS], rb[B_UNITS];
@@ -138,18 +141,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             ++ld_tap;
             if (ld_tap < KT) {
 #pragma unroll
-                for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * 64] : -1;
+                for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * RPU] : -1;
             }
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < A_UNITS; ++u)
-            *reinterpret_cast<float4*>(&As[buf][((tid + u * 256) >> 2) * LD + k4]) = ra[u];
+            *reinterpret_cast<float4*>(&As[buf][((tid + u * 256) / F4) * LD + k4]) = ra[u];
 #pragma unroll
         for (int u = 0; u < B_UNITS; ++u) {
             const int unit = tid + u * 256;
-            if (unit < BN * 4) *reinterpret_cast<float4*>(&Bs[buf][(unit >> 2) * LD + k4]) = rb[u];
+            if (unit < BN * F4) *reinterpret_cast<float4*>(&Bs[buf][(unit / F4) * LD + k4]) = rb[u];
         }
     };
 
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int buf = it & 1;
         if (it + 1 < nK) load_stage();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BK / 8; ++s) {
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -260,6 +263,7 @@ struct WgradArgs {
     int ld_dy;        // row stride of dy (>= Cout; padded gradient buffers)
     int S;            // pixel splits
     int chunks_per_split;  // 16-pixel chunks per split
+    int dbg;          // experiments only (RADET_DBG_WGRAD): 1 = skip global loads after the first stage
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int tilesC = (a.Cin + BN - 1) / BN;
     const int tilesPerSplit = tilesO * KT * tilesC;
     int id = blockIdx.x;
-    const int split = id / tilesPerSplit;
+    const int split = id / tilesPerSplit;   // (debug: bit 12 of S = skip global loads after the first stage)
     id -= split * tilesPerSplit;
     const int to = id % tilesO;
     id /= tilesO;
@@ -300,6 +304,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     float4 bsum[A_UNITS];
 #pragma unroll
     for (int u = 0; u < A_UNITS; ++u) bsum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int brow[B_UNITS];
+    bool bvalid[B_UNITS];
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+        const int unit = tid + u * 256;
+        const int m = p_begin + unit / (BN / 4);
+        bvalid[u] = unit < BP * BN / 4 && m < p_end;
+        brow[u] = tab_tap[bvalid[u] ? m : 0];
+    }
+    // Loads are UNCONDITIONAL (addresses clamped to a valid location) and masked when they are written to
+    // LDS: a "load or zero" select at load time makes hipcc branch around each load and drain vmcnt(0)
+    // before the MFMAs (cdna_hip_programming.md, ".s-level traps" (c)), which serialises the pipeline.
+    bool am[A_UNITS], bm[B_UNITS];
     auto load_stage = [&](int it) {
         const int p0 = p_begin + it * BP;
 #pragma unroll
@@ -307,43 +324,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             const int unit = tid + u * 256;
             const int j = unit / (BM / 4), o = o0 + (unit % (BM / 4)) * 4;
             const int m = p0 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (unit < BP * BM / 4 && m < p_end) {
-                const float* src = a.dy + (size_t)m * a.ld_dy + o;
-                if (o + 3 < a.Cout && (a.ld_dy & 3) == 0) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    if (o < a.Cout) v.x = src[0];
-                    if (o + 1 < a.Cout) v.y = src[1];
-                    if (o + 2 < a.Cout) v.z = src[2];
-                    if (o + 3 < a.Cout) v.w = src[3];
-                }
-            }
-            ra[u] = v;
-            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
+            am[u] = (unit < BP * BM / 4) && (m < p_end) && (o < a.Cout);
+            const float* src = a.dy + (am[u] ? (size_t)m * a.ld_dy + o : (size_t)0);
+            ra[u] = *reinterpret_cast<const float4*>(src);
         }
 #pragma unroll
         for (int u = 0; u < B_UNITS; ++u) {
             const int unit = tid + u * 256;
             const int j = unit / (BN / 4), c = c0 + (unit % (BN / 4)) * 4;
             const int m = p0 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (unit < BP * BN / 4 && m < p_end && c < a.Cin) {
-                const int row = tab_tap[m];
-                if (row >= 0) v = *reinterpret_cast<const float4*>(a.x + (size_t)row * a.Cin + c);
-            }
-            rb[u] = v;
+            const bool live = unit < BP * BN / 4 && c < a.Cin;
+            bm[u] = live && bvalid[u] && brow[u] >= 0;
+            const float* src = a.x + (bm[u] ? (size_t)brow[u] * a.Cin + c : (size_t)0);
+            rb[u] = *reinterpret_cast<const float4*>(src);
+            // gather-table entry of the NEXT stage (raw; validity kept separately so that nothing consumes
+            // the loaded value before the next stage): its latency overlaps this stage's data loads
+            bvalid[u] = live && (m + BP < p_end);
+            brow[u] = tab_tap[bvalid[u] ? m + BP : 0];
         }
     };
     auto store_stage = [&](int buf) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < A_UNITS; ++u) {
             const int unit = tid + u * 256;
-            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[buf][unit * 4]) = ra[u];
+            float4 v = am[u] ? ra[u] : z4;
+            // channels beyond Cout inside the last float4 of a padded row are zero in the buffer already
+            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[buf][unit * 4]) = v;
+            // fused bias gradient: consume the dy tile here (data has landed), never at load time
+            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
         }
 #pragma unroll
         for (int u = 0; u < B_UNITS; ++u) {
             const int unit = tid + u * 256;
-            if (unit < BP * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = rb[u];
+            if (unit < BP * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = bm[u] ? rb[u] : z4;
         }
     };
 
@@ -362,20 +376,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nIt) load_stage(it + 1);
+        if (it + 1 < nIt && !(a.dbg && it > 0)) load_stage(it + 1);
+        // all fragments of the stage are issued to LDS first, so the MFMAs wait with counted lgkmcnt only
+        float af[BP / 2][TM], bf[BP / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BP / 2; ++kk) {
-            float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
+            for (int i = 0; i < TM; ++i) af[kk][i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+            for (int j = 0; j < TN; ++j) bf[kk][j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads ahead of the MFMA block (hipcc otherwise sinks them)
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
         if (it + 1 < nIt) store_stage(buf ^ 1);
         __syncthreads();
     }
@@ -442,10 +460,15 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm(const ConvArgs& a, hipStream_t st, int tag) {
+static void launch_igemm(const ConvArgs& a, hipStream_t st, int tag, int bk) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(tiles, a.sk), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    if (bk == 32) {
+        if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    } else {
+        if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, 16>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, 16>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    }
     if (a.sk > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         int blocks = (int)((total + 255) / 256);
@@ -498,6 +521,8 @@ extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* b
     a.Mp = radet_gather_table_rows(M);
     hipStream_t st = (hipStream_t)stream;
     const int tag = (tile_override >> 8) & 1;
+    int bk = ((tile_override >> 9) & 1) ? 32 : 16;
+    if (Cin % 32 != 0) bk = 16;
     int choice = tile_override & 0xFF;
     if (choice <= 0) {
         if (Cout <= 32) choice = 4;
@@ -512,7 +537,7 @@ extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* b
         }
     }
     // split-K for launches that cannot fill 256 CUs twice over (low-M stages): each split keeps >= 8 K stages
-    const int nK = KH * KW * (Cin / 16);
+    const int nK = KH * KW * (Cin / bk);
     int sk = 1;
     const int sk_force = (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice);
@@ -530,10 +555,10 @@ extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* b
     a.it_per_split = (nK + sk - 1) / sk;
     a.partial = splitk_ws;
     switch (choice) {
-        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag); break;
-        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag); break;
-        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag); break;
-        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag); break;
+        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk); break;
+        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk); break;
+        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk); break;
+        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk); break;
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();
@@ -557,7 +582,17 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
     wgrad_tile(Cout, Cin, &bm, &bn);
     const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
     const int chunks = (M + 15) / 16;
-    long S = (512 + tiles / 2) / tiles;          // ~2 resident blocks per CU (256 CUs)
+    // pick S in the 2..4 blocks-per-CU range whose block count quantises best onto 256 CUs
+    long lo = (448 + tiles - 1) / tiles, hi = (1024 + tiles - 1) / tiles;
+    { const char* e = getenv("RADET_WGRAD_BLOCKS"); if (e) lo = hi = (atol(e) + tiles / 2) / tiles; }
+    if (lo < 1) lo = 1;
+    long S = lo;
+    double best = -1.0;
+    for (long c = lo; c <= hi; ++c) {
+        const long blocks = tiles * c;
+        const double eff = (double)blocks / (256.0 * ((blocks + 255) / 256)) - 0.002 * (double)(c - lo);
+        if (eff > best) { best = eff; S = c; }
+    }
     const long maxS = (chunks + 7) / 8;          // at least 8 stages (128 pixels) per block
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
@@ -568,7 +603,10 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
 extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials,
                                   const int* gather_table, int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S,
                                   void* stream) {
-    if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || M <= 0 || gather_table == nullptr) return RADET_ERR_ARG;
+    // dy rows must be 16-byte aligned and hold whole float4s for every real channel (pad small heads with zeros)
+    if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || (ld_dy & 3) || ((Cout + 3) / 4) * 4 > ld_dy || M <= 0 ||
+        gather_table == nullptr)
+        return RADET_ERR_ARG;
     WgradArgs a;
     a.ld_dy = ld_dy;
     a.dy = dy; a.x = x; a.slabs = slabs; a.dbias_partials = dbias_partials;
@@ -577,6 +615,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     a.M = M;
     a.Mp = radet_gather_table_rows(M);
     a.S = S;
+    { const char* e = getenv("RADET_DBG_WGRAD"); a.dbg = e ? atoi(e) : 0; }
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;

@@ -62,7 +62,9 @@ class Engine:
         self.table = None
 
     # ------------------------------------------------------------------ profiling hook
-    TOWER_TAG = 0x100   # own kernel symbol for the head-tower GEMM family (see conv_igemm.hip)
+    # own kernel symbol for the head-tower GEMM family (see conv_igemm.hip) + its measured-best tile:
+    # 64x64 block tile with a 32-deep K step (bench_conv.py: 98.7 vs 88.8 TFLOP/s for the heuristic pick)
+    TOWER_TAG = 0x100 | 0x200 | 3
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 
     def _tower_launch(self, fn, *args, **kw):

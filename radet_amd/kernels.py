@@ -98,12 +98,14 @@ _SPLITK_WS = {}
 
 
 def splitk_ws():
-    """One split-K workspace per device (launches are stream-ordered, so it is shared by all convs)."""
+    """One split-K workspace per (device, stream): launches on one stream are ordered, so all convs issued
+    there can share it; concurrent streams get their own."""
     dev = torch.cuda.current_device()
-    t = _SPLITK_WS.get(dev)
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _SPLITK_WS.get(key)
     if t is None:
         t = torch.empty(16 * 1024 * 1024, device=torch.device("cuda", dev))   # 64 MiB
-        _SPLITK_WS[dev] = t
+        _SPLITK_WS[key] = t
     return t
 
 

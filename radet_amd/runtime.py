@@ -205,6 +205,7 @@ class DetectorRuntime:
         desc_bytes = C.sizeof(_lib.RadetConvDesc)
 
         def unfold(bucket):
+            e.join_side()                       # weight-gradient GEMMs run on the side stream
             a, b = bucket["convs"]
             K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
             if bucket_hook is not None:

@@ -119,24 +119,66 @@ extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W,
 // ------------------------------------------------------------------------------------------ fold / unfold
 // fold: for every conv in the table, s[o] = gamma*rsqrt(var+eps) (1 without BN):
 //   wf[o][t][c] = s[o] * w[o][c][t] ; wft[c][t][o] = same value ; bias_f[o] = beta - mean*s | conv bias | 0
+// One work item = (o-tile of 16, c-tile of 32): the OIHW slab [16][32*KT] is read with contiguous runs,
+// transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
+#define FOLD_TO 16
+#define FOLD_TC 32
 __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
     const int KT = d.kh * d.kw;
-    const size_t total = (size_t)d.cout * d.cin * KT;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        // i indexes the OHWI output (coalesced writes); reads of OIHW are strided but L2-resident
-        const int c = (int)(i % d.cin);
-        const size_t oc = i / d.cin;
-        const int t = (int)(oc % KT);
-        const int o = (int)(oc / KT);
-        float s = 1.f;
-        if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
-        const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
-        d.wf[i] = v;
-        if (d.wft) d.wft[((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o] = v;
+    __shared__ float tile[FOLD_TO][FOLD_TC * 9 + 1];
+    __shared__ float ssc[FOLD_TO];
+    const int tid = threadIdx.x;
+    if (KT > 9) {   // 7x7 stem: small, keep the simple element-wise path
+        const size_t total = (size_t)d.cout * d.cin * KT;
+        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i % d.cin);
+            const size_t oc = i / d.cin;
+            const int t = (int)(oc % KT);
+            const int o = (int)(oc / KT);
+            float s = 1.f;
+            if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+            const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
+            d.wf[i] = v;
+            if (d.wft) d.wft[((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o] = v;
+        }
+    } else {
+        const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + FOLD_TC - 1) / FOLD_TC;
+        const int ld_t = d.wft_ld ? d.wft_ld : d.cout;
+        for (int item = blockIdx.x; item < tiles_o * tiles_c; item += gridDim.x) {
+            const int o0 = (item / tiles_c) * FOLD_TO, c0 = (item % tiles_c) * FOLD_TC;
+            const int nc = min(FOLD_TC, d.cin - c0), no = min(FOLD_TO, d.cout - o0);
+            const int run = nc * KT;                      // contiguous floats per output channel
+            __syncthreads();
+            if (tid < FOLD_TO) {
+                float s = 1.f;
+                const int o = o0 + tid;
+                if (d.bn_gamma && o < d.cout) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+                ssc[tid] = s;
+            }
+            for (int i = tid; i < no * run; i += 256) {
+                const int oo = i / run, k = i - oo * run;   // k = c_local*KT + t
+                tile[oo][k] = d.w[((size_t)(o0 + oo) * d.cin + c0) * KT + k];
+            }
+            __syncthreads();
+            // OHWI: wf[o][t][c0 + cl]  (runs of nc floats)
+            for (int i = tid; i < no * run; i += 256) {
+                const int oo = i / run, r = i - oo * run;
+                const int t = r / nc, cl = r - t * nc;
+                d.wf[((size_t)(o0 + oo) * KT + t) * d.cin + c0 + cl] = tile[oo][cl * KT + t] * ssc[oo];
+            }
+            // [c][t][o0 + oo]  (runs of no floats)
+            if (d.wft) {
+                for (int i = tid; i < no * run; i += 256) {
+                    const int oo = i % no, r = i / no;      // r = cl*KT + t
+                    const int cl = r / KT, t = r - cl * KT;
+                    d.wft[((size_t)(c0 + cl) * KT + t) * ld_t + d.wft_off + o0 + oo] = tile[oo][r] * ssc[oo];
+                }
+            }
+        }
     }
     if (blockIdx.x == 0 && d.bias_f) {
-        for (int o = threadIdx.x; o < d.cout; o += 256) {
+        for (int o = tid; o < d.cout; o += 256) {
             float b = 0.f;
             if (d.bn_gamma) {
                 const float s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
@@ -149,13 +191,14 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
 
 extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {
     if (nconv <= 0) return RADET_OK;
-    hipLaunchKernelGGL(fold_kernel, dim3(128, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
+    hipLaunchKernelGGL(fold_kernel, dim3(96, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     return radet_check_launch();
 }
 
-// unfold: one block per (conv, o).  dwf_sum[o][t][c] = sum over wgrad splits; then
+// unfold: one block per (conv, o).  dwf_sum[o][t][c] = sum over wgrad splits (fixed order); then
 //   dw[o][c][t] = s[o]*dwf_sum ; ds[o] = <dwf_sum[o], w[o]> ; db[o] = sum of bias partials
 //   BN: dgamma = rstd*(ds - db*mean) ; dbeta = db.  plain bias: dbias = db.
+// The [t][c] row is staged in LDS so that slab reads, weight reads and OIHW writes are all contiguous.
 __global__ __launch_bounds__(256) void unfold_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
     const int o = blockIdx.x;
@@ -168,14 +211,36 @@ __global__ __launch_bounds__(256) void unfold_kernel(const RadetConvDesc* __rest
         rstd = 1.0f / sqrtf(d.bn_var[o] + d.eps);
         s = d.bn_gamma[o] * rstd;
     }
+    __shared__ float row[2304 + 8];
     float dot = 0.f;
-    for (int i = threadIdx.x; i < K; i += 256) {  // i = t*cin + c (OHWI inner index, coalesced slab reads)
-        const int t = i / d.cin, c = i - t * d.cin;
-        float g = 0.f;
-        for (int sp = 0; sp < d.nsplit; ++sp) g += d.dwf_slabs[sp * slab + (size_t)o * K + i];
-        const size_t wi = ((size_t)o * d.cin + c) * KT + t;
-        dot += g * d.w[wi];
-        d.dw[wi] = g * s;
+    for (int k0 = 0; k0 < K; k0 += 2304) {   // chunk = whole taps x channels span of <= 2304 (KT*256)
+        const int kn = min(2304, K - k0);
+        // k0 is a multiple of KT*... only when K > 2304; handle generally by index math below
+        __syncthreads();
+        for (int i = threadIdx.x; i < kn; i += 256) {        // i + k0 = t*cin + c  (OHWI inner index)
+            float g = 0.f;
+            for (int sp = 0; sp < d.nsplit; ++sp) g += d.dwf_slabs[sp * slab + (size_t)o * K + k0 + i];
+            row[i] = g;
+        }
+        __syncthreads();
+        if (K <= 2304) {
+            // whole row resident: emit OIHW order j = c*KT + t contiguously
+            for (int j = threadIdx.x; j < K; j += 256) {
+                const int c = j / KT, t = j - c * KT;
+                const float g = row[t * d.cin + c];
+                const size_t wi = (size_t)o * K + j;
+                dot += g * d.w[wi];
+                d.dw[wi] = g * s;
+            }
+        } else {
+            for (int i = threadIdx.x; i < kn; i += 256) {
+                const int q = k0 + i;
+                const int t = q / d.cin, c = q - t * d.cin;
+                const size_t wi = ((size_t)o * d.cin + c) * KT + t;
+                dot += row[i] * d.w[wi];
+                d.dw[wi] = row[i] * s;
+            }
+        }
     }
     __shared__ float red[4];
     dot = wave_sum(dot);

@@ -205,11 +205,20 @@ class DetectorRuntime:
         desc_bytes = C.sizeof(_lib.RadetConvDesc)
 
         def unfold(bucket):
-            e.join_side()                       # weight-gradient GEMMs run on the side stream
             a, b = bucket["convs"]
-            K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
-            if bucket_hook is not None:
-                bucket_hook(bucket)
+            if e.use_streams:
+                # the slab reduction follows the bucket's weight-gradient GEMMs on the side stream, off the
+                # critical path of the dgrad chain; the all-reduce hook keys off the side stream too
+                side = e._side()
+                e._fork(side)
+                with torch.cuda.stream(side):
+                    K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
+                    if bucket_hook is not None:
+                        bucket_hook(bucket)
+            else:
+                K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
+                if bucket_hook is not None:
+                    bucket_hook(bucket)
 
         bk = {b["prefix"]: b for b in self.buckets}
         dP = e.head_backward()
@@ -217,6 +226,7 @@ class DetectorRuntime:
         d_feats = e.neck_backward(dP)
         unfold(bk["neck."])
         e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk[f"backbone.layer{li + 1}."]))
+        e.join_side()                           # gradients complete on the current stream from here on
         del sz
 
     # ------------------------------------------------------------------ optimiser

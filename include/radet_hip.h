@@ -62,6 +62,13 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                        float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                        int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream);
+/* Tap-subset variant for the dgrad of strided convs: GEMM row m writes output row out_rows[m]; only `ntaps` taps
+ * (tap_ids_host[t] = tap index inside the weight's kt_w taps) contribute; gather_table is [ntaps][Mp]. One launch
+ * per stride-parity class performs only the non-zero multiply-adds (no bias / relu; addend + mask supported). */
+int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                            const int* gather_table, const int* out_rows, const int* tap_ids_host, int ntaps, int kt_w,
+                            int M, int Cin, int Cout, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
+                            void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);

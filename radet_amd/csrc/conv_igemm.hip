@@ -26,6 +26,9 @@ struct ConvArgs {
     float* y;             // [M][Cout]
     const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
     float* partial;       // split-K: [sk][M][Cout] raw partial sums (epilogue applied by splitk_epilogue_kernel)
+    const int* out_rows;  // optional [M]: output row of GEMM row m (parity-class dgrad of strided convs)
+    int tap_ids[16];      // weight tap index of table tap t (identity unless a tap subset is used)
+    int KTw;              // taps in the weight tensor (row stride of w is KTw*Cin)
     int M, Mp, Cin, Cout, KH, KW;
     int relu;
     int sk, it_per_split; // K-stage range of block z = blockIdx.y: [z*it_per_split, min(nK, (z+1)*it_per_split))
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int u = 0; u < B_UNITS; ++u) {
         const int unit = tid + u * 256;
         const int n = n0 + (unit / F4);
-        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? a.w + (size_t)n * KT * a.Cin + k4 : nullptr;
+        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? a.w + (size_t)n * a.KTw * a.Cin + k4 : nullptr;
     }
 
     float4 ra[A_UNITS], rb[B_UNITS];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int u = 0; u < A_UNITS; ++u)
             ra[u] = arow[u] >= 0 ? *reinterpret_cast<const float4*>(a.x + (size_t)arow[u] * a.Cin + ld_c0 + k4)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int woff = ld_tap * a.Cin + ld_c0;
+        const int woff = a.tap_ids[ld_tap] * a.Cin + ld_c0;
 #pragma unroll
         for (int u = 0; u < B_UNITS; ++u)
             rb[u] = wp[u] ? *reinterpret_cast<const float4*>(wp[u] + woff) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= a.M) continue;
-                const size_t o = (size_t)row * a.Cout + col;
+                const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
                 float v = acc[i][j][r] + bv;
                 if (a.addend) v += a.addend[o];
                 if (a.relu) v = fmaxf(v, 0.f);
@@ -244,11 +247,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) 
         float v = 0.f;
         for (int z = 0; z < a.sk; ++z) v += a.partial[(size_t)z * total + o];
         const int col = (int)(o % a.Cout);
+        const size_t oo = a.out_rows ? (size_t)a.out_rows[o / a.Cout] * a.Cout + col : o;
         if (a.bias) v += a.bias[col];
-        if (a.addend) v += a.addend[o];
+        if (a.addend) v += a.addend[oo];
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-        a.y[o] = v;
+        if (a.mask) v = a.mask[oo] > 0.f ? v : 0.f;
+        a.y[oo] = v;
     }
 }
 
@@ -507,12 +511,40 @@ extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int s
     return radet_check_launch();
 }
 
+static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
+                      float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
+                      int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
+                      const int* tap_ids, int kt_w, void* stream);
+
 extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend,
                                   const float* mask, float* y, const int* gather_table, int M, int Cin, int Cout,
                                   int KH, int KW, int relu, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
                                   void* stream) {
-    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr) return RADET_ERR_ARG;
+    return igemm_impl(x, w, bias, addend, mask, y, gather_table, M, Cin, Cout, KH, KW, relu, tile_override, splitk_ws,
+                      splitk_ws_floats, nullptr, nullptr, 0, stream);
+}
+
+// Tap-subset variant: GEMM rows are a subset of the output rows (out_rows[m] = real output row) that share the
+// same set of contributing taps (tap_ids[t] = index into the weight's KTw taps); table is [ntaps][Mp].
+// Used for the dgrad of strided convs: one launch per parity class does only the non-zero work.
+extern "C" int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                                       const int* gather_table, const int* out_rows, const int* tap_ids_host, int ntaps,
+                                       int kt_w, int M, int Cin, int Cout, int tile_override, float* splitk_ws,
+                                       size_t splitk_ws_floats, void* stream) {
+    if (ntaps < 1 || ntaps > 16 || kt_w < ntaps || out_rows == nullptr || tap_ids_host == nullptr) return RADET_ERR_ARG;
+    return igemm_impl(x, w, nullptr, addend, mask, y, gather_table, M, Cin, Cout, ntaps, 1, 0, tile_override, splitk_ws,
+                      splitk_ws_floats, out_rows, tap_ids_host, kt_w, stream);
+}
+
+static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
+                      float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
+                      int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
+                      const int* tap_ids, int kt_w, void* stream) {
+    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr || KH * KW > 16) return RADET_ERR_ARG;
     ConvArgs a;
+    a.out_rows = out_rows;
+    for (int t = 0; t < 16; ++t) a.tap_ids[t] = tap_ids ? (t < KH * KW ? tap_ids[t] : 0) : t;
+    a.KTw = kt_w > 0 ? kt_w : KH * KW;
     a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.mask = mask; a.y = y;
     a.rowtab = gather_table;
     a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;

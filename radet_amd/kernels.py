@@ -52,6 +52,7 @@ def _desc(pairs):
 
 
 _TABLE_CACHE = {}
+STRIDED_DGRAD_CLASSES = True   # parity-class dgrad for strided convs (False = one dense launch)
 
 
 def _gather_table(key, B, k, so, sr, off, div, desc, nseg, rows):
@@ -109,6 +110,52 @@ def splitk_ws():
     return t
 
 
+def _strided_dgrad_classes(g):
+    """Parity classes of the dgrad of a strided conv (built once per geometry).
+
+    dx[h, w] only receives taps r with (h + pad - r) % stride == 0, so the rows of the dgrad GEMM split
+    into stride^2 classes by (h % stride, w % stride), each with a fixed subset of contributing taps.
+    One tap-subset launch per class does only the non-zero work (a dense launch wastes 75 % of the MFMAs
+    of a 3x3/2 conv).  Returns a list of dicts(table, out_rows, tap_ids, ntaps, rows, zero)."""
+    import numpy as np
+    key = ("cls",) + g._key
+    dev = torch.cuda.current_device()
+    ck = (dev,) + key
+    if ck in _TABLE_CACHE:
+        return _TABLE_CACHE[ck]
+    KT = g.k * g.k
+    M = g.lin.rows
+    mp = _lib.load().radet_gather_table_rows(M)
+    full = g.bwd_table.cpu().numpy().reshape(KT, mp)[:, :M]
+    cls_id = np.empty(M, np.int64)
+    for (h, w), off in zip(g.lin.hw, g.lin.offsets):
+        hh, ww = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        c = ((hh % g.stride) * g.stride + (ww % g.stride)).reshape(-1)
+        cls_id[off:off + g.B * h * w] = np.tile(c, g.B)
+    out, zero_rows = [], []
+    for c in range(g.stride * g.stride):
+        rows = np.nonzero(cls_id == c)[0]
+        if rows.size == 0:
+            continue
+        taps = [t for t in range(KT) if (full[t, rows] >= 0).any()]
+        if not taps:
+            zero_rows.append(rows)
+            continue
+        mpc = _lib.load().radet_gather_table_rows(rows.size)
+        tab = np.full((len(taps), mpc), -1, np.int32)
+        tab[:, :rows.size] = full[taps][:, rows]
+        out.append(dict(table=torch.from_numpy(tab).cuda(), out_rows=torch.from_numpy(rows.astype(np.int32)).cuda(),
+                        tap_ids=(C.c_int * len(taps))(*taps), ntaps=len(taps), rows=int(rows.size), zero=False))
+    if zero_rows:
+        rows = np.concatenate(zero_rows)
+        mpc = _lib.load().radet_gather_table_rows(rows.size)
+        tab = np.full((1, mpc), -1, np.int32)
+        out.append(dict(table=torch.from_numpy(tab).cuda(), out_rows=torch.from_numpy(rows.astype(np.int32)).cuda(),
+                        tap_ids=(C.c_int * 1)(0), ntaps=1, rows=int(rows.size), zero=True))
+    _TABLE_CACHE[ck] = out
+    return out
+
+
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
     ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
@@ -120,6 +167,13 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels
     ws = splitk_ws() if splitk else None
+    if g.stride > 1 and STRIDED_DGRAD_CLASSES:
+        for c in _strided_dgrad_classes(g):
+            # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table
+            _lib.call("radet_conv2d_igemm_taps", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
+                      _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"], 16 if c["zero"] else kc, g.cin,
+                      tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
+        return
     _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
 

@@ -17,6 +17,7 @@ FPN.forward (necks/fpn.py:170-221), ATSSHead.forward / RADetHead.forward_single
 (dense_heads/atss_head.py:100-145, radet_head.py:27-30) and their autograd backward.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -253,6 +254,10 @@ class Engine:
                 c.dbias_partials = self.bp_arena[o_b:o_b + n]
                 o_b += n
         self._build_table()
+        if os.environ.get("RADET_AUTOTUNE", "1") != "0":
+            for c in self.convs:
+                if c is not self.stem and c.geom is not None and c not in self.cls_tower and c not in self.reg_tower:
+                    K.autotune(c.geom, need_dgrad=c.need_dgrad)
 
     def _build_table(self):
         n = len(self.convs)

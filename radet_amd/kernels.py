@@ -82,6 +82,7 @@ class ConvGeom:
         self.fwd_desc, self.nseg = _desc(f)
         self.bwd_desc, _ = _desc(b)
         self._key = (tuple(lin.hw), tuple(lin.offsets), lin.B, k, stride, pad)
+        self.fwd_tile = self.bwd_tile = 0     # 0 = launcher heuristic; set by autotune()
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
 
     @property
@@ -156,7 +157,53 @@ def _strided_dgrad_classes(g):
     return out
 
 
+_TUNE_CACHE = {}
+
+
+def autotune(g, need_dgrad=True, reps=3):
+    """Pick the fastest (block tile, K step) of the implicit-GEMM kernel for this geometry by timing the
+    candidates once (results cached per shape, so identical layers and identical models agree)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def best_of(fn, cands):
+        out = []
+        for t in cands:
+            fn(t)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                fn(t)
+                e.record()
+                e.synchronize()
+                ts.append(s.elapsed_time(e))
+            out.append((sorted(ts)[len(ts) // 2], t))
+        return min(out)[1]
+
+    def cands(kdim, n):
+        tiles = [4] if n <= 32 else [1, 2, 3]
+        c = [t for t in tiles]
+        if kdim % 32 == 0:
+            c += [t | 0x200 for t in tiles]
+        return c
+
+    key = (g._key, g.cin, g.cout)
+    if key not in _TUNE_CACHE:
+        x = torch.randn(g.lin.rows, g.cin, device=dev)
+        w = torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05
+        y = torch.empty(g.lout.rows, g.cout, device=dev)
+        ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout))
+        bt = 0
+        if need_dgrad and g.stride == 1 and g.cout % 16 == 0:
+            dx = torch.empty(g.lin.rows, g.cin, device=dev)
+            bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin))
+        _TUNE_CACHE[key] = (ft, bt)
+    g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
+
+
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
+    tile = tile or g.fwd_tile
     ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
               g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
@@ -166,6 +213,7 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels
+    tile = tile or g.bwd_tile
     ws = splitk_ws() if splitk else None
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         for c in _strided_dgrad_classes(g):

@@ -1,0 +1,98 @@
+"""Other BASELINE.json configurations on the GPU: ResNet-101 backbone / non-640x480 inputs (config 5 geometry at a
+size the CPU oracle finishes in seconds), empty-gt batches, and the batched-NMS inference branch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make(depth, test_nms=None):
+    from oracle import synth
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    cfg.model["backbone"]["depth"] = depth
+    if test_nms:
+        cfg.test_cfg["nms"] = test_nms
+    d = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(d.state_dict(), seed=1)
+    return d.cuda()
+
+
+def batch(H, W, B, G=(3, 0)):
+    from oracle import assigner as oa, synth
+    img = synth.synth_images(5, B, H, W)
+    gt_b, gt_l, p2g, pw = [], [], [], []
+    for i in range(B):
+        g = G[i % len(G)]
+        rng = np.random.RandomState(40 + i)
+        boxes = np.zeros((g, 4), np.float32)
+        masks = np.zeros((g, H, W), np.uint8)
+        for k in range(g):
+            w, h = rng.randint(30, W // 2), rng.randint(30, H // 2)
+            x, y = rng.randint(0, W - w), rng.randint(0, H - h)
+            boxes[k] = (x, y, x + w, y + h)
+            masks[k, y:y + h, x + w // 4:x + w] = 1
+        labels = rng.randint(0, 21, g).astype(np.int64)
+        a, wt = oa.assign_points(boxes, labels, masks, (H, W, 3), rng=np.random.RandomState(i))
+        gt_b.append(torch.from_numpy(boxes)); gt_l.append(torch.from_numpy(labels))
+        p2g.append(torch.from_numpy(a)); pw.append(torch.from_numpy(wt))
+    return img, gt_b, gt_l, p2g, pw
+
+
+@pytest.mark.parametrize("depth,H,W", [(101, 200, 264), (50, 224, 224)])
+def test_train_step_vs_oracle(depth, H, W):
+    """Odd feature-map sizes (25x33 ... 2x3), an image without gts in the batch, R101."""
+    from oracle import model as om, synth
+    det = make(depth)
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2)
+    det.train()
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    sum(losses.values()).backward()
+    odet = om.OracleDetector(depth, seed=1)
+    ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+    om.parse_losses(ol).backward()
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), k
+    og = odet.named_grads()
+    tot = float(np.sqrt(sum(g.double().norm().item() ** 2 for g in og.values())))
+    for n, p in det.named_parameters():
+        if p.requires_grad:
+            a, b = p.grad.double().norm().item(), og[n].double().norm().item()
+            assert abs(a - b) <= 1e-3 * b + 1e-6 * tot, (n, a, b)
+
+
+def test_empty_batch_and_batched_nms_branch():
+    from oracle import model as om, synth
+    det = make(50, test_nms=dict(type="nms", iou_threshold=0.5))
+    H, W = 160, 192
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2, G=(0, 0))
+    det.train()
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    assert losses["loss_bbox"].item() == 0.0 and losses["loss_iou"].item() == 0.0 and losses["loss_cls"].item() > 0
+    sum(losses.values()).backward()
+    assert float(dict(det.named_parameters())["bbox_head.atss_reg.weight"].grad.abs().sum()) == 0.0
+    det.eval()
+    res = det(img=[img.cuda()], img_metas=[synth.img_metas(2, H, W)], return_loss=False, rescale=True)
+    odet = om.OracleDetector(50, seed=1, test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, max_per_img=100,
+                                                       nms=dict(type="nms", iou_threshold=0.5)))
+    ref = odet.simple_test(img, synth.img_metas(2, H, W))
+    for per_cls, (rb, rl) in zip(res, ref):
+        dets = np.concatenate([np.concatenate([d, np.full((d.shape[0], 1), c, np.float32)], 1) for c, d in enumerate(per_cls)], 0)
+        assert dets.shape[0] == rb.shape[0]
+        # hard NMS on ~5000 network-produced candidates is knife-edge sensitive (an IoU within 1e-6 of the threshold
+        # flips a keep decision), so the end-to-end check matches detections as a set; the NMS kernel itself is
+        # checked bit-exactly on fixed inputs in test_gpu_kernels.py::test_nms_ops_bit_exact
+        matched = 0
+        for row, lab in zip(rb, rl):
+            d = np.abs(dets[:, :5] - row[None, :]).max(1)
+            j = int(d.argmin())
+            matched += int(d[j] <= 2e-3 + 1e-4 * np.abs(row).max() and int(dets[j, 5]) == int(lab))
+        assert matched >= 0.95 * rb.shape[0], (matched, rb.shape[0])

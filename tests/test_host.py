@@ -152,3 +152,13 @@ def test_bbox2result_and_anchor_cpu_grid():
     a = ag.grid_anchors([(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)], device="cpu")
     g = np.load(os.path.join(REPO, "tests", "golden", "anchors.npz"))
     assert np.array_equal(torch.cat(a).numpy(), g["a480x640"])
+
+
+def test_reference_import_paths():
+    """`radet.*` import paths of the reference resolve to the MI355X implementation."""
+    from radet.models import DETECTORS, build_detector  # noqa: F401
+    from radet.core import build_anchor_generator, bbox2result  # noqa: F401
+    from radet.ops import vote_nms, global_vote_nms, cluster_nms  # noqa: F401
+    from radet.datasets import PIPELINES
+    import radet_amd.models
+    assert DETECTORS is radet_amd.models.DETECTORS and "LabelAssignment" in PIPELINES

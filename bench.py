@@ -183,12 +183,17 @@ def main():
                        "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
         if events:
+            traffic = None          # HBM bytes/launch of the roofline kernel from the committed PMC pass (offline)
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
             ms_list = [s.elapsed_time(e) for s, e in events]
             avg_ms = float(np.mean(ms_list))
             flops = rt.engine.tower_gemm_flops()
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32> (head-tower 3x3 conv GEMM, fwd+dgrad)",
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}

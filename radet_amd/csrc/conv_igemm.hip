@@ -32,6 +32,9 @@ struct ConvArgs {
     int M, Mp, Cin, Cout, KH, KW;
     int relu;
     int sk, it_per_split; // K-stage range of block z = blockIdx.y: [z*it_per_split, min(nK, (z+1)*it_per_split))
+    // tail split: tiles [0, n_full) run whole; the T % 256 left-over tiles (which would otherwise occupy a mostly
+    // empty last round on the 256 CUs) are cut sk_tail ways along K, their partial tiles reduced by a second pass
+    int n_full, sk_tail, it_per_tail;
 };
 
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
@@ -101,8 +104,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int tilesN = (a.Cout + BN - 1) / BN;
-    const int tilesM = (a.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tilesM * tilesN);
+    const bool tail = (int)blockIdx.x >= a.n_full;
+    const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;       // = tail_tile * sk_tail + k_slice
+    const int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
 
@@ -110,9 +114,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int RPU = 256 / F4;         // tile rows covered by one 256-thread load unit
     const int KT = a.KH * a.KW;
     const int cpt = a.Cin / BK;
-    const int it0 = blockIdx.y * a.it_per_split;
+    const int per = tail ? a.it_per_tail : a.it_per_split;
+    const int it0 = (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
     int nK = KT * cpt - it0;
-    if (nK > a.it_per_split) nK = a.it_per_split;
+    if (nK > per) nK = per;
 
     // loop-carried load state: (tap, c0) of the NEXT stage to fetch, rows of the current tap
     int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
@@ -203,6 +208,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 
     // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (tail) {       // raw partial tile, tile-local [BM][BN] layout; tail_epilogue_kernel finishes it
+        float* part = a.partial + (size_t)tail_slot * BM * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    part[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + (wn * TN + j) * 32 + li] = acc[i][j][r];
+        return;
+    }
     if (a.sk > 1) {   // split-K: raw partial sums, epilogue runs in splitk_epilogue_kernel
         float* part = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
 #pragma unroll
@@ -253,6 +269,27 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) 
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.mask) v = a.mask[oo] > 0.f ? v : 0.f;
         a.y[oo] = v;
+    }
+}
+
+// tail-split second pass: one workgroup per left-over tile sums its sk_tail partial tiles (fixed order) + epilogue
+__global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, int BM, int BN) {
+    const int tilesN = (a.Cout + BN - 1) / BN;
+    const int id = a.n_full + blockIdx.x;
+    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
+    const float* part = a.partial + (size_t)blockIdx.x * a.sk_tail * BM * BN;
+    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+        const int rl = e / BN, cl = e - rl * BN;
+        const int row = m0 + rl, col = n0 + cl;
+        if (row >= a.M || col >= a.Cout) continue;
+        float v = 0.f;
+        for (int z = 0; z < a.sk_tail; ++z) v += part[(size_t)z * BM * BN + e];
+        const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
+        if (a.bias) v += a.bias[col];
+        if (a.addend) v += a.addend[o];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
+        a.y[o] = v;
     }
 }
 
@@ -464,8 +501,26 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm(const ConvArgs& a, hipStream_t st, int tag, int bk) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats) {
+    ConvArgs a = a_in;
+    const int T = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    a.n_full = T; a.sk_tail = 1; a.it_per_tail = a.it_per_split;
+    const int nKs = a.KH * a.KW * (a.Cin / bk);
+    const int rem = T % 256;
+    // only for long K loops: on short kernels the extra epilogue launch costs more than the idle tail
+    if (a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 1152 &&
+        !getenv("RADET_NO_TAIL_SPLIT")) {
+        int skt = 256 / rem;
+        if (skt > 8) skt = 8;
+        if (skt > nKs / 8) skt = nKs / 8;
+        while (skt > 1 && (size_t)rem * skt * BM * BN > ws_floats) --skt;
+        if (skt >= 2) {
+            a.n_full = T - rem;
+            a.sk_tail = skt;
+            a.it_per_tail = (nKs + skt - 1) / skt;
+        }
+    }
+    const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
     if (bk == 32) {
         if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
@@ -479,6 +534,8 @@ static void launch_igemm(const ConvArgs& a, hipStream_t st, int tag, int bk) {
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, a);
     }
+    if (a.sk_tail > 1)
+        hipLaunchKernelGGL(tail_epilogue_kernel, dim3(T - a.n_full), dim3(256), 0, st, a, BM, BN);
 }
 
 static long igemm_tiles(int M, int N, int choice) {
@@ -587,10 +644,10 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.it_per_split = (nK + sk - 1) / sk;
     a.partial = splitk_ws;
     switch (choice) {
-        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk); break;
-        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk); break;
-        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk); break;
-        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk); break;
+        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
+        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
+        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
+        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats); break;
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();

@@ -51,6 +51,8 @@ CONV_CASES = [
     (1, 512, 512, 15, 20, 3, 1, 0x3003),     # forced split-K = 3, 64x64 tiles
     (1, 1024, 256, 15, 20, 1, 1, 0x2000),    # forced split-K = 2, heuristic tile
     (4, 2048, 512, 15, 20, 1, 1, 0),         # layer4 shape: heuristic picks split-K
+    (4, 256, 256, 80, 80, 3, 1, 0x203),      # 1600 tiles: the 64 left-over tiles are split along K (tail split)
+    (3, 128, 256, 40, 56, 3, 1, 2),          # 53 x 4 = 212... tiles with a ragged last M tile
 ]
 
 

@@ -190,11 +190,17 @@ def main():
                     traffic = json.load(f).get("traffic_bytes_per_launch")
             ms_list = [s.elapsed_time(e) for s, e in events]
             avg_ms = float(np.mean(ms_list))
+            # pair mode: most tower launches are grouped (cls + reg layer in one launch = 2x the flops)
             flops = rt.engine.tower_gemm_flops()
+            pair = rt.engine.tower_mode == "pair"
+            if pair:
+                n_per_step = len(ms_list) // args.steps
+                # per step: 4 fwd pairs + 3 dgrad pairs (2 GEMMs each) + 2 single dgrads into dL/dP
+                flops = flops * 16.0 / n_per_step
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32> (head-tower 3x3 conv GEMM, fwd+dgrad)",
+                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32> (head-tower 3x3 conv GEMMs fwd+dgrad; cls+reg layers grouped per launch; flop_per_launch = average)",
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:

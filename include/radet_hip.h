@@ -62,6 +62,12 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                        float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                        int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream);
+/* Two independent convolutions of identical geometry (cls / reg tower layers of the shared head) in ONE launch */
+int radet_conv2d_igemm_pair(const float* x0, const float* w0, const float* bias0, const float* addend0,
+                            const float* mask0, float* y0, const float* x1, const float* w1, const float* bias1,
+                            const float* addend1, const float* mask1, float* y1, const int* gather_table, int M, int Cin,
+                            int Cout, int KH, int KW, int relu, int tile_override, float* splitk_ws,
+                            size_t splitk_ws_floats, void* stream);
 /* Tap-subset variant for the dgrad of strided convs: GEMM row m writes output row out_rows[m]; only `ntaps` taps
  * (tap_ids_host[t] = tap index inside the weight's kt_w taps) contribute; gather_table is [ntaps][Mp]. One launch
  * per stride-parity class performs only the non-zero multiply-adds (no bias / relu; addend + mask supported). */

@@ -17,13 +17,18 @@
 #include "common.h"
 #include <stdlib.h>
 
-struct ConvArgs {
+struct ConvPtrs {
     const float* x;       // input rows [*, Cin]
     const float* w;       // [Cout][KH*KW][Cin]
     const float* bias;    // [Cout] or null
     const float* addend;  // [M][Cout] or null (added before relu / mask)
     const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
     float* y;             // [M][Cout]
+};
+
+struct ConvArgs {
+    ConvPtrs p[2];        // 1 or 2 independent problems of identical geometry in one launch (cls / reg tower)
+    int groups;
     const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
     float* partial;       // split-K: [sk][M][Cout] raw partial sums (epilogue applied by splitk_epilogue_kernel)
     const int* out_rows;  // optional [M]: output row of GEMM row m (parity-class dgrad of strided convs)
@@ -106,7 +111,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int tilesN = (a.Cout + BN - 1) / BN;
     const bool tail = (int)blockIdx.x >= a.n_full;
     const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;       // = tail_tile * sk_tail + k_slice
-    const int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
+    int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
+    const int tilesG = ((a.M + BM - 1) / BM) * tilesN;       // tiles per group
+    const int grp = id >= tilesG ? 1 : 0;
+    id -= grp * tilesG;
+    const ConvPtrs P = a.p[grp];
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
 
@@ -130,14 +139,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int u = 0; u < B_UNITS; ++u) {
         const int unit = tid + u * 256;
         const int n = n0 + (unit / F4);
-        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? a.w + (size_t)n * a.KTw * a.Cin + k4 : nullptr;
+        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? P.w + (size_t)n * a.KTw * a.Cin + k4 : nullptr;
     }
 
     float4 ra[A_UNITS], rb[B_UNITS];
     auto load_stage = [&]() {
 #pragma unroll
         for (int u = 0; u < A_UNITS; ++u)
-            ra[u] = arow[u] >= 0 ? *reinterpret_cast<const float4*>(a.x + (size_t)arow[u] * a.Cin + ld_c0 + k4)
+            ra[u] = arow[u] >= 0 ? *reinterpret_cast<const float4*>(P.x + (size_t)arow[u] * a.Cin + ld_c0 + k4)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
         const int woff = a.tap_ids[ld_tap] * a.Cin + ld_c0;
 #pragma unroll
@@ -241,17 +250,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + li;
             if (col >= a.Cout) continue;
-            const float bv = a.bias ? a.bias[col] : 0.f;
+            const float bv = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= a.M) continue;
                 const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
                 float v = acc[i][j][r] + bv;
-                if (a.addend) v += a.addend[o];
+                if (P.addend) v += P.addend[o];
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-                a.y[o] = v;
+                if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
+                P.y[o] = v;
             }
         }
 }
@@ -264,18 +273,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) 
         for (int z = 0; z < a.sk; ++z) v += a.partial[(size_t)z * total + o];
         const int col = (int)(o % a.Cout);
         const size_t oo = a.out_rows ? (size_t)a.out_rows[o / a.Cout] * a.Cout + col : o;
-        if (a.bias) v += a.bias[col];
-        if (a.addend) v += a.addend[oo];
+        if (a.p[0].bias) v += a.p[0].bias[col];
+        if (a.p[0].addend) v += a.p[0].addend[oo];
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.mask) v = a.mask[oo] > 0.f ? v : 0.f;
-        a.y[oo] = v;
+        if (a.p[0].mask) v = a.p[0].mask[oo] > 0.f ? v : 0.f;
+        a.p[0].y[oo] = v;
     }
 }
 
 // tail-split second pass: one workgroup per left-over tile sums its sk_tail partial tiles (fixed order) + epilogue
 __global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, int BM, int BN) {
     const int tilesN = (a.Cout + BN - 1) / BN;
-    const int id = a.n_full + blockIdx.x;
+    int id = a.n_full + blockIdx.x;
+    const int tilesG = ((a.M + BM - 1) / BM) * tilesN;
+    const int grp = id >= tilesG ? 1 : 0;
+    id -= grp * tilesG;
+    const ConvPtrs P = a.p[grp];
     const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
     const float* part = a.partial + (size_t)blockIdx.x * a.sk_tail * BM * BN;
     for (int e = threadIdx.x; e < BM * BN; e += 256) {
@@ -285,11 +298,11 @@ __global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, in
         float v = 0.f;
         for (int z = 0; z < a.sk_tail; ++z) v += part[(size_t)z * BM * BN + e];
         const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
-        if (a.bias) v += a.bias[col];
-        if (a.addend) v += a.addend[o];
+        if (P.bias) v += P.bias[col];
+        if (P.addend) v += P.addend[o];
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.mask) v = a.mask[o] > 0.f ? v : 0.f;
-        a.y[o] = v;
+        if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
+        P.y[o] = v;
     }
 }
 
@@ -503,7 +516,7 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
 template <int BM, int BN, int WM, int WN>
 static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats) {
     ConvArgs a = a_in;
-    const int T = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    const int T = a.groups * ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     a.n_full = T; a.sk_tail = 1; a.it_per_tail = a.it_per_split;
     const int nKs = a.KH * a.KW * (a.Cin / bk);
     const int rem = T % 256;
@@ -571,7 +584,20 @@ extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int s
 static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
-                      const int* tap_ids, int kt_w, void* stream);
+                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second = nullptr);
+
+// Two independent convolutions of identical geometry (the cls- and reg-tower layers of the shared head) as ONE
+// launch: twice the tiles per launch halves the wave-quantisation loss on 256 CUs and the launch count.
+extern "C" int radet_conv2d_igemm_pair(const float* x0, const float* w0, const float* bias0, const float* addend0,
+                                       const float* mask0, float* y0, const float* x1, const float* w1,
+                                       const float* bias1, const float* addend1, const float* mask1, float* y1,
+                                       const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
+                                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream) {
+    ConvPtrs second;
+    second.x = x1; second.w = w1; second.bias = bias1; second.addend = addend1; second.mask = mask1; second.y = y1;
+    return igemm_impl(x0, w0, bias0, addend0, mask0, y0, gather_table, M, Cin, Cout, KH, KW, relu, tile_override,
+                      splitk_ws, splitk_ws_floats, nullptr, nullptr, 0, stream, &second);
+}
 
 extern "C" int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend,
                                   const float* mask, float* y, const int* gather_table, int M, int Cin, int Cout,
@@ -596,13 +622,16 @@ extern "C" int radet_conv2d_igemm_taps(const float* x, const float* w, const flo
 static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
-                      const int* tap_ids, int kt_w, void* stream) {
+                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second) {
     if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr || KH * KW > 16) return RADET_ERR_ARG;
     ConvArgs a;
     a.out_rows = out_rows;
     for (int t = 0; t < 16; ++t) a.tap_ids[t] = tap_ids ? (t < KH * KW ? tap_ids[t] : 0) : t;
     a.KTw = kt_w > 0 ? kt_w : KH * KW;
-    a.x = x; a.w = w; a.bias = bias; a.addend = addend; a.mask = mask; a.y = y;
+    a.p[0].x = x; a.p[0].w = w; a.p[0].bias = bias; a.p[0].addend = addend; a.p[0].mask = mask; a.p[0].y = y;
+    a.p[1] = a.p[0];
+    a.groups = 1;
+    if (second != nullptr) { a.p[1] = *second; a.groups = 2; }
     a.rowtab = gather_table;
     a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW;
     a.relu = relu;
@@ -629,8 +658,8 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     const int nK = KH * KW * (Cin / bk);
     int sk = 1;
     const int sk_force = (tile_override >> 12) & 0xF;
-    const long tiles = igemm_tiles(a.M, Cout, choice);
-    if (splitk_ws != nullptr) {
+    const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;
+    if (splitk_ws != nullptr && a.groups == 1) {
         if (sk_force) sk = sk_force;
         else if (tiles < 384) {
             sk = (int)((512 + tiles - 1) / tiles);

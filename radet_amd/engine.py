@@ -223,7 +223,9 @@ class Engine:
                 new(f"{t}.y{i}", R, f)
                 self.buf[f"{t}.stats{i}"] = torch.empty(len(hw) * B * 64, device=dev)
             new(f"{t}.dy", R, f)
-            new(f"{t}.dz", R, f)
+            new(f"{t}.dz0", R, f)      # two alternating GN-backward outputs: the async wgrad of layer i may still
+            new(f"{t}.dz1", R, f)      # read dz[i & 1] while layer i-1 writes the other one
+            self.buf[f"{t}.dz"] = self.buf[f"{t}.dz0"]
         for c in self.cls_tower + self.reg_tower:
             c.geom = ConvGeom(self.plv, f, f, 3, 1, 1)
         for c in (self.pred_cls, self.pred_reg, self.pred_iou):
@@ -372,11 +374,14 @@ class Engine:
         """Weight-gradient GEMM off the critical path: issued on the side stream once `dy` is ready."""
         if not self.use_streams:
             K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
-            return
+            return None
         side = self._side()
         self._fork(side)
         with torch.cuda.stream(side):
             K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
+            ev = self._event()
+            ev.record()
+        return ev   # completes when this weight-gradient GEMM has finished reading dy / x
 
     def join_side(self):
         """Current stream waits for all side-stream work (call before consuming wgrad slabs)."""
@@ -392,10 +397,31 @@ class Engine:
         K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], ws)
         return y
 
+    tower_mode = os.environ.get("RADET_TOWER_MODE", "streams")   # "pair": cls+reg layer = one grouped launch; "streams"
+
+    def _tower_pair_fwd(self, i, xc, xr):
+        """cls_convs[i] and reg_convs[i] as ONE grouped GEMM launch, then the two GroupNorm+ReLU."""
+        b, p = self.buf, self.p
+        cc, cr = self.cls_tower[i], self.reg_tower[i]
+        zc, yc, zr, yr = b[f"cls.z{i}"], b[f"cls.y{i}"], b[f"reg.z{i}"], b[f"reg.y{i}"]
+        self._tower_launch(K.conv_fwd_pair, cc.geom, dict(x=xc, w=cc.wf, y=zc), dict(x=xr, w=cr.wf, y=zr),
+                           tile=self.TOWER_TAG)
+        for t, z, y in (("cls", zc, yc), ("reg", zr, yr)):
+            gn = f"bbox_head.{t}_convs.{i}.gn"
+            K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], self.gn_ws)
+        return yc, yr
+
     def head_forward(self, P):
         b = self.buf
         n = self.stacked_convs
-        if self.use_streams:
+        if self.tower_mode == "pair":
+            xc = xr = P
+            for i in range(n):
+                xc, xr = self._tower_pair_fwd(i, xc, xr)
+            K.conv_fwd(self.pred_cls.geom, xc, self.pred_cls.wf, self.pred_cls.bias_f, b["cls"])
+            K.conv_fwd(self.pred_reg.geom, xr, self.pred_reg.wf, self.pred_reg.bias_f, b["reg_u"])
+            K.conv_fwd(self.pred_iou.geom, xr, self.pred_iou.wf, self.pred_iou.bias_f, b["iou"])
+        elif self.use_streams:
             side = self._side()
             self._fork(side)
             xc = xr = P
@@ -455,6 +481,32 @@ class Engine:
             K.conv_wgrad(pi.geom, dri.view(-1)[4:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=16)
             K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=16)
 
+    def _tower_bwd_head_async(self, t):
+        """like _tower_bwd_head, with the predictor weight-gradient GEMMs on the side stream"""
+        b = self.buf
+        ylast = b[f"{t}.y{self.stacked_convs - 1}"]
+        dy = b[f"{t}.dy"]
+        side = self._side() if self.use_streams else None
+
+        def wg(*a, **k):
+            if side is None:
+                K.conv_wgrad(*a, **k)
+            else:
+                self._fork(side)
+                with torch.cuda.stream(side):
+                    K.conv_wgrad(*a, **k)
+
+        if t == "cls":
+            pc = self.pred_cls
+            wg(pc.geom, b["dcls"], ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
+            K.conv_dgrad(pc.geom, b["dcls"], pc.wft, dy, k_channels=self.cls_pad)
+        else:
+            pr, pi = self.pred_reg, self.pred_iou
+            dri = b["dregiou"]
+            wg(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=16)
+            wg(pi.geom, dri.view(-1)[4:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=16)
+            K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=16)
+
     def _tower_bwd_layer(self, t, tower, i, ws, dP, addend):
         b, p, g = self.buf, self.p, self.g
         c = tower[i]
@@ -474,7 +526,30 @@ class Engine:
         b = self.buf
         n = self.stacked_convs
         dP = b["dP"]
-        if self.use_streams:
+        if self.tower_mode == "pair":
+            p, g = self.p, self.g
+            self._tower_bwd_head_async("cls")
+            self._tower_bwd_head_async("reg")
+            wg_done = {}
+            for i in range(n - 1, -1, -1):
+                for t, tower in (("cls", self.cls_tower), ("reg", self.reg_tower)):
+                    gn = f"bbox_head.{t}_convs.{i}.gn"
+                    ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                    K.gn_relu_bwd(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                  p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
+                    x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
+                    wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
+                cc, cr = self.cls_tower[i], self.reg_tower[i]
+                dzc, dzr = b[f"cls.dz{i & 1}"], b[f"reg.dz{i & 1}"]
+                if i > 0:
+                    self._tower_launch(K.conv_dgrad_pair, cc.geom, dict(x=dzc, w=cc.wft, y=b["cls.dy"]),
+                                       dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self.TOWER_TAG)
+                else:   # both write dL/dP: the second accumulates onto the first
+                    self._tower_launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self.TOWER_TAG)
+                    self._tower_launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self.TOWER_TAG)
+        elif self.use_streams:
             side = self._side()
             self._fork(side)
             self._tower_bwd_head("cls")

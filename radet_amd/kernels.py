@@ -210,6 +210,23 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
               _stream())
 
 
+def conv_fwd_pair(g, a, b, relu=False, tile=0):
+    """a, b: dicts(x, w, bias, addend, mask, y) -- two convs of geometry g in one launch."""
+    ws = splitk_ws()
+    q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
+    _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.fwd_table), g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu),
+              tile or g.fwd_tile, _ptr(ws), C.c_size_t(ws.numel()), _stream())
+
+
+def conv_dgrad_pair(g, a, b, tile=0):
+    """a, b: dicts(x=dy, w=wft, addend, mask, y=dx) -- two stride-1 dgrads of geometry g in one launch."""
+    assert g.stride == 1
+    ws = splitk_ws()
+    q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
+    _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.bwd_table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
+              tile or g.bwd_tile, _ptr(ws), C.c_size_t(ws.numel()), _stream())
+
+
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels

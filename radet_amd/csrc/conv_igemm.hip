@@ -483,6 +483,142 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps
+// 3x3 convs: one workgroup owns a (128 output-channel) x (32 input-channel) tile of ALL nine taps for its pixel
+// split.  The dy tile is loaded once per stage instead of once per tap, and the nine shifted x tiles overlap
+// in L1 (they read the same 3x(16+2) pixel rows), so the L2->LDS traffic per MAC drops ~2.4x against the
+// one-tap kernel above, and 72 MFMAs (9 taps x 8 K steps) run between barriers instead of 32.
+// Wave w owns output channels [32w, 32w+32): 9 accumulator tiles (144 AGPRs), one A fragment feeds 9 MFMAs.
+template <int NW>   // NW waves: block tile = (32*NW output channels) x 32 input channels x 9 taps
+__global__ __launch_bounds__(NW * 64) void conv_wgrad9_kernel(const WgradArgs a) {
+    constexpr int BP = 16, BM = 32 * NW, BC = 32, KT = 9, NT = NW * 64;
+    constexpr int A_UNITS = BP * BM / 4 / NT;             // 2
+    constexpr int B_TOTAL = KT * BP * BC / 4;             // 1152 float4 per stage
+    constexpr int B_UNITS = (B_TOTAL + NT - 1) / NT;      // 5 (4 waves) / 3 (8 waves)
+    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KT * BP * BC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * BP;
+    int p_end = p_begin + a.chunks_per_split * BP;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    float4 ra[A_UNITS], rb[B_UNITS];
+    bool am[A_UNITS], bm[B_UNITS];
+    float4 bsum[A_UNITS];
+#pragma unroll
+    for (int u = 0; u < A_UNITS; ++u) bsum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-unit constants of the x-tile loads: tap, pixel-in-stage, channel offset
+    int brow[B_UNITS];
+    bool bvalid[B_UNITS];
+    // unit -> (tap, pixel-in-stage, channel) are shifts of the unit index (128 float4 per tap tile, 8 per pixel)
+#define W9_TAP(unit) ((unit) >> 7)
+#define W9_PIX(unit) (((unit) & 127) >> 3)
+#define W9_CH(unit) (c0 + ((unit) & 7) * 4)
+#pragma unroll
+    for (int u = 0; u < B_UNITS; ++u) {
+        const int unit = tid + u * NT;
+        const int m = p_begin + W9_PIX(unit);
+        bvalid[u] = unit < B_TOTAL && m < p_end;
+        brow[u] = a.rowtab[(size_t)(bvalid[u] ? W9_TAP(unit) : 0) * a.Mp + (bvalid[u] ? m : 0)];
+    }
+    auto load_stage = [&](int it) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const int unit = tid + u * NT;
+            const int j = unit / (BM / 4), o = o0 + (unit % (BM / 4)) * 4;
+            const int m = p0 + j;
+            am[u] = (m < p_end) && (o < a.Cout);
+            ra[u] = *reinterpret_cast<const float4*>(a.dy + (am[u] ? (size_t)m * a.ld_dy + o : (size_t)0));
+        }
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * NT;
+            const int m = p0 + W9_PIX(unit);
+            bm[u] = bvalid[u] && brow[u] >= 0;
+            rb[u] = *reinterpret_cast<const float4*>(a.x + (bm[u] ? (size_t)brow[u] * a.Cin + W9_CH(unit) : (size_t)0));
+            bvalid[u] = unit < B_TOTAL && (m + BP < p_end);
+            brow[u] = a.rowtab[(size_t)(bvalid[u] ? W9_TAP(unit) : 0) * a.Mp + (bvalid[u] ? m + BP : 0)];
+        }
+    };
+    auto store_stage = [&](int buf) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) {
+            const float4 v = am[u] ? ra[u] : z4;
+            *reinterpret_cast<float4*>(&As[buf][(tid + u * NT) * 4]) = v;
+            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < B_UNITS; ++u) {
+            const int unit = tid + u * NT;
+            if (unit < B_TOTAL) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = bm[u] ? rb[u] : z4;
+        }
+    };
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (nIt > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) load_stage(it + 1);
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk) {
+            const float af = As[buf][(2 * kk + lh) * BM + wave * 32 + li];
+            float bf[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bf[t] = Bs[buf][(t * BP + 2 * kk + lh) * BC + li];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[t], acc[t], 0, 0, 0);
+        }
+        if (it + 1 < nIt) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (a.dbias_partials && tc == 0) {
+#pragma unroll
+        for (int u = 0; u < A_UNITS; ++u) *reinterpret_cast<float4*>(&As[0][(tid + u * NT) * 4]) = bsum[u];
+        __syncthreads();
+        if (tid < BM && o0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < BP; ++j) t += As[0][j * BM + tid];
+            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
+        }
+    }
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < a.Cout) out[((size_t)o * KT + t) * a.Cin + c] = acc[t][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -688,6 +824,16 @@ static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
 }
 
+static int wgrad9_bm(int Cout) { return (Cout >= 256 && !getenv("RADET_WGRAD9_BM128")) ? 256 : 128; }
+
+// all-taps kernel: pays off for 3x3 convs with >= 256 output channels and a long pixel dimension (head towers,
+// FPN P3): measured 96.6 vs 84.5 TFLOP/s on the tower shape; for the short-M backbone stages the one-tap kernel
+// with its finer tile grid stays ahead (tools/bench_conv.py)
+static bool use_wgrad9(int M, int Cin, int Cout, int KH, int KW) {
+    return KH == 3 && KW == 3 && Cin % 32 == 0 && Cout >= 256 && M >= 16384 && !getenv("RADET_NO_WGRAD9");
+}
+
+
 static void wgrad_tile(int Cout, int Cin, int* bm, int* bn) {
     if (Cout <= 32) { *bm = 32; *bn = 128; }
     else if (Cout <= 64 || Cin <= 64) { *bm = 64; *bn = 64; }
@@ -698,10 +844,21 @@ static void wgrad_tile(int Cout, int Cin, int* bm, int* bn) {
 extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
     wgrad_tile(Cout, Cin, &bm, &bn);
-    const long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
+    long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
+    if (use_wgrad9(M, Cin, Cout, KH, KW)) {
+        const int b9 = wgrad9_bm(Cout);
+        tiles = (long)((Cout + b9 - 1) / b9) * (Cin / 32);
+    }
     const int chunks = (M + 15) / 16;
     // pick S in the 2..4 blocks-per-CU range whose block count quantises best onto 256 CUs
     long lo = (448 + tiles - 1) / tiles, hi = (1024 + tiles - 1) / tiles;
+    if (use_wgrad9(M, Cin, Cout, KH, KW) && wgrad9_bm(Cout) == 256) {
+        // 8-wave workgroups: one per CU already gives 2 waves per SIMD, and every extra split costs a full
+        // weight-sized slab write + read in unfold
+        lo = hi = (256 + tiles - 1) / tiles;
+        const char* e9 = getenv("RADET_WGRAD9_BLOCKS");
+        if (e9) lo = hi = (atol(e9) + tiles / 2) / tiles;
+    }
     { const char* e = getenv("RADET_WGRAD_BLOCKS"); if (e) lo = hi = (atol(e) + tiles / 2) / tiles; }
     if (lo < 1) lo = 1;
     long S = lo;
@@ -737,6 +894,16 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
+    if (use_wgrad9(M, Cin, Cout, KH, KW)) {
+        if (wgrad9_bm(Cout) == 256) {
+            const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
+            hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+        } else {
+            const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
+            hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
+        }
+        return radet_check_launch();
+    }
     int bm, bn;
     wgrad_tile(Cout, Cin, &bm, &bn);
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);

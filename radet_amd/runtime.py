@@ -5,6 +5,8 @@ with backward + fused clip/AdamW) and inference (decode + NMS).
 Replaces what the reference obtains from torch autograd + mmcv's DDP wrapper / OptimizerHook
 (radet/apis/train.py:73-126, radet/models/detectors/base.py:185-253).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -253,7 +255,10 @@ class DetectorRuntime:
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.forward(img)
         self.loss(tg)
-        if world > 1:
+        # a 1-rank process group still exercises the bucketed exchange when forced (single-GPU test of the RCCL path)
+        use_reducer = world > 1 or (world == 1 and dist.is_available() and dist.is_initialized()
+                                    and os.environ.get("RADET_FORCE_REDUCER") == "1")
+        if use_reducer:
             if self.reducer is None:
                 self.reducer = GradReducer(self.flat.grads, self.dev)
             self.backward(self.reducer.bucket_ready)

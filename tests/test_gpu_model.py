@@ -126,3 +126,34 @@ def test_native_train_step_matches_autograd(det, golden):
                 d = (pa[n].detach() - pb[n].detach()).abs().max().item()
                 assert d <= 1e-6, (n, d)
             assert abs(rt.opt_state["grad_norm"].item() - float(golden("model")["total_grad_norm"])) < 1e-3 * 1053
+
+
+def test_rccl_bucket_exchange_single_rank(det, golden):
+    """The data-parallel step with a 1-rank RCCL group: bucketed async all-reduce on the comm stream, unfold on the
+    side stream, mean folded into AdamW -- must equal the plain single-GPU step bit for bit."""
+    import torch.distributed as dist
+    from oracle import synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        img = synth.synth_images(0, 2).cuda()
+        gt_b, gt_l, p2g, pw = targets(golden)
+        a, b = make_det(), make_det()
+        a.train(); b.train()
+        ra, rb = a.runtime(), b.runtime()
+        for rt in (ra, rb):
+            rt.init_optimizer()
+        tg = ra.pack_targets(gt_b, gt_l, p2g, pw)
+        os.environ["RADET_FORCE_REDUCER"] = "1"
+        la = ra.train_step(img, tg).clone()
+        os.environ["RADET_FORCE_REDUCER"] = "0"
+        lb = rb.train_step(img, tg).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb)
+        assert ra.reducer is not None and rb.reducer is None
+        assert torch.equal(ra.flat.grads, rb.flat.grads) and torch.equal(ra.flat.params, rb.flat.params)
+    finally:
+        os.environ["RADET_FORCE_REDUCER"] = "0"
+        dist.destroy_process_group()

@@ -200,7 +200,9 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32> (head-tower 3x3 conv GEMMs fwd+dgrad; cls+reg layers grouped per launch; flop_per_launch = average)",
+                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304), "
+                                         "fwd+dgrad launches" + ("; cls+reg layers grouped per launch, flop_per_launch = average" if pair
+                                                                 else "; cls and reg towers run concurrently on two streams"),
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:

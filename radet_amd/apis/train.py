@@ -1,0 +1,101 @@
+"""Iteration-based training harness around the native train step.
+
+Reproduces what the reference delegates to mmcv (radet/apis/train.py:87-169, configs/base/default_runtime.py:1-26):
+IterBasedRunner loop, AdamW + grad-clip (fused on the GPU), OneCycle learning rate with mmcv's defaults
+(div_factor 25, final_div_factor 1e4, linear anneal, two phases), text log every `interval` iterations (one 3-float
+device->host read instead of the reference's four blocking all-reduces per iteration) and checkpoints whose
+`state_dict` uses the reference's parameter names."""
+import time
+
+import torch
+import torch.distributed as dist
+
+
+class OneCycleLR:
+    """mmcv OneCycleLrUpdaterHook (policy='OneCycle', anneal_strategy='linear', three_phase=False)."""
+
+    def __init__(self, max_lr, total_steps, pct_start=0.3, anneal_strategy="linear", div_factor=25.0,
+                 final_div_factor=1e4, three_phase=False):
+        if anneal_strategy not in ("linear", "cos"):
+            raise ValueError("anneal_strategy must be 'cos' or 'linear'")
+        if three_phase:
+            raise NotImplementedError("three_phase=True is not used by the RADet configs")
+        self.max_lr, self.total_steps, self.anneal = float(max_lr), int(total_steps), anneal_strategy
+        self.initial_lr = self.max_lr / div_factor
+        self.min_lr = self.initial_lr / final_div_factor
+        self.up_end = float(pct_start * total_steps) - 1
+        self.down_end = float(total_steps) - 1
+
+    def _anneal(self, start, end, pct):
+        if self.anneal == "linear":
+            return (end - start) * pct + start
+        import math
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1)
+
+    def get_lr(self, step):
+        """Learning rate used for iteration `step` (0-based), exactly torch.optim.lr_scheduler.OneCycleLR's value."""
+        if step > self.down_end:
+            raise ValueError(f"step {step} exceeds total_steps {self.total_steps}")
+        if step <= self.up_end:
+            return self._anneal(self.initial_lr, self.max_lr, step / self.up_end)
+        return self._anneal(self.max_lr, self.min_lr, (step - self.up_end) / (self.down_end - self.up_end))
+
+
+def save_checkpoint(model, path, meta=None, runtime=None):
+    """mmcv-style checkpoint: dict(meta=..., state_dict=..., optimizer=...) with reference parameter names."""
+    ckpt = dict(meta=dict(meta or {}), state_dict={k: v.detach().cpu() for k, v in model.state_dict().items()})
+    if runtime is not None and runtime.opt_state is not None:
+        st = runtime.opt_state
+        ckpt["optimizer"] = dict(step=runtime.step_count, exp_avg=st["m"].cpu(), exp_avg_sq=st["v"].cpu())
+    torch.save(ckpt, path)
+    return path
+
+
+def load_checkpoint(model, path, strict=False, runtime=None):
+    ckpt = torch.load(path, map_location="cpu")
+    sd = ckpt.get("state_dict", ckpt)
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    missing = model.load_state_dict(sd, strict=strict)      # copies in place: parameters stay in the flat arena
+    if runtime is not None and "optimizer" in ckpt and runtime.opt_state is not None:
+        runtime.step_count = int(ckpt["optimizer"]["step"])
+        runtime.opt_state["m"].copy_(ckpt["optimizer"]["exp_avg"])
+        runtime.opt_state["v"].copy_(ckpt["optimizer"]["exp_avg_sq"])
+    return ckpt.get("meta", {}), missing
+
+
+def train_detector(model, batches, cfg, max_iters=None, log=print, checkpoint_path=None):
+    """`batches`: iterable of dict(img=f32[B,3,H,W], gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+    (device or host tensors; lists per image).  One process per GPU; gradients are averaged over the
+    `torch.distributed` group if one is initialised.  Returns the list of logged loss triples."""
+    rt = model.train().runtime()
+    o = cfg.optimizer
+    clip = cfg.get("optimizer_config", {}).get("grad_clip") or {}
+    rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
+                      max_norm=float(clip.get("max_norm", 0.0)))
+    head = model.bbox_head
+    rt.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
+                           lbw=float(head.loss_bbox.loss_weight))
+    lc = cfg.lr_config
+    sched = OneCycleLR(lc.max_lr, lc.total_steps, pct_start=lc.get("pct_start", 0.3),
+                       anneal_strategy=lc.get("anneal_strategy", "cos"))
+    max_iters = max_iters or cfg.runner.max_iters
+    interval = cfg.get("log_config", {}).get("interval", 50)
+    ckpt_every = cfg.get("checkpoint_config", {}).get("interval", 0)
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    history, t0 = [], time.time()
+    for it, batch in enumerate(batches):
+        if it >= max_iters:
+            break
+        lr = sched.get_lr(it)
+        tg = rt.pack_targets(batch["gt_bboxes"], batch["gt_labels"], batch["points_to_gt_index"], batch["points_weight"])
+        losses = rt.train_step(batch["img"].to(rt.dev), tg, lr=lr)
+        if (it + 1) % interval == 0 or it + 1 == max_iters:
+            vals = torch.cat([losses, rt.opt_state["grad_norm"]]).cpu().tolist()     # the only host sync
+            history.append(vals[:3])
+            if rank == 0:
+                log(f"Iter [{it + 1}/{max_iters}] lr: {lr:.3e}, loss_cls: {vals[0]:.4f}, loss_bbox: {vals[1]:.4f}, "
+                    f"loss_iou: {vals[2]:.4f}, loss: {sum(vals[:3]):.4f}, grad_norm: {vals[3]:.4f}, "
+                    f"time: {(time.time() - t0) / (it + 1):.4f} s/iter")
+        if checkpoint_path and ckpt_every and (it + 1) % ckpt_every == 0 and rank == 0:
+            save_checkpoint(model, checkpoint_path.format(iter=it + 1), meta=dict(iter=it + 1), runtime=rt)
+    return history

@@ -162,3 +162,37 @@ def test_reference_import_paths():
     from radet.datasets import PIPELINES
     import radet_amd.models
     assert DETECTORS is radet_amd.models.DETECTORS and "LabelAssignment" in PIPELINES
+
+
+def test_onecycle_matches_torch():
+    """mmcv's OneCycle hook == torch.optim.lr_scheduler.OneCycleLR (linear, two-phase) for the config's values."""
+    from radet_amd.apis import OneCycleLR
+    total, max_lr, pct = 1000, 4e-4, 0.05
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=max_lr)
+    ref = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=max_lr, total_steps=total, pct_start=pct,
+                                              anneal_strategy="linear", div_factor=25.0, final_div_factor=1e4)
+    mine = OneCycleLR(max_lr, total, pct_start=pct, anneal_strategy="linear")
+    for step in range(total):
+        assert abs(opt.param_groups[0]["lr"] - mine.get_lr(step)) <= 1e-12 + 1e-9 * max_lr, step
+        opt.step()
+        if step + 1 < total:
+            ref.step()
+    assert abs(mine.get_lr(0) - 1.6e-5) < 1e-12 and abs(mine.get_lr(total - 1) - 1.6e-9) < 1e-15
+
+
+def test_checkpoint_roundtrip_cpu(tmp_path):
+    from radet_amd.apis import load_checkpoint, save_checkpoint
+    a, b = build(), build()
+    for p in a.parameters():
+        torch.nn.init.normal_(p, 0, 0.02)
+    path = save_checkpoint(a, str(tmp_path / "iter_{iter}.pth").format(iter=7), meta=dict(iter=7, CLASSES=("a", "b")))
+    meta, _ = load_checkpoint(b, path, strict=True)
+    assert meta["iter"] == 7
+    sa, sb = a.state_dict(), b.state_dict()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    # a reference-style checkpoint saved from a DDP-wrapped model ("module." prefix) also loads
+    torch.save(dict(state_dict={"module." + k: v for k, v in sa.items()}, meta={}), str(tmp_path / "ddp.pth"))
+    c = build()
+    load_checkpoint(c, str(tmp_path / "ddp.pth"), strict=True)
+    assert torch.equal(c.state_dict()["bbox_head.atss_cls.weight"], sa["bbox_head.atss_cls.weight"])

@@ -834,16 +834,24 @@ static bool use_wgrad9(int M, int Cin, int Cout, int KH, int KW) {
 }
 
 
-static void wgrad_tile(int Cout, int Cin, int* bm, int* bn) {
-    if (Cout <= 32) { *bm = 32; *bn = 128; }
-    else if (Cout <= 64 || Cin <= 64) { *bm = 64; *bn = 64; }
-    else { *bm = 128; *bn = 128; }
+// Tile of the one-tap wgrad kernel.  Short pixel dimensions (M) would need many K-splits to fill the GPU with
+// 128x128 tiles, and every split costs a weight-sized slab write + read; a 64x64 tile grid has 4x the tiles, so a
+// quarter of the splits, at a modest loss of MFMA efficiency -> preferred when M is short.
+static void wgrad_tile(int M, int Cout, int Cin, int KT, int* bm, int* bn) {
+    if (Cout <= 32) { *bm = 32; *bn = 128; return; }
+    if (Cout <= 64 || Cin <= 64) { *bm = 64; *bn = 64; return; }
+    *bm = 128; *bn = 128;
+    const long tiles128 = (long)((Cout + 127) / 128) * ((Cin + 127) / 128) * KT;
+    const long s128 = (448 + tiles128 - 1) / tiles128;
+    const char* e = getenv("RADET_WGRAD_TILE64_M");
+    const int mthr = e ? atoi(e) : 0;   // measured: no net gain on R50 640x480 (kept as a switch)
+    if (M <= mthr && s128 >= 4) { *bm = 64; *bn = 64; }
 }
 
 // Number of pixel splits the wgrad launcher will use (callers size the slab buffer with it).
 extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
-    wgrad_tile(Cout, Cin, &bm, &bn);
+    wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
     long tiles = (long)((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW;
     if (use_wgrad9(M, Cin, Cout, KH, KW)) {
         const int b9 = wgrad9_bm(Cout);
@@ -905,7 +913,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
         return radet_check_launch();
     }
     int bm, bn;
-    wgrad_tile(Cout, Cin, &bm, &bn);
+    wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
     else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
     else launch_wgrad<128, 128, 2, 2>(a, st);

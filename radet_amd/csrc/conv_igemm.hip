@@ -619,6 +619,131 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9_kernel(const WgradArgs a)
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, LDS-DMA
+// Same tiling as conv_wgrad9_kernel, but the dy tile and the nine x tiles go global -> LDS directly
+// (global_load_lds_dwordx4: each wave instruction lands 1 KiB lane-linearly, which is exactly one 256-channel dy
+// row or eight 32-channel x rows of the unpadded tiles).  No staging VGPRs (the register-staged version spills its
+// prefetch registers next to 144 accumulators), no ds_write pass; padding / out-of-range rows are read from a zero page.
+__device__ __attribute__((aligned(16))) float radet_zero_page[512];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a) {
+    constexpr int BP = 16, BM = 32 * NW, BC = 32, KT = 9, NT = NW * 64;
+    constexpr int A_INSTR = BP * BM * 4 / 1024;             // wave instructions per dy tile (1 KiB each)
+    constexpr int B_INSTR = KT * BP * BC * 4 / 1024;        // 18
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;
+    constexpr int ROWS_A = 1024 / (BM * 4);                 // dy rows per instruction (1 for BM=256, 2 for BM=128)
+    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][KT * BP * BC];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * BP;
+    int p_end = p_begin + a.chunks_per_split * BP;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    // gather-table rows of the NEXT stage for this wave's x-tile instructions (loaded one stage ahead)
+    int brow[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int ins = wave + k * NW - A_INSTR;             // x-tile instruction index (tap, half)
+        brow[k] = -1;
+        if (ins >= 0 && ins < B_INSTR) {
+            const int m = p_begin + (ins & 1) * 8 + (lane >> 3);
+            brow[k] = m < p_end ? a.rowtab[(size_t)(ins >> 1) * a.Mp + m] : -1;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int j = ins * ROWS_A + (ROWS_A == 1 ? 0 : (lane * 4) / BM);
+                const int o = o0 + (lane * 4) % BM;
+                const int m = p0 + j;
+                const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
+            } else if (ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const float* src = brow[k] >= 0 ? a.x + (size_t)brow[k] * a.Cin + c0 + (lane & 7) * 4
+                                               : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+                const int m = p0 + BP + (bi & 1) * 8 + (lane >> 3);
+                brow[k] = m < p_end ? a.rowtab[(size_t)(bi >> 1) * a.Mp + m] : -1;
+            }
+        }
+    };
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;                                        // column sum of dy for o = o0 + tid % BM (bias gradient)
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+
+    if (nIt > 0) issue_stage(0, 0);
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk) {
+            const float af = As[buf][(2 * kk + lh) * BM + wave * 32 + li];
+            float bf[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) bf[t] = Bs[buf][(t * BP + 2 * kk + lh) * BC + li];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[t], acc[t], 0, 0, 0);
+        }
+        if (want_bias) {
+            constexpr int RPT = BP * BM / NT;                // rows per thread: 8
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) bsum += As[buf][((tid / BM) * RPT + j) * BM + (tid % BM)];
+        }
+        __syncthreads();
+    }
+
+    if (want_bias) {
+        constexpr int GROUPS = NT / BM;                      // 2
+        __syncthreads();
+        As[0][tid] = bsum;
+        __syncthreads();
+        if (tid < BM && o0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) t += As[0][g * BM + tid];
+            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
+        }
+    }
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < a.Cout) out[((size_t)o * KT + t) * a.Cin + c] = acc[t][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -905,7 +1030,8 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (use_wgrad9(M, Cin, Cout, KH, KW)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
-            hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+            if (getenv("RADET_WGRAD9_REGSTAGE")) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL(conv_wgrad9g_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
             hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);

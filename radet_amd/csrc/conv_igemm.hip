@@ -744,6 +744,140 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, one tap, LDS-DMA
+// conv_wgrad_kernel with the dy / x tiles brought in by global_load_lds (see conv_wgrad9g_kernel): the unpadded
+// [pixel][channel] tiles are lane-linear images of 1-KiB wave loads, so no staging registers and no ds_write pass.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
+    constexpr int BP = 16, NW = 4;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_INSTR = BP * BM * 4 / 1024, B_INSTR = BP * BN * 4 / 1024;
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;
+    constexpr int RA = 256 / BM, RB = 256 / BN;             // tile rows per wave instruction
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BP * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int KT = a.KH * a.KW;
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = (a.Cin + BN - 1) / BN;
+    const int tilesPerSplit = tilesO * tilesC * KT;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO;
+    id /= tilesO;
+    const int tc = id % tilesC;
+    const int tap = id / tilesC;
+    const int o0 = to * BM, c0 = tc * BN;
+    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
+
+    const int p_begin = split * a.chunks_per_split * BP;
+    int p_end = p_begin + a.chunks_per_split * BP;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    int brow[PER_WAVE];                                     // gather rows of the NEXT stage (x-tile instructions)
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int m = p_begin + bi * RB + (lane * 4) / BN;
+            brow[k] = m < p_end ? tab_tap[m] : -1;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int m = p0 + ins * RA + (lane * 4) / BM;
+                const int o = o0 + (lane * 4) % BM;
+                const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
+            } else if (ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int c = c0 + (lane * 4) % BN;
+                const float* src = (brow[k] >= 0 && c < a.Cin) ? a.x + (size_t)brow[k] * a.Cin + c
+                                                               : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+                const int m = p0 + BP + bi * RB + (lane * 4) / BN;
+                brow[k] = m < p_end ? tab_tap[m] : -1;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
+
+    if (nIt > 0) issue_stage(0, 0);
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int kk = 0; kk < BP / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (want_bias) {
+            constexpr int G = 256 / BM, RPT = BP / G;       // row groups, rows per thread
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) bsum += As[buf][((tid / BM) * RPT + j) * BM + (tid % BM)];
+        }
+        __syncthreads();
+    }
+    if (want_bias) {
+        constexpr int G = 256 / BM;
+        __syncthreads();
+        As[0][tid] = bsum;
+        __syncthreads();
+        if (tid < BM && o0 + tid < a.Cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) t += As[0][g * BM + tid];
+            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
+        }
+    }
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + (wn * TN + j) * 32 + li;
+            if (c >= a.Cin) continue;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int o = o0 + (wm * TM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (o >= a.Cout) continue;
+                out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -946,7 +1080,8 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
-    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+    if (getenv("RADET_WGRAD_REGSTAGE")) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
 }
 
 static int wgrad9_bm(int Cout) { return (Cout >= 256 && !getenv("RADET_WGRAD9_BM128")) ? 256 : 128; }

@@ -16,6 +16,7 @@
 // double-buffered: one barrier per K step, next step's loads in flight under 8*TM*TN MFMAs.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct ConvPtrs {
     const float* x;       // input rows [*, Cin]
@@ -41,6 +42,11 @@ struct ConvArgs {
     // empty last round on the 256 CUs) are cut sk_tail ways along K, their partial tiles reduced by a second pass
     int n_full, sk_tail, it_per_tail;
 };
+
+__device__ __attribute__((aligned(16))) float radet_zero_page[512];
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
     int l = 0;
@@ -87,6 +93,60 @@ __device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr,
     }
     if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) return -1;
     return p.base + iy * p.Wi + ix;
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P,
+                                            f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, bool tail,
+                                            int tail_slot, int wm, int wn, int li, int lh) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (tail) {       // raw partial tile, tile-local [BM][BN] layout; tail_epilogue_kernel finishes it
+        float* part = a.partial + (size_t)tail_slot * BM * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    part[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + (wn * TN + j) * 32 + li] = acc[i][j][r];
+        return;
+    }
+    if (a.sk > 1) {   // split-K: raw partial sums, epilogue runs in splitk_epilogue_kernel
+        float* part = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + (wn * TN + j) * 32 + li;
+                if (col >= a.Cout) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < a.M) part[(size_t)row * a.Cout + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            if (col >= a.Cout) continue;
+            const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= a.M) continue;
+                const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
+                float v = acc[i][j][r] + bv;
+                if (P.addend) v += P.addend[o];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
+                P.y[o] = v;
+            }
+        }
 }
 
 // TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
@@ -216,53 +276,184 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (tail) {       // raw partial tile, tile-local [BM][BN] layout; tail_epilogue_kernel finishes it
-        float* part = a.partial + (size_t)tail_slot * BM * BN;
+    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, tail, tail_slot, wm, wn, li, lh);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS-DMA variant of conv_igemm_kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
+// global_load_lds_dwordx4, no staging registers and no ds_write pass.  A wave load writes 1 KiB lane-linearly, so
+// the LDS rows are unpadded [row][BK]; bank conflicts of the 16-byte fragment reads are avoided by an XOR swizzle
+// of the 16-byte slot inside a row, applied on the SOURCE side: the lane that fills slot q of tile row r fetches
+// k-quad q ^ swz(r), swz(r) = (r / (64 / BK)) % (BK / 4); the reader of k-quad kq looks in slot kq ^ swz(r).
+// Stage order per K step: issue the next stage's loads into the other buffer, then fragment reads (software
+// pipelined one 8-wide k slice ahead) + MFMAs on the current buffer, then vmcnt(0) + barrier.
+template <int BM, int BN, int WM, int WN, int TAG, int BK>
+__global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
+    constexpr int F4 = BK / 4;            // 16-byte slots per tile row
+    constexpr int RPI = 64 / F4;          // tile rows per wave load
+    constexpr int RPB = 64 / BK;          // tile rows per 256 bytes of LDS
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
+    constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
+    constexpr int NS = BK / 8;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesN = (a.Cout + BN - 1) / BN;
+    const bool tail = (int)blockIdx.x >= a.n_full;
+    const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;
+    int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
+    const int tilesG = ((a.M + BM - 1) / BM) * tilesN;
+    const int grp = id >= tilesG ? 1 : 0;
+    id -= grp * tilesG;
+    const ConvPtrs P = a.p[grp];
+    const int m0 = (id / tilesN) * BM;
+    const int n0 = (id % tilesN) * BN;
+
+    const int KT = a.KH * a.KW;
+    const int cpt = a.Cin / BK;
+    const int per = tail ? a.it_per_tail : a.it_per_split;
+    const int it0 = (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
+    int nK = KT * cpt - it0;
+    if (nK > per) nK = per;
+
+    // writer side: this lane fills slot (lane % F4) of tile row ins * RPI + lane / F4 of every load it issues
+    const int lrow = lane / F4;
+    int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
+    int arow[A_PW], akq[A_PW];
+    const float* wp[B_PW];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    part[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + (wn * TN + j) * 32 + li] = acc[i][j][r];
-        return;
+    for (int k = 0; k < A_PW; ++k) {
+        const int r = (wave + 4 * k) * RPI + lrow;
+        akq[k] = 4 * ((lane % F4) ^ ((r / RPB) % F4));
+        arow[k] = (nK > 0 && wave + 4 * k < A_INSTR) ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : -1;
     }
-    if (a.sk > 1) {   // split-K: raw partial sums, epilogue runs in splitk_epilogue_kernel
-        float* part = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int k = 0; k < B_PW; ++k) {
+        const int r = (wave + 4 * k) * RPI + lrow;
+        const int n = n0 + r;
+        wp[k] = (wave + 4 * k < B_INSTR && n < a.Cout)
+                    ? P.w + (size_t)n * a.KTw * a.Cin + 4 * ((lane % F4) ^ ((r / RPB) % F4)) : nullptr;
+    }
+    constexpr bool A_FULL = A_INSTR % 4 == 0, B_FULL = B_INSTR % 4 == 0;   // every wave owns A_PW / B_PW loads
+    int wtap = nK > 0 ? a.tap_ids[ld_tap] : 0;
+    auto issue_stage = [&](int buf) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + li;
-                if (col >= a.Cout) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < a.M) part[(size_t)row * a.Cout + col] = acc[i][j][r];
-                }
+        for (int k = 0; k < A_PW; ++k) {
+            const int ins = wave + 4 * k;
+            if (A_FULL || ins < A_INSTR) {
+                const float* src = arow[k] >= 0 ? P.x + (size_t)arow[k] * a.Cin + ld_c0 + akq[k] : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
             }
-        return;
-    }
+        }
+        const int woff = wtap * a.Cin + ld_c0;
+#pragma unroll
+        for (int k = 0; k < B_PW; ++k) {
+            const int ins = wave + 4 * k;
+            if (B_FULL || ins < B_INSTR) {
+                const float* src = wp[k] ? wp[k] + woff : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][ins * 256]), 16, 0, 0);
+            }
+        }
+        ld_c0 += BK;
+        if (ld_c0 == a.Cin) {
+            ld_c0 = 0;
+            ++ld_tap;
+            if (ld_tap < KT) {
+                wtap = a.tap_ids[ld_tap];
+#pragma unroll
+                for (int k = 0; k < A_PW; ++k)
+                    if (A_FULL || wave + 4 * k < A_INSTR)
+                        arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + 4 * k) * RPI + lrow];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + li;
-            if (col >= a.Cout) continue;
-            const float bv = P.bias ? P.bias[col] : 0.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= a.M) continue;
-                const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
-                float v = acc[i][j][r] + bv;
-                if (P.addend) v += P.addend[o];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
-                P.y[o] = v;
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nK > 0) issue_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // reader side: tile rows wm*TM*32 + i*32 + li; (i*32) % (RPB*F4) == 0 so swz only depends on li.
+    // The fragment reads are inline asm: the compiler would otherwise order every ds_read behind a vmcnt(0) wait on
+    // the in-flight LDS-DMA loads (it cannot prove they target the other buffer) and serialise load and compute.
+    const int rswz = (li / RPB) % F4;
+    unsigned aaddr[NS], baddr[NS];
+    {
+        const unsigned a_lds = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((wm * TM * 32 + li) * BK * 4);
+        const unsigned b_lds = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((wn * TN * 32 + li) * BK * 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            aaddr[s] = a_lds + 16u * (unsigned)((2 * s + lh) ^ rswz);
+            baddr[s] = b_lds + 16u * (unsigned)((2 * s + lh) ^ rswz);
         }
+    }
+    auto stage = [&](auto bufc, int it) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr int AO = BUF * BM * BK * 4, BO = BUF * BN * BK * 4, RO = 32 * BK * 4;
+        if (it + 1 < nK) issue_stage(BUF ^ 1);
+        f32x4 af[2][TM], bf[2][TN];
+        auto read_s = [&](int s, int pp) {
+            lds_read128<AO>(af[pp][0], aaddr[s]);
+            if constexpr (TM > 1) lds_read128<AO + RO>(af[pp][TM - 1], aaddr[s]);
+            lds_read128<BO>(bf[pp][0], baddr[s]);
+            if constexpr (TN > 1) lds_read128<BO + RO>(bf[pp][TN - 1], baddr[s]);
+        };
+        read_s(0, 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int pp = s & 1;
+            if (s + 1 < NS) {
+                read_s(s + 1, pp ^ 1);
+                lds_wait<TM + TN>();
+            } else {
+                lds_wait<0>();
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[pp][i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[pp][j]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].x, bf[pp][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].y, bf[pp][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].z, bf[pp][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].w, bf[pp][j].w, acc[i][j], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);                // keep the MFMAs of slice s ahead of the next waits
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA loads have landed
+        __syncthreads();
+    };
+    for (int it = 0; it < nK; it += 2) {
+        stage(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nK) stage(std::integral_constant<int, 1>{}, it + 1);
+    }
+    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, tail, tail_slot, wm, wn, li, lh);
 }
 
 // split-K second pass: y = epilogue(sum_z partial[z])   (fixed summation order -> deterministic)
@@ -624,10 +815,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9_kernel(const WgradArgs a)
 // (global_load_lds_dwordx4: each wave instruction lands 1 KiB lane-linearly, which is exactly one 256-channel dy
 // row or eight 32-channel x rows of the unpadded tiles).  No staging VGPRs (the register-staged version spills its
 // prefetch registers next to 144 accumulators), no ds_write pass; padding / out-of-range rows are read from a zero page.
-__device__ __attribute__((aligned(16))) float radet_zero_page[512];
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a) {
@@ -929,13 +1117,16 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
-    if (bk == 32) {
-        if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+    static const bool regstage = getenv("RADET_IGEMM_REGSTAGE") != nullptr;
+#define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
+    if (regstage) {
+        if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
+        else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 16); }
     } else {
-        if (tag) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, 16>), dim3(tiles, a.sk), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0, 16>), dim3(tiles, a.sk), dim3(256), 0, st, a);
+        if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); }
+        else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 16); }
     }
+#undef RADET_LAUNCH_IGEMM
     if (a.sk > 1) {
         const size_t total = (size_t)a.M * a.Cout;
         int blocks = (int)((total + 255) / 256);

@@ -193,6 +193,9 @@ def main():
             # pair mode: most tower launches are grouped (cls + reg layer in one launch = 2x the flops)
             flops = rt.engine.tower_gemm_flops()
             pair = rt.engine.tower_mode == "pair"
+            hybrid = rt.engine.tower_mode == "hybrid"
+            if hybrid:
+                flops = flops * 2.0     # every tagged launch = cls_convs[i] + reg_convs[i] grouped, forward only
             if pair:
                 n_per_step = len(ms_list) // args.steps
                 # per step: 4 fwd pairs + 3 dgrad pairs (2 GEMMs each) + 2 single dgrads into dL/dP
@@ -200,9 +203,10 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "conv_igemm_kernel<64,64,2,2,TAG=1,BK=32>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304), "
-                                         "fwd+dgrad launches" + ("; cls+reg layers grouped per launch, flop_per_launch = average" if pair
-                                                                 else "; cls and reg towers run concurrently on two streams"),
+                               "kernel": "conv_igemmg_kernel<64,64,2,2,TAG=1,BK=32>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
+                                         + ("; forward launches, cls_convs[i] + reg_convs[i] grouped per launch (2 GEMMs), alone on the device"
+                                            if hybrid else "; fwd+dgrad launches, cls+reg layers grouped per launch, flop_per_launch = average"
+                                            if pair else "; fwd+dgrad launches, cls and reg towers run concurrently on two streams"),
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}
         if world == 1 and not args.no_cpu_baseline:

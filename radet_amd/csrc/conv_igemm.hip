@@ -284,6 +284,17 @@ template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read32(float& d, unsigned addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -888,25 +899,48 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
     const bool want_bias = a.dbias_partials != nullptr && tc == 0;
 
     if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int it = 0; it < nIt; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
-#pragma unroll
-        for (int kk = 0; kk < BP / 2; ++kk) {
-            const float af = As[buf][(2 * kk + lh) * BM + wave * 32 + li];
-            float bf[KT];
-#pragma unroll
-            for (int t = 0; t < KT; ++t) bf[t] = Bs[buf][(t * BP + 2 * kk + lh) * BC + li];
-#pragma unroll
-            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[t], acc[t], 0, 0, 0);
-        }
-        if (want_bias) {
+    // fragment reads are inline asm (see conv_igemmg_kernel): the compiler would put a vmcnt(0) wait on the in-flight
+    // LDS-DMA loads of the other buffer in front of every ds_read it can see
+    const unsigned a_addr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((lh * BM + wave * 32 + li) * 4);
+    const unsigned b_addr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((lh * BC + li) * 4);
+    auto stage = [&](auto bufc, int it) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr int AO = BUF * BP * BM * 4, BO = BUF * KT * BP * BC * 4;
+        if (want_bias) {                                     // plain LDS reads: keep them ahead of the next loads
             constexpr int RPT = BP * BM / NT;                // rows per thread: 8
 #pragma unroll
-            for (int j = 0; j < RPT; ++j) bsum += As[buf][((tid / BM) * RPT + j) * BM + (tid % BM)];
+            for (int j = 0; j < RPT; ++j) bsum += As[BUF][((tid / BM) * RPT + j) * BM + (tid % BM)];
         }
+        if (it + 1 < nIt) issue_stage(it + 1, BUF ^ 1);
+        float af[2], bf[2][KT];
+        lds_read32<AO>(af[0], a_addr);
+        static_for<0, KT>([&](auto t) { lds_read32<BO + decltype(t)::value * BP * BC * 4>(bf[0][decltype(t)::value], b_addr); });
+        static_for<0, BP / 2>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value, pp = kk & 1;
+            if constexpr (kk + 1 < BP / 2) {
+                lds_read32<AO + 2 * (kk + 1) * BM * 4>(af[pp ^ 1], a_addr);
+                static_for<0, KT>([&](auto t) {
+                    lds_read32<BO + (decltype(t)::value * BP + 2 * (kk + 1)) * BC * 4>(bf[pp ^ 1][decltype(t)::value], b_addr);
+                });
+                lds_wait<KT + 1>();
+            } else {
+                lds_wait<0>();
+            }
+            asm volatile("" : "+v"(af[pp]));
+#pragma unroll
+            for (int t = 0; t < KT; ++t) asm volatile("" : "+v"(bf[pp][t]));
+#pragma unroll
+            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp], bf[pp][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+    for (int it = 0; it < nIt; it += 2) {
+        stage(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nIt) stage(std::integral_constant<int, 1>{}, it + 1);
     }
 
     if (want_bias) {

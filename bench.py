@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = the headline metric (BASELINE configs[1]); bf16 = configs[2] arithmetic: conv operands "
+                         "rounded to bf16 into the matrix cores, fp32 accumulate / storage / optimizer (secondary line)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +134,7 @@ def main():
     cfg.model["pretrained"] = None
     torch.manual_seed(0)                      # identical replicas on every rank
     det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device).train()
-    rt = det.runtime()
+    rt = det.runtime(math=args.math)
     o = cfg.optimizer
     rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
                       max_norm=float(cfg.optimizer_config.grad_clip.max_norm))
@@ -175,14 +178,17 @@ def main():
             "metric": "images/sec train-step, r50_ycbv_pbr 640x480 bs=4/GPU",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.math == "fp32" else "bf16 operands, f32 accumulate (f32 tensors in HBM)", "data": "synthetic",
             "config": {"workload": "r50_ycbv_pbr bs=4 fp32 forward+loss+backward+allreduce+clip+AdamW (BASELINE configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "image": f"{IMG_W}x{IMG_H}",
                        "parallelism": f"dp{world}", "losses": [float(x) for x in losses],
                        "step_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
                        "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
-        if events:
+        if args.math != "fp32":
+            out["metric"] += " [bf16 math mode: NOT the headline fp32 metric]"
+            out["config"]["workload"] = out["config"]["workload"].replace("fp32", "bf16-math").replace("configs[1]", "configs[2] arithmetic")
+        if events and args.math == "fp32":
             traffic = None          # HBM bytes/launch of the roofline kernel from the committed PMC pass (offline)
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             if os.path.exists(tpath):

@@ -56,7 +56,9 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
 /* Implicit-GEMM conv on MFMA: y[m,n] = sum_{tap,c} x[table[tap][m], c] * w[n][tap][c].  Forward: w = wf.
  * dgrad: x = dy, w = wft (Cin/Cout swapped, dgrad table).
  * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0.
- * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling); bits 12-15 force
+ * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling); +0x200 = K step 32;
+ * +0x400 = bf16 math mode (operands rounded RNE to bf16 between LDS and the matrix core, fp32 accumulate, fp32
+ * tensors in HBM -- the arithmetic of mmcv's fp16 wrapper, `apis/train.py:113-117`, in bf16); bits 12-15 force
  * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats; when given, launches with too
  * few tiles for 256 CUs split the K loop (<= 8 ways) into partial slabs reduced by a second, deterministic pass. */
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
@@ -76,10 +78,11 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
                             int M, int Cin, int Cout, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
                             void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
- * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits. */
+ * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
+ * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm). */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
-                       int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, void* stream);
+                       int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);
 int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream);
 int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, void* stream);
 /* stem: 7x7/2 conv (3->64) + folded BN + ReLU, NCHW image in, NHWC out (resnet.py:558-570,627-629) */

@@ -94,9 +94,67 @@ def is_trainable(name, frozen_stages=1):
 
 
 # ----------------------------------------------------------------------------- forward
+# Mixed-precision arithmetic of BASELINE config 3 (the reference's fp16 wrapper, apis/train.py:113-117, in bf16 and
+# without loss scaling): every matrix-core convolution rounds BOTH operands to bf16 (RNE) and accumulates in fp32,
+# in forward, dgrad and wgrad; eval-mode BN is folded into the weight BEFORE the rounding (as the HIP engine does);
+# the 7x7 stem (frozen, VALU kernel), GroupNorm, the loss and the optimizer stay fp32.
+MATH = "fp32"
+
+
+class conv_math:
+    def __init__(self, mode):
+        assert mode in ("fp32", "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        global MATH
+        self.prev, MATH = MATH, self.mode
+
+    def __exit__(self, *a):
+        global MATH
+        MATH = self.prev
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+class _ConvBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, padding)
+        return F.conv2d(_r(x), _r(w), None, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.sp
+        gyr = _r(gy)
+        gx = torch.nn.grad.conv2d_input(x.shape, _r(w), gyr, stride=stride, padding=padding) if ctx.needs_input_grad[0] else None
+        gw = torch.nn.grad.conv2d_weight(_r(x), w.shape, gyr, stride=stride, padding=padding) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+def _conv(x, w, b=None, stride=1, padding=0):
+    if MATH == "fp32":
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+    y = _ConvBF16.apply(x, w, stride, padding)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
 def _bn(x, sd, p):
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
                         sd[p + ".bias"], training=False, eps=1e-5)
+
+
+def _conv_bn(x, sd, wname, p, stride=1, padding=0):
+    """conv (no bias) followed by eval-mode BN `p`"""
+    if MATH == "fp32":
+        return _bn(F.conv2d(x, sd[wname], stride=stride, padding=padding), sd, p)
+    s = sd[p + ".weight"] * torch.rsqrt(sd[p + ".running_var"] + 1e-5)
+    shift = sd[p + ".bias"] - sd[p + ".running_mean"] * s
+    return _conv(x, sd[wname] * s.view(-1, 1, 1, 1), None, stride, padding) + shift.view(1, -1, 1, 1)
 
 
 def backbone(sd, img, depth=50):
@@ -109,26 +167,26 @@ def backbone(sd, img, depth=50):
             p = f"backbone.layer{li + 1}.{b}"
             stride = 2 if (b == 0 and li > 0) else 1
             idt = x
-            o = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1"))
-            o = F.relu(_bn(F.conv2d(o, sd[p + ".conv2.weight"], stride=stride, padding=1), sd, p + ".bn2"))
-            o = _bn(F.conv2d(o, sd[p + ".conv3.weight"]), sd, p + ".bn3")
+            o = F.relu(_conv_bn(x, sd, p + ".conv1.weight", p + ".bn1"))
+            o = F.relu(_conv_bn(o, sd, p + ".conv2.weight", p + ".bn2", stride=stride, padding=1))
+            o = _conv_bn(o, sd, p + ".conv3.weight", p + ".bn3")
             if b == 0:
-                idt = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1")
+                idt = _conv_bn(x, sd, p + ".downsample.0.weight", p + ".downsample.1", stride=stride)
             x = F.relu(o + idt)
         outs.append(x)
     return outs  # C2..C5
 
 
 def neck(sd, feats):
-    lat = [F.conv2d(feats[i + 1], sd[f"neck.lateral_convs.{i}.conv.weight"], sd[f"neck.lateral_convs.{i}.conv.bias"])
+    lat = [_conv(feats[i + 1], sd[f"neck.lateral_convs.{i}.conv.weight"], sd[f"neck.lateral_convs.{i}.conv.bias"])
            for i in range(3)]
     for i in (2, 1):
         lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
-    outs = [F.conv2d(lat[i], sd[f"neck.fpn_convs.{i}.conv.weight"], sd[f"neck.fpn_convs.{i}.conv.bias"], padding=1)
+    outs = [_conv(lat[i], sd[f"neck.fpn_convs.{i}.conv.weight"], sd[f"neck.fpn_convs.{i}.conv.bias"], padding=1)
             for i in range(3)]
     for i in (3, 4):
-        outs.append(F.conv2d(outs[-1], sd[f"neck.fpn_convs.{i}.conv.weight"], sd[f"neck.fpn_convs.{i}.conv.bias"],
-                             stride=2, padding=1))
+        outs.append(_conv(outs[-1], sd[f"neck.fpn_convs.{i}.conv.weight"], sd[f"neck.fpn_convs.{i}.conv.bias"],
+                          stride=2, padding=1))
     return outs  # P3..P7
 
 
@@ -137,14 +195,14 @@ def head(sd, feats):
     for l, x in enumerate(feats):
         c, r = x, x
         for i in range(4):
-            c = F.relu(F.group_norm(F.conv2d(c, sd[f"bbox_head.cls_convs.{i}.conv.weight"], padding=1), 32,
+            c = F.relu(F.group_norm(_conv(c, sd[f"bbox_head.cls_convs.{i}.conv.weight"], padding=1), 32,
                                     sd[f"bbox_head.cls_convs.{i}.gn.weight"], sd[f"bbox_head.cls_convs.{i}.gn.bias"], 1e-5))
-            r = F.relu(F.group_norm(F.conv2d(r, sd[f"bbox_head.reg_convs.{i}.conv.weight"], padding=1), 32,
+            r = F.relu(F.group_norm(_conv(r, sd[f"bbox_head.reg_convs.{i}.conv.weight"], padding=1), 32,
                                     sd[f"bbox_head.reg_convs.{i}.gn.weight"], sd[f"bbox_head.reg_convs.{i}.gn.bias"], 1e-5))
-        cls_scores.append(F.conv2d(c, sd["bbox_head.atss_cls.weight"], sd["bbox_head.atss_cls.bias"], padding=1))
-        reg = F.conv2d(r, sd["bbox_head.atss_reg.weight"], sd["bbox_head.atss_reg.bias"], padding=1)
+        cls_scores.append(_conv(c, sd["bbox_head.atss_cls.weight"], sd["bbox_head.atss_cls.bias"], padding=1))
+        reg = _conv(r, sd["bbox_head.atss_reg.weight"], sd["bbox_head.atss_reg.bias"], padding=1)
         bbox_preds.append(F.relu(reg * sd[f"bbox_head.scales.{l}.scale"]))
-        iou_preds.append(F.conv2d(r, sd["bbox_head.atss_centerness.weight"], sd["bbox_head.atss_centerness.bias"], padding=1))
+        iou_preds.append(_conv(r, sd["bbox_head.atss_centerness.weight"], sd["bbox_head.atss_centerness.bias"], padding=1))
     return cls_scores, bbox_preds, iou_preds
 
 
@@ -341,9 +399,9 @@ def get_bboxes(cls_scores, bbox_preds, iou_preds, img_metas, test_cfg, rescale=T
 class OracleDetector:
     """State-dict-driven detector. `sd` tensors that are trainable get requires_grad=True."""
 
-    def __init__(self, depth=50, seed=None, test_cfg=None):
+    def __init__(self, depth=50, seed=None, test_cfg=None, math="fp32"):
         from . import synth
-        self.depth = depth
+        self.depth, self.math = depth, math
         self.sd = make_state_dict(depth)
         if seed is not None:
             synth.fill_state_dict(self.sd, seed)
@@ -358,12 +416,13 @@ class OracleDetector:
         return neck(self.sd, backbone(self.sd, img, self.depth))
 
     def forward_train(self, img, gt_bboxes, gt_labels, p2g, pw):
-        outs = head(self.sd, self.extract_feat(img))
+        with conv_math(self.math):
+            outs = head(self.sd, self.extract_feat(img))
         losses, _ = head_loss(*outs, gt_bboxes, gt_labels, p2g, pw)
         return losses
 
     def simple_test(self, img, img_metas, rescale=True):
-        with torch.no_grad():
+        with torch.no_grad(), conv_math(self.math):
             outs = head(self.sd, self.extract_feat(img))
         return get_bboxes(*outs, img_metas, self.test_cfg, rescale)
 

@@ -63,10 +63,19 @@ def load_checkpoint(model, path, strict=False, runtime=None):
     return ckpt.get("meta", {}), missing
 
 
+def wrap_fp16_model(model):
+    """Mixed-precision switch with mmcv's name: marks the detector so that its HIP runtime is built in bf16 math
+    mode (conv operands rounded to bf16 into the matrix cores; fp32 accumulate, GroupNorm, loss and optimizer)."""
+    model.fp16_enabled = True
+    return model
+
+
 def train_detector(model, batches, cfg, max_iters=None, log=print, checkpoint_path=None):
     """`batches`: iterable of dict(img=f32[B,3,H,W], gt_bboxes, gt_labels, points_to_gt_index, points_weight)
     (device or host tensors; lists per image).  One process per GPU; gradients are averaged over the
     `torch.distributed` group if one is initialised.  Returns the list of logged loss triples."""
+    if cfg.get("fp16", None) is not None:        # reference: Fp16OptimizerHook + wrap_fp16_model (apis/train.py:113-117)
+        wrap_fp16_model(model)                   # here: bf16 operands, fp32 accumulate / master weights, no loss scaling
     rt = model.train().runtime()
     o = cfg.optimizer
     clip = cfg.get("optimizer_config", {}).get("grad_clip") or {}

@@ -284,6 +284,22 @@ template <int OFF>
 __device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+// bf16 math mode: operands are rounded (RNE) to bf16 on the way from LDS to the matrix core, accumulation stays
+// fp32 (v_mfma_f32_32x32x8_bf16_1k: lane (i, h) holds k = 4h..4h+3 -- the same 4 consecutive k a ds_read_b128 of an
+// fp32 tile row delivers, so the fp32 LDS layouts are used unchanged); activations / weights stay fp32 in HBM
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {    // one v_cvt_pk_bf16_f32 (RNE)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ s16x4 cvt_bf16x4(float a, float b, float c, float d) {
+    const u32x2 r = {cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)};
+    return __builtin_bit_cast(s16x4, r);
+}
+
 template <int OFF>
 __device__ __forceinline__ void lds_read32(float& d, unsigned addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
@@ -316,6 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
     constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
     constexpr int NS = BK / 8;
+    constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
     static_assert(WM * WN == 4, "4 waves");
     __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
@@ -446,15 +463,28 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
             for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[pp][i]));
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[pp][j]));
+            if constexpr (BF16) {
+                s16x4 ab[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) ab[i] = cvt_bf16x4(af[pp][i].x, af[pp][i].y, af[pp][i].z, af[pp][i].w);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].x, bf[pp][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].y, bf[pp][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].z, bf[pp][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].w, bf[pp][j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) bb[j] = cvt_bf16x4(bf[pp][j].x, bf[pp][j].y, bf[pp][j].z, bf[pp][j].w);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ab[i], bb[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].x, bf[pp][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].y, bf[pp][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].z, bf[pp][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i].w, bf[pp][j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);                // keep the MFMAs of slice s ahead of the next waits
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA loads have landed
@@ -520,6 +550,7 @@ struct WgradArgs {
     int S;            // pixel splits
     int chunks_per_split;  // 16-pixel chunks per split
     int dbg;          // experiments only (RADET_DBG_WGRAD): 1 = skip global loads after the first stage
+    int math;         // 0: fp32 MFMA; 1: operands rounded to bf16, fp32 accumulate (LDS-DMA kernels only)
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -828,7 +859,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9_kernel(const WgradArgs a)
 // prefetch registers next to 144 accumulators), no ds_write pass; padding / out-of-range rows are read from a zero page.
 
 
-template <int NW>
+template <int NW, int MATH>   // MATH 1: bf16 operands (rounded from the fp32 tiles), fp32 accumulate
 __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a) {
     constexpr int BP = 16, BM = 32 * NW, BC = 32, KT = 9, NT = NW * 64;
     constexpr int A_INSTR = BP * BM * 4 / 1024;             // wave instructions per dy tile (1 KiB each)
@@ -905,6 +936,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
     // LDS-DMA loads of the other buffer in front of every ds_read it can see
     const unsigned a_addr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((lh * BM + wave * 32 + li) * 4);
     const unsigned b_addr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((lh * BC + li) * 4);
+    const unsigned a_addr4 = a_addr + (unsigned)(3 * lh * BM * 4), b_addr4 = b_addr + (unsigned)(3 * lh * BC * 4);  // row 4*lh
     auto stage = [&](auto bufc, int it) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int AO = BUF * BP * BM * 4, BO = BUF * KT * BP * BC * 4;
@@ -914,6 +946,36 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
             for (int j = 0; j < RPT; ++j) bsum += As[BUF][((tid / BM) * RPT + j) * BM + (tid % BM)];
         }
         if (it + 1 < nIt) issue_stage(it + 1, BUF ^ 1);
+        if constexpr (MATH == 1) {
+            // v_mfma_f32_32x32x8_bf16_1k: lane (i, h) holds pixels 4h..4h+3 of an 8-pixel group for its channel
+            static_for<0, BP / 8>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                float a4[4], b4[KT][4];
+                static_for<0, 4>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    lds_read32<AO + (8 * g + r) * BM * 4>(a4[r], a_addr4);
+                    static_for<0, KT>([&](auto t) {
+                        lds_read32<BO + (decltype(t)::value * BP + 8 * g + r) * BC * 4>(b4[decltype(t)::value][r], b_addr4);
+                    });
+                });
+                lds_wait<0>();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(a4[r]));
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(b4[t][r]));
+                const s16x4 ab = cvt_bf16x4(a4[0], a4[1], a4[2], a4[3]);
+#pragma unroll
+                for (int t = 0; t < KT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ab, cvt_bf16x4(b4[t][0], b4[t][1], b4[t][2], b4[t][3]),
+                                                                      acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return;
+        }
         float af[2], bf[2][KT];
         lds_read32<AO>(af[0], a_addr);
         static_for<0, KT>([&](auto t) { lds_read32<BO + decltype(t)::value * BP * BC * 4>(bf[0][decltype(t)::value], b_addr); });
@@ -969,7 +1031,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
 // ------------------------------------------------------------------------------------------ wgrad, one tap, LDS-DMA
 // conv_wgrad_kernel with the dy / x tiles brought in by global_load_lds (see conv_wgrad9g_kernel): the unpadded
 // [pixel][channel] tiles are lane-linear images of 1-KiB wave loads, so no staging registers and no ds_write pass.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MATH>
 __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
     constexpr int BP = 16, NW = 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -1052,18 +1114,40 @@ __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        if constexpr (MATH == 1) {
 #pragma unroll
-        for (int kk = 0; kk < BP / 2; ++kk) {
-            float af[TM], bf[TN];
+            for (int g = 0; g < BP / 8; ++g) {
+                s16x4 ab[TM], bb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
+                for (int i = 0; i < TM; ++i) {
+                    const float* q = &As[buf][(8 * g + 4 * lh) * BM + (wm * TM + i) * 32 + li];
+                    ab[i] = cvt_bf16x4(q[0], q[BM], q[2 * BM], q[3 * BM]);
+                }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+                for (int j = 0; j < TN; ++j) {
+                    const float* q = &Bs[buf][(8 * g + 4 * lh) * BN + (wn * TN + j) * 32 + li];
+                    bb[j] = cvt_bf16x4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+                }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ab[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BP / 2; ++kk) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
         }
         if (want_bias) {
             constexpr int G = 256 / BM, RPT = BP / G;       // row groups, rows per thread
@@ -1153,12 +1237,25 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
     static const bool regstage = getenv("RADET_IGEMM_REGSTAGE") != nullptr;
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
-    if (regstage) {
+    if (regstage && tag < 2) {
         if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
         else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 16); }
     } else {
-        if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); }
-        else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 16); }
+        if (bk == 32) {
+            switch (tag) {
+                case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); break;
+                case 1: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 32); break;
+                case 2: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 2, 32); break;
+                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 32); break;
+            }
+        } else {
+            switch (tag) {
+                case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 16); break;
+                case 1: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 16); break;
+                case 2: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 2, 16); break;
+                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 16); break;
+            }
+        }
     }
 #undef RADET_LAUNCH_IGEMM
     if (a.sk > 1) {
@@ -1258,7 +1355,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.M = M;
     a.Mp = radet_gather_table_rows(M);
     hipStream_t st = (hipStream_t)stream;
-    const int tag = (tile_override >> 8) & 1;
+    const int tag = ((tile_override >> 8) & 1) | (((tile_override >> 10) & 1) << 1);   // 0x100 symbol tag, 0x400 bf16 math
     int bk = ((tile_override >> 9) & 1) ? 32 : 16;
     if (Cin % 32 != 0) bk = 16;
     int choice = tile_override & 0xFF;
@@ -1305,8 +1402,9 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
-    if (getenv("RADET_WGRAD_REGSTAGE")) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+    if (getenv("RADET_WGRAD_REGSTAGE") && a.math == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+    else if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
 }
 
 static int wgrad9_bm(int Cout) { return (Cout >= 256 && !getenv("RADET_WGRAD9_BM128")) ? 256 : 128; }
@@ -1370,7 +1468,7 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
 
 extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials,
                                   const int* gather_table, int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S,
-                                  void* stream) {
+                                  int flags, void* stream) {
     // dy rows must be 16-byte aligned and hold whole float4s for every real channel (pad small heads with zeros)
     if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || (ld_dy & 3) || ((Cout + 3) / 4) * 4 > ld_dy || M <= 0 ||
         gather_table == nullptr)
@@ -1384,14 +1482,16 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     a.Mp = radet_gather_table_rows(M);
     a.S = S;
     { const char* e = getenv("RADET_DBG_WGRAD"); a.dbg = e ? atoi(e) : 0; }
+    a.math = flags & 1;
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
-    if (use_wgrad9(M, Cin, Cout, KH, KW)) {
+    if (use_wgrad9(M, Cin, Cout, KH, KW) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
-            if (getenv("RADET_WGRAD9_REGSTAGE")) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL(conv_wgrad9g_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+            if (getenv("RADET_WGRAD9_REGSTAGE") && a.math == 0) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+            else if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 0>), dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
             hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);

@@ -49,9 +49,14 @@ class Conv:
 
 class Engine:
     def __init__(self, params, grads, depth=50, num_classes=21, frozen_stages=1, strides=(8, 16, 32, 64, 128),
-                 stacked_convs=4, feat=256):
+                 stacked_convs=4, feat=256, math=None):
         """params / grads: dict name -> device tensor (reference state-dict names; grads only for
-        trainable parameters, same shapes)."""
+        trainable parameters, same shapes).  math: "fp32" (default) or "bf16" = conv operands rounded to bf16 on
+        their way into the matrix cores, fp32 accumulate, fp32 tensors / GroupNorm / loss / optimizer (the mixed
+        precision of BASELINE config 3; env RADET_MATH)."""
+        math = math or os.environ.get("RADET_MATH", "fp32")
+        assert math in ("fp32", "bf16"), math
+        self.math = 1 if math == "bf16" else 0
         self.p, self.g = params, grads
         self.depth, self.num_classes, self.frozen_stages = depth, num_classes, frozen_stages
         self.strides, self.stacked_convs, self.feat = tuple(strides), stacked_convs, feat
@@ -66,6 +71,11 @@ class Engine:
     # own kernel symbol for the head-tower GEMM family (see conv_igemm.hip) + its measured-best tile:
     # 64x64 block tile with a 32-deep K step (bench_conv.py: 98.7 vs 88.8 TFLOP/s for the heuristic pick)
     TOWER_TAG = 0x100 | 0x200 | 3
+
+    def _ttile(self, c, bwd=False, tag=True):
+        """tile_override of a tower conv launch: fixed tile in fp32, autotuned in bf16 math; + profiling tag"""
+        t = (self.TOWER_TAG & ~0x100) if not self.math else (c.geom.bwd_tile if bwd else c.geom.fwd_tile)
+        return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 
     def _tower_launch(self, fn, *args, **kw):
@@ -256,9 +266,14 @@ class Engine:
                 c.dbias_partials = self.bp_arena[o_b:o_b + n]
                 o_b += n
         self._build_table()
+        for c in self.convs:
+            if c.geom is not None:
+                c.geom.math = self.math
         if os.environ.get("RADET_AUTOTUNE", "1") != "0":
+            towers = self.cls_tower + self.reg_tower
             for c in self.convs:
-                if c is not self.stem and c.geom is not None and c not in self.cls_tower and c not in self.reg_tower:
+                # the fp32 tower GEMM has a fixed, measured-best tile (TOWER_TAG); in bf16 math it is tuned like the rest
+                if c is not self.stem and c.geom is not None and (self.math or c not in towers):
                     K.autotune(c.geom, need_dgrad=c.need_dgrad)
 
     def _build_table(self):
@@ -392,7 +407,7 @@ class Engine:
         b, p = self.buf, self.p
         c = tower[i]
         z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
-        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=self.TOWER_TAG)
+        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=self._ttile(c))
         gn = f"bbox_head.{t}_convs.{i}.gn"
         K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], ws)
         return y
@@ -408,7 +423,7 @@ class Engine:
         cc, cr = self.cls_tower[i], self.reg_tower[i]
         zc, yc, zr, yr = b[f"cls.z{i}"], b[f"cls.y{i}"], b[f"reg.z{i}"], b[f"reg.y{i}"]
         self._tower_launch(K.conv_fwd_pair, cc.geom, dict(x=xc, w=cc.wf, y=zc), dict(x=xr, w=cr.wf, y=zr),
-                           tile=self.TOWER_TAG)
+                           tile=self._ttile(cc))
         gc, gr = f"bbox_head.cls_convs.{i}.gn", f"bbox_head.reg_convs.{i}.gn"
         side = self._side() if self.use_streams else None
         if side is not None:                        # the two (HBM-bound) GroupNorms overlap each other's tails
@@ -529,11 +544,11 @@ class Engine:
         K.conv_wgrad(c.geom, dz, x, c.slabs, None)
         if self.tower_mode == "hybrid":   # only the (un-overlapped) forward launches carry the profiling tag
             K.conv_dgrad(c.geom, dz, c.wft, dy if i > 0 else dP, addend=None if i > 0 else addend,
-                         tile=self.TOWER_TAG & ~0x100)
+                         tile=self._ttile(c, bwd=True, tag=False))
         elif i > 0:
-            self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dy, tile=self.TOWER_TAG)
+            self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dy, tile=self._ttile(c, bwd=True))
         else:
-            self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dP, addend=addend, tile=self.TOWER_TAG)
+            self._tower_launch(K.conv_dgrad, c.geom, dz, c.wft, dP, addend=addend, tile=self._ttile(c, bwd=True))
 
     def head_backward(self):
         """Consumes buf['dcls'] / buf['dregiou'] (written by loss()); leaves dL/dP in buf['dP']."""
@@ -559,10 +574,10 @@ class Engine:
                 dzc, dzr = b[f"cls.dz{i & 1}"], b[f"reg.dz{i & 1}"]
                 if i > 0:
                     self._tower_launch(K.conv_dgrad_pair, cc.geom, dict(x=dzc, w=cc.wft, y=b["cls.dy"]),
-                                       dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self.TOWER_TAG)
+                                       dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self._ttile(cc, bwd=True))
                 else:   # both write dL/dP: the second accumulates onto the first
-                    self._tower_launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self.TOWER_TAG)
-                    self._tower_launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self.TOWER_TAG)
+                    self._tower_launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self._ttile(cc, bwd=True))
+                    self._tower_launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self._ttile(cr, bwd=True))
         elif self.use_streams:
             side = self._side()
             self._fork(side)

@@ -83,6 +83,7 @@ class ConvGeom:
         self.bwd_desc, _ = _desc(b)
         self._key = (tuple(lin.hw), tuple(lin.offsets), lin.B, k, stride, pad)
         self.fwd_tile = self.bwd_tile = 0     # 0 = launcher heuristic; set by autotune()
+        self.math = 0                         # 1: bf16 math mode (operands rounded to bf16, fp32 accumulate)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
 
     @property
@@ -188,7 +189,7 @@ def autotune(g, need_dgrad=True, reps=3):
             c += [t | 0x200 for t in tiles]
         return c
 
-    key = (g._key, g.cin, g.cout)
+    key = (g._key, g.cin, g.cout, g.math)
     if key not in _TUNE_CACHE:
         x = torch.randn(g.lin.rows, g.cin, device=dev)
         w = torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05
@@ -202,8 +203,15 @@ def autotune(g, need_dgrad=True, reps=3):
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
 
 
+MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
+
+
+def _tile(g, tile, default):
+    return (tile or default) | (MATH_BF16 if g.math else 0)
+
+
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
-    tile = tile or g.fwd_tile
+    tile = _tile(g, tile, g.fwd_tile)
     ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
               g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
@@ -215,7 +223,7 @@ def conv_fwd_pair(g, a, b, relu=False, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.fwd_table), g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu),
-              tile or g.fwd_tile, _ptr(ws), C.c_size_t(ws.numel()), _stream())
+              _tile(g, tile, g.fwd_tile), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
 
 def conv_dgrad_pair(g, a, b, tile=0):
@@ -224,13 +232,13 @@ def conv_dgrad_pair(g, a, b, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.bwd_table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
-              tile or g.bwd_tile, _ptr(ws), C.c_size_t(ws.numel()), _stream())
+              _tile(g, tile, g.bwd_tile), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
     kc = g.cout if k_channels is None else k_channels
-    tile = tile or g.bwd_tile
+    tile = _tile(g, tile, g.bwd_tile)
     ws = splitk_ws() if splitk else None
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         for c in _strided_dgrad_classes(g):
@@ -246,7 +254,7 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
-              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, _stream())
+              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 1 if g.math else 0, _stream())
 
 
 def fold_weights(table_dev, n):

@@ -47,13 +47,19 @@ class RADet(nn.Module):
         # 'torchvision://resnet50' needs network access; weights then come from load_state_dict by the caller
 
     # ------------------------------------------------------------------ runtime
-    def runtime(self):
+    def runtime(self, math=None):
+        """The HIP engine behind this module.  math: "fp32" | "bf16"; default: "bf16" when the model was wrapped for
+        mixed precision (`fp16_enabled`, what mmcv's wrap_fp16_model sets -- apis/train.py:113-117), else RADET_MATH."""
         from ..runtime import DetectorRuntime
+        if math is None and getattr(self, "fp16_enabled", False):
+            math = "bf16"
         rt = self._runtime
+        if rt is not None and math is not None and rt.engine.math != (1 if math == "bf16" else 0):
+            rt = None
         if rt is None or not rt.flat.still_bound():
             rt = DetectorRuntime(self, depth=self.backbone.depth, num_classes=self.bbox_head.num_classes,
                                  frozen_stages=self.backbone.frozen_stages, strides=self.bbox_head.strides,
-                                 stacked_convs=self.bbox_head.stacked_convs)
+                                 stacked_convs=self.bbox_head.stacked_convs, math=math)
             object.__setattr__(self, "_runtime", rt)
             rt.owner = weakref.ref(self)
         return rt

@@ -142,7 +142,7 @@ class GradReducer:
 
 
 class DetectorRuntime:
-    def __init__(self, det, depth, num_classes, frozen_stages, strides, stacked_convs=4):
+    def __init__(self, det, depth, num_classes, frozen_stages, strides, stacked_convs=4, math=None):
         dev = next(det.parameters()).device
         if dev.type != "cuda":
             raise _lib.RadetHipError(
@@ -152,7 +152,7 @@ class DetectorRuntime:
         self.dev = dev
         self.flat = FlatParams(det, dev)
         self.engine = Engine(self.flat.p, self.flat.g, depth=depth, num_classes=num_classes,
-                             frozen_stages=frozen_stages, strides=strides, stacked_convs=stacked_convs)
+                             frozen_stages=frozen_stages, strides=strides, stacked_convs=stacked_convs, math=math)
         self.num_classes, self.strides = num_classes, tuple(strides)
         self.opt_state = None
         self.step_count = 0

@@ -96,3 +96,63 @@ def test_empty_batch_and_batched_nms_branch():
             j = int(d.argmin())
             matched += int(d[j] <= 2e-3 + 1e-4 * np.abs(row).max() and int(dets[j, 5]) == int(lab))
         assert matched >= 0.95 * rb.shape[0], (matched, rb.shape[0])
+
+
+def test_bf16_config3_vs_oracle():
+    """BASELINE config 3 arithmetic (mixed precision): conv operands rounded to bf16 into the matrix cores, fp32
+    accumulate, fp32 GroupNorm / loss.  Oracle = the same rounding on the CPU (oracle.model.conv_math).
+
+    Rounding is discontinuous: an fp32-level difference (1e-6) between two correct implementations flips a bf16
+    rounding now and then, and every flip injects a full bf16 step, so the two sides decorrelate with depth
+    (measured: 2.6e-4 after layer1, 3e-3 = the size of the bf16 perturbation itself after layer3).  The exact check of
+    the arithmetic is therefore at kernel level (tests/test_gpu_kernels.py, bf16math cases: 1e-5 against the
+    convolution of pre-rounded tensors); here we check (a) the first stage agrees far below the bf16 perturbation,
+    (b) losses within 2e-3, (c) every gradient tensor is within the bf16-vs-fp32 perturbation of the oracle's, and
+    closer in aggregate, (d) the mode is really on (results differ from fp32)."""
+    from oracle import model as om, synth
+    from radet_amd.apis import wrap_fp16_model
+    H, W = 224, 224
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2)
+    res, c2 = {}, {}
+    for mode in ("fp32", "bf16"):
+        det = make(50)
+        if mode == "bf16":
+            wrap_fp16_model(det)
+        det.train()
+        losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b,
+                     gt_labels=gt_l, points_to_gt_index=p2g, points_weight=pw)
+        assert det.runtime().engine.math == (1 if mode == "bf16" else 0)
+        sum(losses.values()).backward()
+        res[mode] = ({k: v.item() for k, v in losses.items()},
+                     {n: p.grad.detach().cpu().double() for n, p in det.named_parameters() if p.requires_grad})
+        with torch.no_grad():
+            c2[mode] = det.backbone(img.cuda())[0].cpu().double()
+    ores = {}
+    for mode in ("fp32", "bf16"):
+        odet = om.OracleDetector(50, seed=1, math=mode)
+        ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+        om.parse_losses(ol).backward()
+        with torch.no_grad(), om.conv_math(mode):
+            oc2 = om.backbone(odet.sd, img, 50)[0].double()
+        ores[mode] = ({k: v.item() for k, v in ol.items()}, {n: g.double() for n, g in odet.named_grads().items()}, oc2)
+    rel = lambda a, b: (a - b).norm().item() / max(b.norm().item(), 1e-30)  # noqa: E731
+    # (a) first stage (10 bf16 convs deep)
+    gap_c2 = rel(ores["bf16"][2], ores["fp32"][2])
+    assert gap_c2 > 1e-3 and rel(c2["bf16"], ores["bf16"][2]) < 0.25 * gap_c2, (rel(c2["bf16"], ores["bf16"][2]), gap_c2)
+    # (b) losses
+    lb, gb = res["bf16"]
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(lb[k] - ores["bf16"][0][k]) <= 2e-3 * max(1.0, abs(ores["bf16"][0][k])), (k, lb[k], ores["bf16"][0][k])
+    # (c) gradients
+    ob, of = ores["bf16"][1], ores["fp32"][1]
+    tot = float(np.sqrt(sum(g.norm().item() ** 2 for g in ob.values())))
+    e2 = g2 = 0.0
+    for n, g in gb.items():
+        err, gap = (g - ob[n]).norm().item(), (ob[n] - of[n]).norm().item()
+        assert err <= 1.5 * gap + 1e-3 * tot, (n, err, gap)
+        e2, g2 = e2 + err ** 2, g2 + gap ** 2
+    assert e2 < 0.75 ** 2 * g2, (e2 ** 0.5, g2 ** 0.5)
+    # (d) the mode is really on
+    assert any(abs(lb[k] - res["fp32"][0][k]) > 1e-5 * max(1.0, abs(lb[k])) for k in lb), (lb, res["fp32"][0])
+    print(f"bf16 vs oracle-bf16: C2 {rel(c2['bf16'], ores['bf16'][2]):.2e} (bf16 perturbation {gap_c2:.2e}); "
+          f"gradient error {e2 ** 0.5:.3f} vs perturbation {g2 ** 0.5:.3f}")

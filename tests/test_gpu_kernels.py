@@ -56,26 +56,30 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("math", [0, 1], ids=["fp32", "bf16math"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(K, case):
+def test_conv_fwd_dgrad_wgrad(K, case, math):
+    """math=1: operands rounded (RNE) to bf16 inside the kernel, fp32 accumulate -- the reference is the exact
+    convolution of the pre-rounded tensors, so the tolerance stays at fp32-accumulation level."""
     B, Cin, Cout, H, W, k, s, tile = case
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
     bias = torch.randn(Cout, generator=g)
     pad = k // 2
-    xd = x.double().requires_grad_(True)
-    wd = w.double().requires_grad_(True)
-    y_ref = F.conv2d(xd, wd, bias.double(), stride=s, padding=pad)
+    r = (lambda t: t.bfloat16().double()) if math else (lambda t: t.double())
+    y_ref = F.conv2d(r(x), r(w), bias.double(), stride=s, padding=pad)
     Ho, Wo = y_ref.shape[2:]
     res = torch.randn(B, Cout, Ho, Wo, generator=g)
     out_ref = F.relu(y_ref + res.double())
     dy = torch.randn(B, Cout, Ho, Wo, generator=g)
-    gx, gw = torch.autograd.grad(y_ref, (xd, wd), dy.double())
+    gx = torch.nn.grad.conv2d_input(x.shape, r(w), r(dy), stride=s, padding=pad)
+    gw = torch.nn.grad.conv2d_weight(r(x), w.shape, r(dy), stride=s, padding=pad)
 
     dev = "cuda"
     lv = K.Levels([(H, W)], B)
     geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    geom.math = math
     xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
     y = torch.empty(B * Ho * Wo, Cout, device=dev)
     K.conv_fwd(geom, xr, wf, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)

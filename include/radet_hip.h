@@ -166,6 +166,15 @@ int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t*
                         int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw, int* used,
                         void* ws, void* stream);
 
+/* ---- instance-mask path feeding the assigner: BitmapMasks.rescale / resize / flip / pad
+ *      (core/mask/structures.py:253-303: mmcv.imresize = cv2.INTER_NEAREST, np.flip, np.pad per mask) fused into one
+ *      pass over a [G,Hs,Ws] u8 stack, and LoadAnnotations._load_bop_masks' normalisation (loading.py:419-422).
+ *      dst[g][y][x] = y < Hr && x < Wr ? norm(src[g][nn(flip_y(y))][nn(flip_x(x))]) : pad_val, dst is [G,Hd,Wd];
+ *      flip: 0 none, 1 horizontal, 2 vertical, 3 diagonal; norm_max (from radet_mask_max) or NULL = no normalisation */
+int radet_mask_max(const uint8_t* masks, uint32_t* maxes /* [G] */, int G, size_t hw, void* stream);
+int radet_mask_transform(const uint8_t* src, uint8_t* dst, const uint32_t* norm_max, int G, int Hs, int Ws, int Hr, int Wr,
+                         int Hd, int Wd, int flip, int pad_val, void* stream);
+
 /* ---- anchors (core/anchor/anchor_generator.py:206-271): [sum h*w, 4], centre (j*stride, i*stride), side 8*stride */
 int radet_grid_anchors(float* out, const int* level_desc, int nlvl, int octave_base_scale, void* stream);
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "radet_nms": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "radet_assign_ws_bytes": (_sz, [_i, _i]),
     "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_mask_max": (_i, [_p, _p, _i, _sz, _p]),
+    "radet_mask_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_grid_anchors": (_i, [_p, _p, _i, _i, _p]),
     "radet_sqnorm_partials": (_i, [_p, _sz, _p, _i, _p]),
     "radet_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _i, _p, _p]),

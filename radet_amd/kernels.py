@@ -380,6 +380,26 @@ def assign_ws_bytes(B, N):
     return int(_lib.load().radet_assign_ws_bytes(B, N))
 
 
+FLIP = {None: 0, "none": 0, "horizontal": 1, "vertical": 2, "diagonal": 3}
+
+
+def mask_transform(src, out_hw=None, resized_hw=None, flip=None, pad_val=0, normalize=False):
+    """src: u8[G,Hs,Ws] device tensor -> u8[G,Hd,Wd]: nearest resize to resized_hw, flip, pad to out_hw (one pass)."""
+    G, Hs, Ws = src.shape
+    Hr, Wr = resized_hw or (Hs, Ws)
+    Hd, Wd = out_hw or (Hr, Wr)
+    dst = torch.empty(G, Hd, Wd, dtype=torch.uint8, device=src.device)
+    if G == 0:
+        return dst
+    mx = None
+    if normalize:
+        mx = torch.empty(G, dtype=torch.int32, device=src.device)
+        _lib.call("radet_mask_max", _ptr(src), _ptr(mx), G, C.c_size_t(Hs * Ws), _stream())
+    _lib.call("radet_mask_transform", _ptr(src), _ptr(dst), _ptr(mx), G, Hs, Ws, Hr, Wr, Hd, Wd, FLIP[flip], int(pad_val),
+              _stream())
+    return dst
+
+
 def assign_points(gt_boxes, gt_off, masks, H, W, uniforms, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
                   ws):
     _lib.call("radet_assign_points", _ptr(gt_boxes), _ptr(gt_off), _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges,

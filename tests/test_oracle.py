@@ -232,3 +232,22 @@ def test_full_model_against_reference(golden):
         rorder = np.argsort(-ref[:, 4], kind="stable")
         assert np.array_equal(dl[order], ref[rorder, 5].astype(np.int64))
         assert np.allclose(db[order], ref[rorder, :5], rtol=1e-4, atol=1e-3)
+
+
+def test_mask_oracle_identities():
+    """oracle/masks.py (parity unpinned for the cv2 nearest rule): structural identities that any correct
+    restatement satisfies."""
+    from oracle import masks as om
+    rng = np.random.RandomState(0)
+    m = (rng.rand(3, 37, 53) * 256).astype(np.uint8)
+    assert (om.resize_nearest(m, (37, 53)) == m).all()                       # identity resize
+    up = om.resize_nearest(m, (74, 106))                                     # x2: every pixel replicated 2x2
+    assert (up[:, ::2, ::2] == m).all() and (up[:, 1::2, 1::2] == m).all()
+    for d in ("horizontal", "vertical", "diagonal"):
+        assert (om.flip(om.flip(m, d), d) == m).all()
+    assert (om.flip(m, "diagonal") == om.flip(om.flip(m, "horizontal"), "vertical")).all()
+    p = om.pad(m, (40, 64), 9)
+    assert (p[:, :37, :53] == m).all() and (p[:, 37:] == 9).all() and (p[:, :, 53:] == 9).all()
+    n = om.normalize(np.stack([m[0], np.zeros_like(m[0]), (m[2] > 128).astype(np.uint8) * 255]))
+    assert set(np.unique(n)) <= {0, 1} and n[1].max() == 0 and (n[2] == (m[2] > 128)).all()
+    assert om.rescale_size((640, 480), (1333, 800)) == (1067, 800) and om.rescale_size((640, 480), 0.5) == (320, 240)

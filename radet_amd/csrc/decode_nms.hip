@@ -11,6 +11,7 @@
 //  Modes: 0 vote_nms, 1 global_vote_nms (vote_ext.cpp:70-353), 2 cluster_nms (cluster_ext.cpp:4-87),
 //         3 class-aware hard NMS with mmcv.ops.batched_nms semantics.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/radet_hip.h"
 
 struct DecLevels {
@@ -265,6 +266,11 @@ __device__ __forceinline__ float iou_ref(float x1i, float y1i, float x2i, float 
     return inter / (area_j + area_i - inter);
 }
 
+#define NMS_KREG 4   // label segments of up to 64 * NMS_KREG boxes are clustered out of registers
+
+#define NMS_SMEM_BASE ((size_t)8192 * 8 + 8192 + 64 * 4 + (8192 + 8) * 4)   // keys | sup | s_misc | seg_start | batch state
+#define NMS_SMEM_TOTAL (NMS_SMEM_BASE + (8 + 64 + 64 + 256) * 4)
+
 struct NmsWs {   // per-image global workspace (cap entries each)
     float* bx;   // [4][cap] sorted coordinates (mode 3: offset coordinates)
     float* vs;   // adjusted vote scores
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
                                                    float* __restrict__ out_scores, int64_t* __restrict__ out_labels,
                                                    int* __restrict__ out_count, int64_t* __restrict__ aux0,
                                                    int64_t* __restrict__ aux1, char* __restrict__ ws_all,
-                                                   size_t ws_per_image) {
+                                                   size_t ws_per_image, int dbg_stop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -336,6 +342,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
     }
     __syncthreads();
     bitonic_sort_u64(keys, m);
+    if (dbg_stop == 1) return;
     for (int i = tid; i < n; i += 1024) {
         const int o = (int)(keys[i] & 0xFFFFull);
         const int lab = (int)lsrc[o];
@@ -368,36 +375,185 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         __syncthreads();
     }
     const int nseg = s_misc[32];
-    // ---- greedy clustering, one wavefront per label segment
-    for (int s = wave; s < nseg; s += 16) {
+    if (dbg_stop == 2) return;
+    // ---- greedy clustering.  Phase A: one wavefront per label segment of up to 64 * NMS_KREG boxes, segments handed
+    //      out dynamically (long ones do not pile up on one wave).  Phase B: longer segments, whole workgroup per head.
+    if (tid == 0) s_misc[34] = 0;
+    __syncthreads();
+    for (;;) {
+        int s = 0;
+        if (lane == 0) s = atomicAdd(&s_misc[34], 1);
+        s = __shfl(s, 0, 64);
+        if (s >= nseg) break;
         const int p0 = seg_start[s], p1 = seg_start[s + 1];
+        const int cnt = p1 - p0;
+        if (cnt > 64 * NMS_KREG) continue;                   // phase B
+        // register-resident segment: lane l holds boxes p0 + k*64 + l (k < NMS_KREG) and their suppressed bits;
+        // the head box is broadcast with readlane -> no memory access inside the greedy loop except the
+        // fire-and-forget head[] stores.  Same IoU arithmetic and visiting order as the reference's loop.
+        float X1[NMS_KREG], Y1[NMS_KREG], X2[NMS_KREG], Y2[NMS_KREG];
+        unsigned supm = 0;
+#pragma unroll
+        for (int k = 0; k < NMS_KREG; ++k) {
+            const int jl = k * 64 + lane;
+            const bool v = jl < cnt;
+            const int j = v ? p0 + jl : p0;
+            X1[k] = ws.bx[j]; Y1[k] = ws.bx[cap + j]; X2[k] = ws.bx[2 * cap + j]; Y2[k] = ws.bx[3 * cap + j];
+            if (!v) supm |= 1u << k;
+        }
+        const int kmax = (cnt + 63) >> 6;
         bool label_done = false;
-        for (int i = p0; i < p1; ++i) {
-            if (sup[i]) continue;
-            if (mode == 1 && label_done) { if (lane == 0) sup[i] = 1; continue; }
-            const float x1 = ws.bx[i], y1 = ws.bx[cap + i], x2 = ws.bx[2 * cap + i], y2 = ws.bx[3 * cap + i];
+        for (int i = 0; i < cnt; ++i) {
+            const int ki = i >> 6, li = i & 63;
+            if ((__shfl(supm, li, 64) >> ki) & 1u) continue;
+            if (mode == 1 && label_done) break;              // the rest of the label is dropped (head stays -1)
+            float sx1 = X1[0], sy1 = Y1[0], sx2 = X2[0], sy2 = Y2[0];
+#pragma unroll
+            for (int q = 1; q < NMS_KREG; ++q)
+                if (ki == q) { sx1 = X1[q]; sy1 = Y1[q]; sx2 = X2[q]; sy2 = Y2[q]; }
+            const float x1 = __shfl(sx1, li, 64), y1 = __shfl(sy1, li, 64);
+            const float x2 = __shfl(sx2, li, 64), y2 = __shfl(sy2, li, 64);
             const float area_i = (x2 - x1) * (y2 - y1);
-            if (lane == 0) { sup[i] = 1; ws.head[i] = i; }
+            if (lane == li) { supm |= 1u << ki; ws.head[p0 + i] = p0 + i; }
             label_done = true;
-            for (int j = i + 1 + lane; j < p1; j += 64) {
-                if (sup[j]) continue;
-                const float iou = iou_ref(x1, y1, x2, y2, area_i, ws.bx[j], ws.bx[cap + j], ws.bx[2 * cap + j],
-                                          ws.bx[3 * cap + j]);
-                if (iou > thr) {
-                    sup[j] = 1;
-                    ws.head[j] = i;
-                    if (iou_enable && mode <= 1) {
-                        const float f = -(1 - iou) * (1 - iou) / sigma;
-                        ws.vs[j] = ws.vs[j] * expf(f);
+#pragma unroll
+            for (int k = 0; k < NMS_KREG; ++k) {
+                if (k < ki || k >= kmax) continue;           // uniform: blocks behind the head / past the segment
+                const int jl = k * 64 + lane;
+                if (jl > i && !((supm >> k) & 1u)) {
+                    const float iou = iou_ref(x1, y1, x2, y2, area_i, X1[k], Y1[k], X2[k], Y2[k]);
+                    if (iou > thr) {
+                        supm |= 1u << k;
+                        ws.head[p0 + jl] = p0 + i;
+                        if (iou_enable && mode <= 1) {
+                            const float f = -(1 - iou) * (1 - iou) / sigma;
+                            ws.vs[p0 + jl] = ws.vs[p0 + jl] * expf(f);
+                        }
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
+    }
+    __syncthreads();
+    // Phase B (segments longer than 64 * NMS_KREG): blocked greedy NMS with the reference's exact sequential result.
+    // Per round: (1) wave 0 collects the next <= 64 unsuppressed positions (ordered), (2) resolves the greedy order
+    // among them in registers (readlane broadcast, one IoU per lane and step) -> the round's true heads, (3) all 16
+    // wavefronts test every later unsuppressed box against those heads IN ORDER and stop at the first IoU > thr, which
+    // is exactly the head the sequential loop would have assigned.  Two barriers per 64 candidates instead of a
+    // serial pass per head.  Coordinates staged in the LDS region the sort keys no longer need (<= 4096 boxes).
+    int* bmisc = reinterpret_cast<int*>(smem + NMS_SMEM_BASE);      // [0]=nc, [1]=nh, [2]=batch_end, [3]=stop
+    int* bcand = bmisc + 8;                                         // [64] candidate positions
+    int* bhead = bcand + 64;                                        // [64] true-head positions
+    float* bhx = reinterpret_cast<float*>(bhead + 64);              // [4][64] true-head coordinates
+    for (int s = 0; s < nseg; ++s) {
+        const int p0 = seg_start[s], p1 = seg_start[s + 1];
+        const int cnt = p1 - p0;
+        if (cnt <= 64 * NMS_KREG) continue;
+        float* lx = reinterpret_cast<float*>(smem);          // [4][4096]
+        const bool in_lds = cnt <= 4096;
+        if (in_lds)
+            for (int t = tid; t < cnt; t += 1024) {
+                lx[t] = ws.bx[p0 + t]; lx[4096 + t] = ws.bx[cap + p0 + t];
+                lx[8192 + t] = ws.bx[2 * cap + p0 + t]; lx[12288 + t] = ws.bx[3 * cap + p0 + t];
+            }
+        __syncthreads();
+        const float* c0 = in_lds ? lx : ws.bx + p0;
+        const int cs = in_lds ? 4096 : cap;
+        int pos = 0;
+        bool first_round = true;
+        while (pos < cnt) {
+            if (wave == 0) {
+                // (1) next <= 64 unsuppressed positions at or after pos
+                int nc = 0, scan = pos, last = pos;
+                while (nc < 64 && scan < cnt) {
+                    const int probe = scan + lane;
+                    const bool al = probe < cnt && !sup[p0 + probe];
+                    const unsigned long long bal = __ballot(al);
+                    const int rank = nc + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (al && rank < 64) bcand[rank] = probe;
+                    const int got = __popcll(bal);
+                    if (nc + got >= 64) {                     // window holds the 64th candidate: the batch ends right after it
+                        int need = 64 - nc;                   // position of the need-th set bit of bal
+                        unsigned long long t = bal;
+                        for (int q = 1; q < need; ++q) t &= t - 1ull;
+                        last = scan + __ffsll((long long)t);
+                        nc = 64;
+                    } else {
+                        nc += got;
+                        scan += 64;
+                        last = scan < cnt ? scan : cnt;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // (2) greedy order among the candidates
+                const bool have = lane < nc;
+                const int cp = have ? bcand[lane] : 0;
+                const float bx1 = c0[cp], by1 = c0[cs + cp], bx2 = c0[2 * cs + cp], by2 = c0[3 * cs + cp];
+                unsigned long long alive = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+                int nh = 0, stop = 0;
+                for (int t = 0; t < nc; ++t) {
+                    if (!((alive >> t) & 1ull)) continue;
+                    if (mode == 1 && !(first_round && nh == 0)) { stop = 1; break; }   // global vote: one head per label
+                    const float x1 = __shfl(bx1, t, 64), y1 = __shfl(by1, t, 64);
+                    const float x2 = __shfl(bx2, t, 64), y2 = __shfl(by2, t, 64);
+                    const float area_i = (x2 - x1) * (y2 - y1);
+                    const int hp = __shfl(cp, t, 64);
+                    bool kill = false;
+                    float iou = 0.f;
+                    if (have && lane > t && ((alive >> lane) & 1ull)) {
+                        iou = iou_ref(x1, y1, x2, y2, area_i, bx1, by1, bx2, by2);
+                        kill = iou > thr;
+                    }
+                    if (kill) {
+                        sup[p0 + cp] = 1;
+                        ws.head[p0 + cp] = p0 + hp;
+                        if (iou_enable && mode <= 1) {
+                            const float f = -(1 - iou) * (1 - iou) / sigma;
+                            ws.vs[p0 + cp] = ws.vs[p0 + cp] * expf(f);
+                        }
+                    }
+                    alive &= ~__ballot(kill);
+                    if (lane == t) {
+                        sup[p0 + cp] = 1;
+                        ws.head[p0 + cp] = p0 + cp;
+                        bhead[nh] = cp;
+                        bhx[nh] = bx1; bhx[64 + nh] = by1; bhx[128 + nh] = bx2; bhx[192 + nh] = by2;
+                    }
+                    ++nh;
+                }
+                if (lane == 0) { bmisc[0] = nc; bmisc[1] = nh; bmisc[2] = last; bmisc[3] = stop; }
+            }
+            __syncthreads();
+            const int nh = bmisc[1], batch_end = bmisc[2], stop = bmisc[3];
+            // (3) every later box against this round's heads, in head order
+            for (int j = batch_end + tid; j < cnt; j += 1024) {
+                if (sup[p0 + j]) continue;
+                const float jx1 = c0[j], jy1 = c0[cs + j], jx2 = c0[2 * cs + j], jy2 = c0[3 * cs + j];
+                for (int q = 0; q < nh; ++q) {
+                    const float x1 = bhx[q], y1 = bhx[64 + q], x2 = bhx[128 + q], y2 = bhx[192 + q];
+                    const float iou = iou_ref(x1, y1, x2, y2, (x2 - x1) * (y2 - y1), jx1, jy1, jx2, jy2);
+                    if (iou > thr) {
+                        sup[p0 + j] = 1;
+                        ws.head[p0 + j] = p0 + bhead[q];
+                        if (iou_enable && mode <= 1) {
+                            const float f = -(1 - iou) * (1 - iou) / sigma;
+                            ws.vs[p0 + j] = ws.vs[p0 + j] * expf(f);
+                        }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            pos = batch_end;
+            first_round = false;
+            if (stop || (mode == 1 && nh > 0)) break;        // global vote: the label's only head has been applied
+        }
+        __syncthreads();
     }
     __threadfence_block();
     __syncthreads();
+    if (dbg_stop == 3) return;
     // ---- order the heads: (score desc, original index asc)
     for (int i = tid; i < m; i += 1024) {
         unsigned long long key = ~0ull;
@@ -423,6 +579,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         __syncthreads();
     }
     const int nheads = s_misc[33];
+    if (dbg_stop == 4) return;
     const int K = (max_out > 0 && nheads > max_out) ? max_out : nheads;
     if (tid == 0) out_count[b] = K;
     for (int r = tid; r < nheads; r += 1024) ws.hpos[r] = (int)(keys[r] & 0xFFFFull);
@@ -505,7 +662,7 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
                          int64_t* out_labels, int* out_count, int64_t* aux0, int64_t* aux1, void* ws, void* stream) {
     if (cap < 1 || cap > 8192 || mode < 0 || mode > 3 || B < 1) return RADET_ERR_ARG;
     if (mode == 3 && max_out <= 0) return RADET_ERR_ARG;
-    const size_t smem = (size_t)8192 * 8 + 8192 + 64 * 4 + (8192 + 8) * 4;
+    const size_t smem = NMS_SMEM_TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -515,6 +672,6 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
     }
     hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), smem, (hipStream_t)stream, boxes, cluster_scores, vote_scores,
                        labels, counts, cap, mode, iou_thr, iou_enable, sigma, max_out, out_boxes, out_scores, out_labels,
-                       out_count, aux0, aux1, (char*)ws, nms_ws_per_image(cap));
+                       out_count, aux0, aux1, (char*)ws, nms_ws_per_image(cap), getenv("RADET_NMS_STOP") ? atoi(getenv("RADET_NMS_STOP")) : 0);
     return radet_check_launch();
 }

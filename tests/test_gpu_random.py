@@ -101,3 +101,37 @@ def test_assigner_random_batches(seed):
         rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), masks[i], (H, W, 3), rng=orngs[i])
         assert np.array_equal(p2g[i], rp) and np.array_equal(pw[i], rw), (seed, i)
         assert rngs[i].random_sample() == orngs[i].random_sample()      # stream position preserved
+
+
+@pytest.mark.parametrize("n,n_labels,crowd", [(700, 1, 4), (1024, 1, 30), (1025, 1, 4), (4096, 1, 30), (4097, 1, 30),
+                                              (8192, 1, 30), (6000, 2, 4), (5000, 3, 1)])
+def test_nms_long_label_segments(n, n_labels, crowd):
+    """Crowded classes: every clustering path of the kernel -- register-resident segments (<= 1024 boxes), the
+    workgroup-cooperative path with LDS-staged coordinates (<= 4096) and through L2 (> 4096) -- bit-exact, all modes."""
+    from oracle import nms as onms
+    from radet_amd import ops
+    rs = np.random.RandomState(n + n_labels)
+    boxes, labels = random_boxes(rs, n, n_labels, crowd)
+    cls = (rs.rand(n) * 0.9 + 0.05).astype(np.float32)
+    ctr = (rs.rand(n) * 0.9 + 0.05).astype(np.float32)
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    for iou_enable in (False, True):
+        cfg = dict(VOTE_CFG, iou_threshold=0.5, iou_enable=iou_enable)
+        for fn, ofn in ((ops.vote_nms, onms.vote_nms), (ops.global_vote_nms, onms.global_vote_nms)):
+            b, l = fn(t(boxes), t(cls), t(labels), cfg, score_factor=t(ctr), max_num=100)
+            ob, ol = ofn(boxes, cls, labels, cfg, score_factor=ctr, max_num=100)
+            assert np.array_equal(l.numpy(), ol), (fn.__name__, iou_enable)
+            if not iou_enable:
+                assert np.array_equal(b.numpy().view(np.uint32), ob.view(np.uint32)), (fn.__name__, iou_enable)
+            else:
+                # iou_enable rescales vote scores by expf(-(1-iou)^2/sigma): the device expf and glibc's differ by
+                # <= 1 ulp, so the voted fp32 boxes agree to rounding (north_star: 1e-4), not bit for bit; a 1-ulp
+                # weight can also flip a member in / out of the 1-sigma vote window (rare)
+                close = np.isclose(b.numpy(), ob, rtol=1e-4, atol=1e-3) | (np.isnan(b.numpy()) & np.isnan(ob))
+                assert close.all(axis=1).mean() >= 0.98, (fn.__name__, close.all(axis=1).mean())
+    ids, num = ops.cluster_nms(boxes, cls * ctr, labels, 0.5)
+    oids, onum = onms.cluster_nms(boxes, cls * ctr, labels, 0.5)
+    assert np.array_equal(ids.numpy(), oids) and np.array_equal(num.numpy(), onum)
+    dets, keep = ops.batched_nms(t(boxes), t(cls * ctr), t(labels), dict(type="nms", iou_threshold=0.5))
+    odets, okeep = onms.batched_nms(boxes, cls * ctr, labels, 0.5)
+    assert np.array_equal(keep.numpy(), okeep) and np.array_equal(dets.numpy(), odets)

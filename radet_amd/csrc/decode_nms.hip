@@ -268,10 +268,7 @@ __device__ __forceinline__ float iou_ref(float x1i, float y1i, float x2i, float 
 
 #define NMS_KREG 4   // label segments of up to 64 * NMS_KREG boxes are clustered out of registers
 
-#define NMS_SMEM_BASE ((size_t)8192 * 8 + 8192 + 64 * 4 + (8192 + 8) * 4)   // keys | sup | s_misc | seg_start | batch state
-#define NMS_SMEM_TOTAL (NMS_SMEM_BASE + (8 + 64 + 64 + 256) * 4)
-
-struct NmsWs {   // per-image global workspace (cap entries each)
+struct NmsWs {   // per-image global workspace (cap entries each unless noted)
     float* bx;   // [4][cap] sorted coordinates (mode 3: offset coordinates)
     float* vs;   // adjusted vote scores
     float* cs;   // cluster scores
@@ -279,27 +276,12 @@ struct NmsWs {   // per-image global workspace (cap entries each)
     int* oidx;   // original indices
     int* head;   // head position of each sorted position (-1: dropped)
     int* hpos;   // head positions in output order
+    int* seg;    // [cap + 1] label-segment starts (sorted positions), seg[nseg] = n
+    int* big;    // [cap / (64 * NMS_KREG) + 1] indices of the segments longer than 64 * NMS_KREG
+    int* misc;   // [8]: 0 nseg, 1 nbig, 2 nheads, 3 K
 };
 
-__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ boxes, const float* __restrict__ cscores,
-                                                   const float* __restrict__ vscores, const int64_t* __restrict__ labels,
-                                                   const int* __restrict__ counts, int cap, int mode, float thr,
-                                                   int iou_enable, float sigma, int max_out, float* __restrict__ out_boxes,
-                                                   float* __restrict__ out_scores, int64_t* __restrict__ out_labels,
-                                                   int* __restrict__ out_count, int64_t* __restrict__ aux0,
-                                                   int64_t* __restrict__ aux1, char* __restrict__ ws_all,
-                                                   size_t ws_per_image, int dbg_stop) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = counts[b];
-    int m = 1;
-    while (m < n) m <<= 1;
-    if (m < 2) m = 2;
-    volatile unsigned char* sup = smem + (size_t)8192 * 8;        // [8192] suppressed flags
-    int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8 + 8192);    // [64]
-    int* seg_start = s_misc + 64;                        // [<= 8192 + 1] label-segment starts
-
+__device__ __forceinline__ NmsWs nms_ws(char* ws_all, size_t ws_per_image, int b, int cap) {
     char* w = ws_all + (size_t)b * ws_per_image;
     NmsWs ws;
     ws.bx = (float*)w; w += (size_t)cap * 16;
@@ -308,14 +290,41 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
     ws.lab = (int*)w; w += (size_t)cap * 4;
     ws.oidx = (int*)w; w += (size_t)cap * 4;
     ws.head = (int*)w; w += (size_t)cap * 4;
-    ws.hpos = (int*)w;
+    ws.hpos = (int*)w; w += (size_t)cap * 4;
+    ws.seg = (int*)w; w += (size_t)(cap + 8) * 4;
+    ws.big = (int*)w; w += (size_t)(cap / (64 * NMS_KREG) + 8) * 4;
+    ws.misc = (int*)w;
+    return ws;
+}
 
+// The pipeline is five launches so that ONE image's post-processing spreads over many CUs (the reference is a
+// single-threaded host loop; a one-workgroup-per-image kernel leaves 248 of 256 CUs idle at batch 8):
+//   nms_sort_kernel     (1 WG / image)            sort by (label, score desc, index), label segments
+//   nms_small_kernel    (32 WG x 4 waves / image) greedy clustering of segments <= 64*NMS_KREG boxes, one wave each
+//   nms_big_kernel      (1 WG / crowded segment)  blocked exact greedy clustering of longer segments
+//   nms_heads_kernel    (1 WG / image)            order the cluster heads, mode 2 / 3 outputs
+//   nms_vote_kernel     (1 wave / output box)     score-weighted 1-sigma vote, strictly sequential fp32 sums
+
+// ---- 1. sort + segments
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ cscores,
+                                                        const float* __restrict__ vscores, const int64_t* __restrict__ labels,
+                                                        const int* __restrict__ counts, int cap, int mode,
+                                                        char* __restrict__ ws_all, size_t ws_per_image) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
+    int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8);            // [64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts[b];
+    int m = 1;
+    while (m < n) m <<= 1;
+    if (m < 2) m = 2;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
     const float* bsrc = boxes + (size_t)b * cap * 4;
     const float* csrc = cscores + (size_t)b * cap;
     const float* vsrc = vscores + (size_t)b * cap;
     const int64_t* lsrc = labels + (size_t)b * cap;
 
-    // ---- mode 3: class offset = label * (max coordinate + 1)
+    // mode 3: class offset = label * (max coordinate + 1)
     float offs_unit = 0.f;
     if (mode == 3) {
         float mx = -INFINITY;
@@ -330,8 +339,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         offs_unit = mx + 1.0f;
         __syncthreads();
     }
-
-    // ---- sort by (label asc, score desc, index asc)
+    // sort by (label asc, score desc, index asc)
     for (int i = tid; i < m; i += 1024) {
         unsigned long long key = ~0ull;
         if (i < n) {
@@ -342,7 +350,6 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
     }
     __syncthreads();
     bitonic_sort_u64(keys, m);
-    if (dbg_stop == 1) return;
     for (int i = tid; i < n; i += 1024) {
         const int o = (int)(keys[i] & 0xFFFFull);
         const int lab = (int)lsrc[o];
@@ -356,41 +363,48 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         ws.lab[i] = lab;
         ws.oidx[i] = o;
         ws.head[i] = -1;
-        sup[i] = 0;
     }
+    __threadfence_block();
     __syncthreads();
-    // ---- label segments
-    {
-        int nseg_total = 0;
-        for (int c0 = 0; c0 < n; c0 += 1024) {
-            const int i = c0 + tid;
-            const int is_start = (i < n) && (i == 0 || ws.lab[i] != ws.lab[i - 1]);
-            int t;
-            const int pos = block_excl_scan_1024(is_start, s_misc, t);
-            if (is_start) seg_start[nseg_total + pos] = i;
-            nseg_total += t;
-        }
-        __syncthreads();
-        if (tid == 0) { seg_start[nseg_total] = n; s_misc[32] = nseg_total; }
-        __syncthreads();
+    // label segments (ordered compaction of the segment starts)
+    int nseg_total = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const int is_start = (i < n) && (i == 0 || ws.lab[i] != ws.lab[i - 1]);
+        int t;
+        const int pos = block_excl_scan_1024(is_start, s_misc, t);
+        if (is_start) ws.seg[nseg_total + pos] = i;
+        nseg_total += t;
     }
-    const int nseg = s_misc[32];
-    if (dbg_stop == 2) return;
-    // ---- greedy clustering.  Phase A: one wavefront per label segment of up to 64 * NMS_KREG boxes, segments handed
-    //      out dynamically (long ones do not pile up on one wave).  Phase B: longer segments, whole workgroup per head.
-    if (tid == 0) s_misc[34] = 0;
+    if (tid == 0) { ws.seg[nseg_total] = n; ws.misc[0] = nseg_total; }
+    __threadfence_block();
     __syncthreads();
-    for (;;) {
-        int s = 0;
-        if (lane == 0) s = atomicAdd(&s_misc[34], 1);
-        s = __shfl(s, 0, 64);
-        if (s >= nseg) break;
-        const int p0 = seg_start[s], p1 = seg_start[s + 1];
+    // list of the crowded segments
+    int nbig = 0;
+    for (int c0 = 0; c0 < nseg_total; c0 += 1024) {
+        const int sgi = c0 + tid;
+        const int is_big = (sgi < nseg_total) && (ws.seg[sgi + 1] - ws.seg[sgi] > 64 * NMS_KREG);
+        int t;
+        const int pos = block_excl_scan_1024(is_big, s_misc, t);
+        if (is_big) ws.big[nbig + pos] = sgi;
+        nbig += t;
+    }
+    if (tid == 0) ws.misc[1] = nbig;
+}
+
+// ---- 2. short label segments: one wavefront each, boxes and suppressed bits in registers; the head box is
+//         broadcast with readlane -> no memory access inside the greedy loop except the fire-and-forget head[]
+//         stores.  Same IoU arithmetic and visiting order as the reference's loop (vote_ext.cpp:95-146).
+__global__ __launch_bounds__(256) void nms_small_kernel(int cap, int mode, float thr, int iou_enable, float sigma,
+                                                        char* __restrict__ ws_all, size_t ws_per_image) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    const int nseg = ws.misc[0];
+    const int nwaves = gridDim.x * 4;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < nseg; s += nwaves) {
+        const int p0 = ws.seg[s], p1 = ws.seg[s + 1];
         const int cnt = p1 - p0;
-        if (cnt > 64 * NMS_KREG) continue;                   // phase B
-        // register-resident segment: lane l holds boxes p0 + k*64 + l (k < NMS_KREG) and their suppressed bits;
-        // the head box is broadcast with readlane -> no memory access inside the greedy loop except the
-        // fire-and-forget head[] stores.  Same IoU arithmetic and visiting order as the reference's loop.
+        if (cnt > 64 * NMS_KREG) continue;                   // nms_big_kernel
         float X1[NMS_KREG], Y1[NMS_KREG], X2[NMS_KREG], Y2[NMS_KREG];
         unsigned supm = 0;
 #pragma unroll
@@ -434,127 +448,149 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
             }
         }
     }
-    __syncthreads();
-    // Phase B (segments longer than 64 * NMS_KREG): blocked greedy NMS with the reference's exact sequential result.
-    // Per round: (1) wave 0 collects the next <= 64 unsuppressed positions (ordered), (2) resolves the greedy order
-    // among them in registers (readlane broadcast, one IoU per lane and step) -> the round's true heads, (3) all 16
-    // wavefronts test every later unsuppressed box against those heads IN ORDER and stop at the first IoU > thr, which
-    // is exactly the head the sequential loop would have assigned.  Two barriers per 64 candidates instead of a
-    // serial pass per head.  Coordinates staged in the LDS region the sort keys no longer need (<= 4096 boxes).
-    int* bmisc = reinterpret_cast<int*>(smem + NMS_SMEM_BASE);      // [0]=nc, [1]=nh, [2]=batch_end, [3]=stop
+}
+
+// ---- 3. crowded label segments: blocked greedy NMS with the reference's exact sequential result.
+// Per round: (1) wave 0 collects the next <= 64 unsuppressed positions (ordered), (2) resolves the greedy order
+// among them in registers (readlane broadcast, one IoU per lane and step) -> the round's true heads, (3) all 16
+// wavefronts test every later unsuppressed box against those heads IN ORDER and stop at the first IoU > thr, which
+// is exactly the head the sequential loop would have assigned.  Two barriers per 64 candidates instead of a serial
+// pass per head.  Coordinates staged in LDS (<= 4096 boxes, else read through L2).
+__global__ __launch_bounds__(1024) void nms_big_kernel(int cap, int mode, float thr, int iou_enable, float sigma,
+                                                       char* __restrict__ ws_all, size_t ws_per_image) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lx = reinterpret_cast<float*>(smem);                     // [4][4096]
+    volatile unsigned char* sup = smem + (size_t)65536;             // [8192] suppressed flags (segment-local)
+    int* bmisc = reinterpret_cast<int*>(smem + 65536 + 8192);       // [0]=nc, [1]=nh, [2]=batch_end, [3]=stop
     int* bcand = bmisc + 8;                                         // [64] candidate positions
     int* bhead = bcand + 64;                                        // [64] true-head positions
     float* bhx = reinterpret_cast<float*>(bhead + 64);              // [4][64] true-head coordinates
-    for (int s = 0; s < nseg; ++s) {
-        const int p0 = seg_start[s], p1 = seg_start[s + 1];
-        const int cnt = p1 - p0;
-        if (cnt <= 64 * NMS_KREG) continue;
-        float* lx = reinterpret_cast<float*>(smem);          // [4][4096]
-        const bool in_lds = cnt <= 4096;
-        if (in_lds)
-            for (int t = tid; t < cnt; t += 1024) {
-                lx[t] = ws.bx[p0 + t]; lx[4096 + t] = ws.bx[cap + p0 + t];
-                lx[8192 + t] = ws.bx[2 * cap + p0 + t]; lx[12288 + t] = ws.bx[3 * cap + p0 + t];
-            }
-        __syncthreads();
-        const float* c0 = in_lds ? lx : ws.bx + p0;
-        const int cs = in_lds ? 4096 : cap;
-        int pos = 0;
-        bool first_round = true;
-        while (pos < cnt) {
-            if (wave == 0) {
-                // (1) next <= 64 unsuppressed positions at or after pos
-                int nc = 0, scan = pos, last = pos;
-                while (nc < 64 && scan < cnt) {
-                    const int probe = scan + lane;
-                    const bool al = probe < cnt && !sup[p0 + probe];
-                    const unsigned long long bal = __ballot(al);
-                    const int rank = nc + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (al && rank < 64) bcand[rank] = probe;
-                    const int got = __popcll(bal);
-                    if (nc + got >= 64) {                     // window holds the 64th candidate: the batch ends right after it
-                        int need = 64 - nc;                   // position of the need-th set bit of bal
-                        unsigned long long t = bal;
-                        for (int q = 1; q < need; ++q) t &= t - 1ull;
-                        last = scan + __ffsll((long long)t);
-                        nc = 64;
-                    } else {
-                        nc += got;
-                        scan += 64;
-                        last = scan < cnt ? scan : cnt;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                // (2) greedy order among the candidates
-                const bool have = lane < nc;
-                const int cp = have ? bcand[lane] : 0;
-                const float bx1 = c0[cp], by1 = c0[cs + cp], bx2 = c0[2 * cs + cp], by2 = c0[3 * cs + cp];
-                unsigned long long alive = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
-                int nh = 0, stop = 0;
-                for (int t = 0; t < nc; ++t) {
-                    if (!((alive >> t) & 1ull)) continue;
-                    if (mode == 1 && !(first_round && nh == 0)) { stop = 1; break; }   // global vote: one head per label
-                    const float x1 = __shfl(bx1, t, 64), y1 = __shfl(by1, t, 64);
-                    const float x2 = __shfl(bx2, t, 64), y2 = __shfl(by2, t, 64);
-                    const float area_i = (x2 - x1) * (y2 - y1);
-                    const int hp = __shfl(cp, t, 64);
-                    bool kill = false;
-                    float iou = 0.f;
-                    if (have && lane > t && ((alive >> lane) & 1ull)) {
-                        iou = iou_ref(x1, y1, x2, y2, area_i, bx1, by1, bx2, by2);
-                        kill = iou > thr;
-                    }
-                    if (kill) {
-                        sup[p0 + cp] = 1;
-                        ws.head[p0 + cp] = p0 + hp;
-                        if (iou_enable && mode <= 1) {
-                            const float f = -(1 - iou) * (1 - iou) / sigma;
-                            ws.vs[p0 + cp] = ws.vs[p0 + cp] * expf(f);
-                        }
-                    }
-                    alive &= ~__ballot(kill);
-                    if (lane == t) {
-                        sup[p0 + cp] = 1;
-                        ws.head[p0 + cp] = p0 + cp;
-                        bhead[nh] = cp;
-                        bhx[nh] = bx1; bhx[64 + nh] = by1; bhx[128 + nh] = bx2; bhx[192 + nh] = by2;
-                    }
-                    ++nh;
-                }
-                if (lane == 0) { bmisc[0] = nc; bmisc[1] = nh; bmisc[2] = last; bmisc[3] = stop; }
-            }
-            __syncthreads();
-            const int nh = bmisc[1], batch_end = bmisc[2], stop = bmisc[3];
-            // (3) every later box against this round's heads, in head order
-            for (int j = batch_end + tid; j < cnt; j += 1024) {
-                if (sup[p0 + j]) continue;
-                const float jx1 = c0[j], jy1 = c0[cs + j], jx2 = c0[2 * cs + j], jy2 = c0[3 * cs + j];
-                for (int q = 0; q < nh; ++q) {
-                    const float x1 = bhx[q], y1 = bhx[64 + q], x2 = bhx[128 + q], y2 = bhx[192 + q];
-                    const float iou = iou_ref(x1, y1, x2, y2, (x2 - x1) * (y2 - y1), jx1, jy1, jx2, jy2);
-                    if (iou > thr) {
-                        sup[p0 + j] = 1;
-                        ws.head[p0 + j] = p0 + bhead[q];
-                        if (iou_enable && mode <= 1) {
-                            const float f = -(1 - iou) * (1 - iou) / sigma;
-                            ws.vs[p0 + j] = ws.vs[p0 + j] * expf(f);
-                        }
-                        break;
-                    }
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    if ((int)blockIdx.x >= ws.misc[1]) return;
+    const int s = ws.big[blockIdx.x];
+    const int p0 = ws.seg[s], p1 = ws.seg[s + 1];
+    const int cnt = p1 - p0;
+    const bool in_lds = cnt <= 4096;
+    for (int t = tid; t < cnt; t += 1024) {
+        sup[t] = 0;
+        if (in_lds) {
+            lx[t] = ws.bx[p0 + t]; lx[4096 + t] = ws.bx[cap + p0 + t];
+            lx[8192 + t] = ws.bx[2 * cap + p0 + t]; lx[12288 + t] = ws.bx[3 * cap + p0 + t];
+        }
+    }
+    __syncthreads();
+    const float* c0 = in_lds ? lx : ws.bx + p0;
+    const int cs = in_lds ? 4096 : cap;
+    int pos = 0;
+    bool first_round = true;
+    while (pos < cnt) {
+        if (wave == 0) {
+            // (1) next <= 64 unsuppressed positions at or after pos
+            int nc = 0, scan = pos, last = pos;
+            while (nc < 64 && scan < cnt) {
+                const int probe = scan + lane;
+                const bool al = probe < cnt && !sup[probe];
+                const unsigned long long bal = __ballot(al);
+                const int rank = nc + __popcll(bal & ((1ull << lane) - 1ull));
+                if (al && rank < 64) bcand[rank] = probe;
+                const int got = __popcll(bal);
+                if (nc + got >= 64) {                     // this window holds the 64th candidate: the batch ends right after it
+                    const int need = 64 - nc;             // position of the need-th set bit of bal
+                    unsigned long long t = bal;
+                    for (int q = 1; q < need; ++q) t &= t - 1ull;
+                    last = scan + __ffsll((long long)t);
+                    nc = 64;
+                } else {
+                    nc += got;
+                    scan += 64;
+                    last = scan < cnt ? scan : cnt;
                 }
             }
-            __syncthreads();
-            pos = batch_end;
-            first_round = false;
-            if (stop || (mode == 1 && nh > 0)) break;        // global vote: the label's only head has been applied
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (2) greedy order among the candidates
+            const bool have = lane < nc;
+            const int cp = have ? bcand[lane] : 0;
+            const float bx1 = c0[cp], by1 = c0[cs + cp], bx2 = c0[2 * cs + cp], by2 = c0[3 * cs + cp];
+            unsigned long long alive = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+            int nh = 0, stop = 0;
+            for (int t = 0; t < nc; ++t) {
+                if (!((alive >> t) & 1ull)) continue;
+                if (mode == 1 && !(first_round && nh == 0)) { stop = 1; break; }   // global vote: one head per label
+                const float x1 = __shfl(bx1, t, 64), y1 = __shfl(by1, t, 64);
+                const float x2 = __shfl(bx2, t, 64), y2 = __shfl(by2, t, 64);
+                const float area_i = (x2 - x1) * (y2 - y1);
+                const int hp = __shfl(cp, t, 64);
+                bool kill = false;
+                float iou = 0.f;
+                if (have && lane > t && ((alive >> lane) & 1ull)) {
+                    iou = iou_ref(x1, y1, x2, y2, area_i, bx1, by1, bx2, by2);
+                    kill = iou > thr;
+                }
+                if (kill) {
+                    sup[cp] = 1;
+                    ws.head[p0 + cp] = p0 + hp;
+                    if (iou_enable && mode <= 1) {
+                        const float f = -(1 - iou) * (1 - iou) / sigma;
+                        ws.vs[p0 + cp] = ws.vs[p0 + cp] * expf(f);
+                    }
+                }
+                alive &= ~__ballot(kill);
+                if (lane == t) {
+                    sup[cp] = 1;
+                    ws.head[p0 + cp] = p0 + cp;
+                    bhead[nh] = cp;
+                    bhx[nh] = bx1; bhx[64 + nh] = by1; bhx[128 + nh] = bx2; bhx[192 + nh] = by2;
+                }
+                ++nh;
+            }
+            if (lane == 0) { bmisc[0] = nc; bmisc[1] = nh; bmisc[2] = last; bmisc[3] = stop; }
         }
         __syncthreads();
+        const int nh = bmisc[1], batch_end = bmisc[2], stop = bmisc[3];
+        // (3) every later box against this round's heads, in head order
+        for (int j = batch_end + tid; j < cnt; j += 1024) {
+            if (sup[j]) continue;
+            const float jx1 = c0[j], jy1 = c0[cs + j], jx2 = c0[2 * cs + j], jy2 = c0[3 * cs + j];
+            for (int q = 0; q < nh; ++q) {
+                const float x1 = bhx[q], y1 = bhx[64 + q], x2 = bhx[128 + q], y2 = bhx[192 + q];
+                const float iou = iou_ref(x1, y1, x2, y2, (x2 - x1) * (y2 - y1), jx1, jy1, jx2, jy2);
+                if (iou > thr) {
+                    sup[j] = 1;
+                    ws.head[p0 + j] = p0 + bhead[q];
+                    if (iou_enable && mode <= 1) {
+                        const float f = -(1 - iou) * (1 - iou) / sigma;
+                        ws.vs[p0 + j] = ws.vs[p0 + j] * expf(f);
+                    }
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        pos = batch_end;
+        first_round = false;
+        if (stop || (mode == 1 && nh > 0)) break;            // global vote: the label's only head has been applied
     }
-    __threadfence_block();
-    __syncthreads();
-    if (dbg_stop == 3) return;
-    // ---- order the heads: (score desc, original index asc)
+}
+
+// ---- 4. order the cluster heads (score desc, original index asc); mode 2 / 3 outputs
+__global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                         int cap, int mode, int max_out, float* __restrict__ out_boxes,
+                                                         float* __restrict__ out_scores, int64_t* __restrict__ out_labels,
+                                                         int* __restrict__ out_count, int64_t* __restrict__ aux0,
+                                                         int64_t* __restrict__ aux1, char* __restrict__ ws_all,
+                                                         size_t ws_per_image) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
+    int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8);            // [64]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts[b];
+    int m = 1;
+    while (m < n) m <<= 1;
+    if (m < 2) m = 2;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    const float* bsrc = boxes + (size_t)b * cap * 4;
     for (int i = tid; i < m; i += 1024) {
         unsigned long long key = ~0ull;
         if (i < n && ws.head[i] == i)
@@ -579,10 +615,10 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         __syncthreads();
     }
     const int nheads = s_misc[33];
-    if (dbg_stop == 4) return;
     const int K = (max_out > 0 && nheads > max_out) ? max_out : nheads;
-    if (tid == 0) out_count[b] = K;
+    if (tid == 0) { out_count[b] = K; ws.misc[2] = nheads; ws.misc[3] = K; }
     for (int r = tid; r < nheads; r += 1024) ws.hpos[r] = (int)(keys[r] & 0xFFFFull);
+    __threadfence_block();
     __syncthreads();
 
     if (mode == 2) {
@@ -590,6 +626,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
         int64_t* inst = aux0 + (size_t)b * cap;
         int64_t* num = aux1 + (size_t)b * cap;
         for (int i = tid; i < n; i += 1024) num[ws.oidx[i]] = 0;
+        __threadfence_block();
         __syncthreads();
         for (int r = tid; r < nheads; r += 1024) {
             const int h = ws.hpos[r];
@@ -613,37 +650,73 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
             out_labels[(size_t)b * max_out + r] = ws.lab[h];
             keep[r] = o;
         }
-        return;
     }
-    // ---- vote: one thread per (head, coordinate); strictly sequential fp32 sums in member order
+}
+
+// ---- 5. vote: one wavefront per output box.  The wave streams the head's label segment in 64-box chunks
+// (coalesced), compacts the cluster members in order into LDS, and lanes 0..3 (one per coordinate) run the
+// reference's strictly sequential fp32 sums over them (vote_ext.cpp:8-35,148-200): three passes (mean, sigma,
+// 1-sigma window), bit-exact.
+__global__ __launch_bounds__(64) void nms_vote_kernel(const int* __restrict__ counts, int cap, int max_out,
+                                                      float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                      int64_t* __restrict__ out_labels, char* __restrict__ ws_all,
+                                                      size_t ws_per_image) {
+    __shared__ float m_vs[64], m_cs[64], m_x[4][64];
+    const int b = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    if (r >= ws.misc[3]) return;
+    const int n = counts[b];
     const int out_cap = max_out > 0 ? max_out : cap;
-    for (int t = tid; t < K * 4; t += 1024) {
-        const int r = t >> 2, d = t & 3;
-        const int h = ws.hpos[r];
-        const int lab = ws.lab[h];
-        const float* xs = ws.bx + (size_t)d * cap;
-        float ssum = 0.f, v = 0.f;
-        int p1 = h;
-        for (int j = h; j < n && ws.lab[j] == lab; ++j) {
-            p1 = j + 1;
-            if (ws.head[j] != h) continue;
-            ssum += ws.vs[j];
-            v += ws.vs[j] * xs[j];
+    const int h = ws.hpos[r];
+    const int lab = ws.lab[h];
+    // end of the head's label segment: binary search in the segment starts
+    int p1;
+    {
+        int lo = 0, hi = ws.misc[0];           // seg[lo] <= h < seg[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ws.seg[mid] <= h) lo = mid; else hi = mid;
         }
-        v = v / ssum;
-        float sig = 0.f;
-        for (int j = h; j < p1; ++j) {
-            if (ws.head[j] != h) continue;
-            sig += ws.vs[j] * (xs[j] - v) * (xs[j] - v);
+        p1 = ws.seg[hi];
+    }
+    (void)n;
+    const int d = lane & 3;
+    float ssum = 0.f, v = 0.f, sig = 0.f, fs = 0.f, fv = 0.f, mx = -INFINITY;
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int c0 = h; c0 < p1; c0 += 64) {
+            const int j = c0 + lane;
+            const bool mem = j < p1 && ws.head[j] == h;
+            const unsigned long long bal = __ballot(mem);
+            const int cntm = __popcll(bal);
+            if (cntm == 0) continue;
+            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            if (mem) {
+                m_vs[rank] = ws.vs[j];
+                m_cs[rank] = ws.cs[j];
+                m_x[0][rank] = ws.bx[j]; m_x[1][rank] = ws.bx[cap + j];
+                m_x[2][rank] = ws.bx[2 * cap + j]; m_x[3][rank] = ws.bx[3 * cap + j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 4) {
+                if (pass == 0) {
+                    for (int q = 0; q < cntm; ++q) { ssum += m_vs[q]; v += m_vs[q] * m_x[d][q]; }
+                } else if (pass == 1) {
+                    for (int q = 0; q < cntm; ++q) sig += m_vs[q] * (m_x[d][q] - v) * (m_x[d][q] - v);
+                } else {
+                    for (int q = 0; q < cntm; ++q) {
+                        const float x = m_x[d][q];
+                        if ((v - sig <= x) & (x <= v + sig)) { fv += m_vs[q] * x; fs += m_vs[q]; }
+                        mx = fmaxf(mx, m_cs[q]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        sig = sqrtf(sig / ssum);
-        float fs = 0.f, fv = 0.f, mx = -INFINITY;
-        for (int j = h; j < p1; ++j) {
-            if (ws.head[j] != h) continue;
-            const float x = xs[j];
-            if ((v - sig <= x) & (x <= v + sig)) { fv += ws.vs[j] * x; fs += ws.vs[j]; }
-            mx = fmaxf(mx, ws.cs[j]);
-        }
+        if (pass == 0) v = v / ssum;
+        else if (pass == 1) sig = sqrtf(sig / ssum);
+    }
+    if (lane < 4) {
         out_boxes[((size_t)b * out_cap + r) * 4 + d] = fv / fs;
         if (d == 0) {
             out_scores[(size_t)b * out_cap + r] = mx;
@@ -652,7 +725,9 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
     }
 }
 
-static size_t nms_ws_per_image(int cap) { return ((size_t)cap * (16 + 4 * 6) + 255) / 256 * 256; }
+static size_t nms_ws_per_image(int cap) {
+    return ((size_t)cap * (16 + 4 * 6) + (size_t)(cap + 8) * 4 + (size_t)(cap / (64 * NMS_KREG) + 8) * 4 + 64 + 255) / 256 * 256;
+}
 
 extern "C" size_t radet_nms_ws_bytes(int B, int cap) { return (size_t)B * nms_ws_per_image(cap); }
 
@@ -662,16 +737,30 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
                          int64_t* out_labels, int* out_count, int64_t* aux0, int64_t* aux1, void* ws, void* stream) {
     if (cap < 1 || cap > 8192 || mode < 0 || mode > 3 || B < 1) return RADET_ERR_ARG;
     if (mode == 3 && max_out <= 0) return RADET_ERR_ARG;
-    const size_t smem = NMS_SMEM_TOTAL;
+    const size_t smem_sort = (size_t)8192 * 8 + 64 * 4;
+    const size_t smem_big = (size_t)65536 + 8192 + (8 + 64 + 64 + 256) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem_sort) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(nms_heads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem_sort) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(nms_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem_big) != hipSuccess)
             return RADET_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), smem, (hipStream_t)stream, boxes, cluster_scores, vote_scores,
-                       labels, counts, cap, mode, iou_thr, iou_enable, sigma, max_out, out_boxes, out_scores, out_labels,
-                       out_count, aux0, aux1, (char*)ws, nms_ws_per_image(cap), getenv("RADET_NMS_STOP") ? atoi(getenv("RADET_NMS_STOP")) : 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t wpi = nms_ws_per_image(cap);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), smem_sort, st, boxes, cluster_scores, vote_scores, labels,
+                       counts, cap, mode, (char*)ws, wpi);
+    hipLaunchKernelGGL(nms_small_kernel, dim3(32, B), dim3(256), 0, st, cap, mode, iou_thr, iou_enable, sigma, (char*)ws, wpi);
+    hipLaunchKernelGGL(nms_big_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(1024), smem_big, st, cap, mode, iou_thr,
+                       iou_enable, sigma, (char*)ws, wpi);
+    hipLaunchKernelGGL(nms_heads_kernel, dim3(B), dim3(1024), smem_sort, st, boxes, counts, cap, mode, max_out, out_boxes,
+                       out_scores, out_labels, out_count, aux0, aux1, (char*)ws, wpi);
+    if (mode <= 1)
+        hipLaunchKernelGGL(nms_vote_kernel, dim3(max_out > 0 ? max_out : cap, B), dim3(64), 0, st, counts, cap, max_out,
+                           out_boxes, out_scores, out_labels, (char*)ws, wpi);
     return radet_check_launch();
 }

@@ -16,6 +16,10 @@ import os
 import sys
 import time
 
+# main + side (wgrad / slab reduction) + RCCL streams must not share a hardware queue (HIP default: 4 queues, and a
+# queue shared by two busy streams serialises them: -12 % on the data-parallel path); read at HIP initialisation
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -124,8 +128,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or os.environ.get("RADET_FORCE_REDUCER") == "1":   # the latter: 1-rank RCCL run of the bucketed exchange
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from radet_amd.models import build_detector
@@ -218,7 +224,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1443,7 +1443,7 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
     const int chunks = (M + 15) / 16;
     // pick S in the 2..4 blocks-per-CU range whose block count quantises best onto 256 CUs
     long lo = (448 + tiles - 1) / tiles, hi = (1024 + tiles - 1) / tiles;
-    if (use_wgrad9(M, Cin, Cout, KH, KW) && wgrad9_bm(Cout) == 256) {
+    if (use_wgrad9(M, Cin, Cout, KH, KW)) {
         // 8-wave workgroups: one per CU already gives 2 waves per SIMD, and every extra split costs a full
         // weight-sized slab write + read in unfold
         lo = hi = (256 + tiles - 1) / tiles;
@@ -1494,7 +1494,8 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
             else hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 0>), dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
-            hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
+            if (getenv("RADET_WGRAD9_REGSTAGE")) hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad9g_kernel<4, 0>), dim3(tiles), dim3(256), 0, st, a);
         }
         return radet_check_launch();
     }

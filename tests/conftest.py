@@ -1,4 +1,6 @@
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see radet_amd/__init__.py: main / side / RCCL streams, one HW queue each
 import sys
 
 import pytest

@@ -195,8 +195,6 @@ class Engine:
                 if blk["ds"] is not None:
                     blk["ds"].geom = ConvGeom(lv, blk["ds"].cin, blk["ds"].cout, 1, blk["stride"], 0)
                     new(pfx + ".idt", lo.rows, blk["ds"].cout)
-                    if blk["ds"].need_dgrad:
-                        new(pfx + ".tmp_in", lv.rows, blk["ds"].cin)
                 blk["lout"] = lo
                 new(pfx + ".o1", lv.rows, blk["c1"].cout)
                 new(pfx + ".o2", lo.rows, blk["c2"].cout)
@@ -658,9 +656,11 @@ class Engine:
                     K.relu_bwd(ext, None, out, d_pre)
                 elif nxt["ds"] is not None:
                     # next block is the first of the next stage: conv1 + downsample both read `out`
-                    t = nxt["tmp_in"]
-                    K.conv_dgrad(nxt["ds"].geom, nxt["d_pre"], nxt["ds"].wft, t, addend=ext)
-                    K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pre, addend=t, mask=out)
+                    # d_pre = [out > 0] * (dgrad_conv1 + ext + dgrad_downsample): the dense conv1 term first, then the
+                    # strided 1x1 downsample accumulates in place on the quarter of the positions it reaches
+                    K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pre, addend=ext, mask=out)
+                    K.conv_dgrad(nxt["ds"].geom, nxt["d_pre"], nxt["ds"].wft, d_pre, addend=d_pre, mask=out,
+                                 skip_zero_rows=True)
                 else:
                     # identity shortcut: d_out = dgrad_conv1(next) + d_pre(next)
                     K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pre, addend=nxt["d_pre"], mask=out)
@@ -674,8 +674,6 @@ class Engine:
                 self._wgrad_async(c1.geom, d_o1, blk["x"], c1.slabs, c1.dbias_partials)
                 if ds is not None:
                     self._wgrad_async(ds.geom, d_pre, blk["x"], ds.slabs, ds.dbias_partials)
-                    if ds.need_dgrad:
-                        blk["tmp_in"] = b[pfx + ".tmp_in"]
                 nxt = blk
             if after_stage is not None:
                 after_stage(li)

@@ -182,23 +182,32 @@ def autotune(g, need_dgrad=True, reps=3):
             out.append((sorted(ts)[len(ts) // 2], t))
         return min(out)[1]
 
-    def cands(kdim, n):
+    def cands(kdim, n, m, taps):
         tiles = [4] if n <= 32 else [1, 2, 3]
         c = [t for t in tiles]
         if kdim % 32 == 0:
             c += [t | 0x200 for t in tiles]
-        return c
+        # short grids: also try explicit split-K factors (bits 12-15) instead of the launcher's heuristic
+        out = list(c)
+        for t in c:
+            bm = 64 if (t & 0xFF) == 3 else 128
+            bn = {1: 128, 2: 64, 3: 64, 4: 32}[t & 0xFF]
+            ntiles = -(-m // bm) * -(-n // bn)
+            nk = taps * kdim // (32 if t & 0x200 else 16)
+            if ntiles < 512:
+                out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
+        return out
 
     key = (g._key, g.cin, g.cout, g.math)
     if key not in _TUNE_CACHE:
         x = torch.randn(g.lin.rows, g.cin, device=dev)
         w = torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05
         y = torch.empty(g.lout.rows, g.cout, device=dev)
-        ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout))
+        ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout, g.lout.rows, g.k * g.k))
         bt = 0
         if need_dgrad and g.stride == 1 and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev)
-            bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin))
+            bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
         _TUNE_CACHE[key] = (ft, bt)
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
 
@@ -235,13 +244,19 @@ def conv_dgrad_pair(g, a, b, tile=0):
               _tile(g, tile, g.bwd_tile), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
 
-def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True):
-    """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft."""
+def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
+    """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft.
+    skip_zero_rows: the caller accumulates in place (addend is dx) with a mask already applied to dx, so the
+    input positions a strided conv never touches (3/4 of them for a 1x1 / 2) are left alone instead of being
+    rewritten by an epilogue-only launch."""
     kc = g.cout if k_channels is None else k_channels
     tile = _tile(g, tile, g.bwd_tile)
     ws = splitk_ws() if splitk else None
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         for c in _strided_dgrad_classes(g):
+            if c["zero"] and skip_zero_rows:
+                assert addend is not None and addend.data_ptr() == dx.data_ptr()
+                continue
             # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table
             _lib.call("radet_conv2d_igemm_taps", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
                       _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"], 16 if c["zero"] else kc, g.cin,

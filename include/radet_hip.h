@@ -79,7 +79,8 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
                             void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
- * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm). */
+ * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bits 4-5: tile override of the one-tap
+ * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                        int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);

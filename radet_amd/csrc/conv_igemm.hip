@@ -1486,7 +1486,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
-    if (use_wgrad9(M, Cin, Cout, KH, KW) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
+    if (use_wgrad9(M, Cin, Cout, KH, KW) && !(flags & 0x40) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
             if (getenv("RADET_WGRAD9_REGSTAGE") && a.math == 0) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
@@ -1501,6 +1501,8 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     }
     int bm, bn;
     wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
+    if (bm != 32 && ((flags >> 4) & 3) == 1) bm = bn = 128;      // autotuned tile (radet_amd/kernels.py)
+    if (bm != 32 && ((flags >> 4) & 3) == 2) bm = bn = 64;
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
     else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
     else launch_wgrad<128, 128, 2, 2>(a, st);

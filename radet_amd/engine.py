@@ -249,6 +249,14 @@ class Engine:
         self.loss_ws = torch.zeros(K.head_loss_ws_ints(R), dtype=torch.int32, device=dev)
         self.losses = torch.zeros(3, device=dev)
         self.dscales = torch.zeros(len(hw), device=dev)
+        for c in self.convs:
+            if c.geom is not None:
+                c.geom.math = self.math
+        tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
+        if tune:
+            for c in self.convs:          # before the slabs are sized: this chooses the number of pixel splits
+                if c.trainable and c.geom is not None and c.cout > 64 and c.cin > 64:
+                    K.autotune_wgrad(c.geom)
         # wgrad slabs / bias partials + descriptor table
         n_slab = sum(c.geom.nsplit * c.wsize for c in self.convs if c.trainable)
         n_bp = sum(c.geom.nsplit * c.cout for c in self.convs if c.trainable)
@@ -264,10 +272,7 @@ class Engine:
                 c.dbias_partials = self.bp_arena[o_b:o_b + n]
                 o_b += n
         self._build_table()
-        for c in self.convs:
-            if c.geom is not None:
-                c.geom.math = self.math
-        if os.environ.get("RADET_AUTOTUNE", "1") != "0":
+        if tune:
             towers = self.cls_tower + self.reg_tower
             for c in self.convs:
                 # the fp32 tower GEMM has a fixed, measured-best tile (TOWER_TAG); in bf16 math it is tuned like the rest

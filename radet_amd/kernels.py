@@ -1,6 +1,7 @@
 """Thin Python launchers over the C ABI (include/radet_hip.h): torch tensors are used only as device
 buffers (data_ptr) and for the current HIP stream.  No arithmetic happens in PyTorch here."""
 import ctypes as C
+import os
 
 import torch
 
@@ -84,6 +85,7 @@ class ConvGeom:
         self._key = (tuple(lin.hw), tuple(lin.offsets), lin.B, k, stride, pad)
         self.fwd_tile = self.bwd_tile = 0     # 0 = launcher heuristic; set by autotune()
         self.math = 0                         # 1: bf16 math mode (operands rounded to bf16, fp32 accumulate)
+        self.wgrad_flags = 0                  # tile override of the wgrad launcher (set by autotune_wgrad)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
 
     @property
@@ -194,7 +196,7 @@ def autotune(g, need_dgrad=True, reps=3):
             bn = {1: 128, 2: 64, 3: 64, 4: 32}[t & 0xFF]
             ntiles = -(-m // bm) * -(-n // bn)
             nk = taps * kdim // (32 if t & 0x200 else 16)
-            if ntiles < 512:
+            if ntiles < 1024:
                 out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
         return out
 
@@ -225,6 +227,52 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
               g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
               _stream())
+
+
+_WTUNE_CACHE = {}
+
+
+def autotune_wgrad(g, reps=3):
+    """Pick (tile, pixel splits S) of the one-tap wgrad kernel for this geometry: time the candidates and charge each
+    split its downstream cost (a weight-sized slab is written here and read again by unfold: ~2 * 4 B / weight at
+    ~3 TB/s).  Must run before the slab buffers are sized (it changes g.nsplit)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    key = (g._key, g.cin, g.cout, g.math, "w")
+    if key not in _WTUNE_CACHE:
+        M, kk = g.lout.rows, g.k * g.k
+        s0 = g.nsplit
+        cands = [(0, s0)]
+        if g.cout > 64 and g.cin > 64:
+            for tflag, t in ((1 << 4, 128), (2 << 4, 64)):
+                tiles = -(-g.cout // t) * -(-g.cin // t) * kk
+                for blocks in (256, 512, 768, 1024):
+                    S = max(1, min(64, round(blocks / tiles), (M + 127) // 128))
+                    cands.append((tflag | 0x40, S))
+        cands = sorted(set(cands))
+        dy = torch.randn(M, g.cout, device=dev)
+        x = torch.randn(g.lin.rows, g.cin, device=dev)
+        slabs = torch.empty(max(c[1] for c in cands) * g.cout * kk * g.cin, device=dev)
+        best = None
+        for fl, S in cands:
+            g.wgrad_flags, g.nsplit = fl, S
+            conv_wgrad(g, dy, x, slabs)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                conv_wgrad(g, dy, x, slabs)
+                e.record()
+                e.synchronize()
+                ts.append(s.elapsed_time(e))
+            cost = sorted(ts)[len(ts) // 2] + S * g.cout * kk * g.cin * 8 / 3e12 * 1e3
+            if best is None or cost < best[0]:
+                best = (cost, fl, S)
+        _WTUNE_CACHE[key] = best[1:]
+        if os.environ.get("RADET_TUNE_LOG"):
+            print(f"[tune wgrad] M={M} {g.cin}->{g.cout} k{g.k}s{g.stride}: heuristic S={s0} -> flags={best[1]:#x} S={best[2]} "
+                  f"({best[0] * 1e3:.1f} us incl. slab cost)")
+    g.wgrad_flags, g.nsplit = _WTUNE_CACHE[key]
 
 
 def conv_fwd_pair(g, a, b, relu=False, tile=0):
@@ -269,7 +317,7 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
-              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 1 if g.math else 0, _stream())
+              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, (1 if g.math else 0) | g.wgrad_flags, _stream())
 
 
 def fold_weights(table_dev, n):

@@ -41,6 +41,67 @@ __device__ __forceinline__ int block_excl_scan_1024(int flag, int* s_wave, int& 
     return base + within;
 }
 
+#define DEC_LIST_CAP 16384   // candidates per (level, image) the LDS list of the fast decode path holds (128 KiB)
+
+struct DecCtx {
+    const float* reg_u; const float* iou; const float* scale_factor;
+    float* lv_boxes; float* lv_scores; float* lv_ctr; int64_t* lv_labels;
+    int C, wl, stride_i, r0, b;
+    float stride, sc, H, W;
+    size_t obase;
+};
+
+// TBLR decode + clamp (+ rescale) of flattened candidate i with score s into output slot `slot` of its level region
+__device__ __forceinline__ void decode_one(const DecCtx& d, int i, float s, int slot) {
+    const int pt = i / d.C, c = i - pt * d.C;
+    const int iy = pt / d.wl, ix = pt - iy * d.wl;
+    const float cx = (float)(ix * d.stride_i), cy = (float)(iy * d.stride_i);
+    const float4 u4 = *reinterpret_cast<const float4*>(d.reg_u + (size_t)(d.r0 + pt) * 4);
+    const float hw8 = 8.f * d.stride;
+    const float top = fmaxf(u4.x * d.sc, 0.f) * 0.125f * hw8, bottom = fmaxf(u4.y * d.sc, 0.f) * 0.125f * hw8;
+    const float left = fmaxf(u4.z * d.sc, 0.f) * 0.125f * hw8, right = fmaxf(u4.w * d.sc, 0.f) * 0.125f * hw8;
+    float x1 = cx - left, y1 = cy - top, x2 = cx + right, y2 = cy + bottom;
+    x1 = fminf(fmaxf(x1, 0.f), d.W); x2 = fminf(fmaxf(x2, 0.f), d.W);
+    y1 = fminf(fmaxf(y1, 0.f), d.H); y2 = fminf(fmaxf(y2, 0.f), d.H);
+    if (d.scale_factor) {
+        x1 /= d.scale_factor[d.b * 4 + 0]; y1 /= d.scale_factor[d.b * 4 + 1];
+        x2 /= d.scale_factor[d.b * 4 + 2]; y2 /= d.scale_factor[d.b * 4 + 3];
+    }
+    const size_t o = d.obase + slot;
+    *reinterpret_cast<float4*>(d.lv_boxes + o * 4) = make_float4(x1, y1, x2, y2);
+    d.lv_scores[o] = s;
+    d.lv_ctr[o] = sigmoidf_(d.iou[d.r0 + pt]);
+    d.lv_labels[o] = c;
+}
+
+// Radix-select step by one wavefront: the bin (scanning from the highest bin down) in which the cumulative count
+// reaches `remaining`, and how many are still needed inside that bin.  Lane l owns nb/64 consecutive bins (highest
+// first), so the serial part is nb/64 + log2(64) steps instead of a nb-step dependent LDS chain.
+__device__ __forceinline__ void find_kth_bin(const int* hist, int nb, int remaining, int* s_sel) {
+    const int lane = threadIdx.x & 63;
+    const int per = nb >> 6;
+    const int top = nb - 1 - lane * per;               // my bins: top, top-1, ..., top-per+1
+    int mine = 0;
+    for (int j = 0; j < per; ++j) mine += hist[top - j];
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const unsigned long long hit = __ballot(incl >= remaining);
+    const int owner = hit ? __ffsll((long long)hit) - 1 : 63;
+    if (lane == owner) {
+        int acc = incl - mine, bin = top;
+        for (int j = 0; j < per; ++j, --bin) {
+            if (acc + hist[bin] >= remaining || j == per - 1) break;
+            acc += hist[bin];
+        }
+        s_sel[0] = bin;
+        s_sel[1] = remaining - acc;
+    }
+}
+
 __global__ __launch_bounds__(1024) void decode_kernel(const float* __restrict__ cls, const float* __restrict__ reg_u,
                                                       const float* __restrict__ iou, const float* __restrict__ scales,
                                                       const DecLevels L, int B, int C, float score_thr, int nms_pre,
@@ -48,7 +109,7 @@ __global__ __launch_bounds__(1024) void decode_kernel(const float* __restrict__ 
                                                       const float* __restrict__ scale_factor,
                                                       float* __restrict__ lv_boxes, float* __restrict__ lv_scores,
                                                       float* __restrict__ lv_ctr, int64_t* __restrict__ lv_labels,
-                                                      int* __restrict__ lv_count) {
+                                                      int* __restrict__ lv_count, int force_slow) {
     const int l = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x;
     const int hw = L.h[l] * L.w[l];
@@ -59,23 +120,132 @@ __global__ __launch_bounds__(1024) void decode_kernel(const float* __restrict__ 
     __shared__ int s_wave[16];
     __shared__ int s_sel[4];
 
-    // ---- count candidates
-    int cnt = 0;
-    for (int i = tid; i < total; i += 1024) cnt += sigmoidf_(s_in[i]) > score_thr ? 1 : 0;
-    int tot;
-    {
-        // reuse the scan helper for a block sum
-        __syncthreads();
-        int c = cnt;
+    // ---- count candidates: every wavefront owns a contiguous index range (so that ordered compaction needs no
+    //      block-wide scan per 1024 elements, only one 16-entry prefix)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per_wave = (((total + 15) / 16) + 63) / 64 * 64;
+    const int wb = wave * per_wave;
+    const int we = wb + per_wave < total ? wb + per_wave : total;
+    int wc = 0;
+    constexpr int DU = 8;                         // independent loads in flight per lane (the loop is latency bound)
+    for (int i0 = wb; i0 < we; i0 += 64 * DU) {
+        float xv[DU];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if ((tid & 63) == 0) s_wave[tid >> 6] = c;
-        __syncthreads();
-        tot = 0;
+        for (int u = 0; u < DU; ++u) {
+            const int i = i0 + u * 64 + lane;
+            xv[u] = i < we ? s_in[i] : -INFINITY;  // sigmoid(-inf) = 0: never a candidate
+        }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tot += s_wave[i];
-        __syncthreads();
+        for (int u = 0; u < DU; ++u) wc += __popcll(__ballot(sigmoidf_(xv[u]) > score_thr));
     }
+    if (lane == 0) s_wave[wave] = wc;
+    __syncthreads();
+    int tot = 0, wbase = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < wave) wbase += s_wave[i];
+        tot += s_wave[i];
+    }
+    __syncthreads();
+
+    if (tot <= DEC_LIST_CAP && !force_slow) {
+        // ---- fast path: the candidates (a few % of the scores) are compacted once, in index order, into an LDS list
+        //      of (index, score bits); the exact top-k selection and the decode then only touch that list
+        extern __shared__ __attribute__((aligned(16))) unsigned long long dec_list[];
+        int run = wbase;
+        {
+            for (int i0 = wb; i0 < we; i0 += 64 * DU) {
+                float xv[DU];
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    xv[u] = i < we ? s_in[i] : -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    const float sv = sigmoidf_(xv[u]);
+                    const bool pass = sv > score_thr;
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) dec_list[run + __popcll(bal & ((1ull << lane) - 1ull))] =
+                        ((unsigned long long)(unsigned)i << 32) | (unsigned long long)__float_as_uint(sv);
+                    run += __popcll(bal);
+                }
+            }
+        }
+        __syncthreads();
+        DecCtx dc;
+        dc.reg_u = reg_u; dc.iou = iou; dc.scale_factor = scale_factor;
+        dc.lv_boxes = lv_boxes; dc.lv_scores = lv_scores; dc.lv_ctr = lv_ctr; dc.lv_labels = lv_labels;
+        dc.C = C; dc.wl = L.w[l]; dc.stride_i = L.stride[l]; dc.r0 = r0; dc.b = b;
+        dc.stride = (float)L.stride[l]; dc.sc = scales[l]; dc.H = img_hw[b * 2 + 0]; dc.W = img_hw[b * 2 + 1];
+        dc.obase = ((size_t)b * L.n + l) * nms_pre;
+        if (tot <= nms_pre) {
+            for (int t = tid; t < tot; t += 1024)
+                decode_one(dc, (int)(dec_list[t] >> 32), __uint_as_float((unsigned)dec_list[t]), t);
+            if (tid == 0) lv_count[b * L.n + l] = tot;
+            return;
+        }
+        // exact k-th largest score: 3-pass radix select on the (positive) float bits of the list
+        unsigned prefix = 0u, pmask = 0u;
+        int remaining = nms_pre;
+        const int shifts[3] = {21, 10, 0};
+        const int widths[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+            __syncthreads();
+            const int sh = shifts[pass];
+            const unsigned bm = (1u << widths[pass]) - 1u;
+            for (int t = tid; t < tot; t += 1024) {
+                const unsigned u = (unsigned)dec_list[t];
+                if ((u & pmask) == prefix) atomicAdd(&hist[(u >> sh) & bm], 1);
+            }
+            __syncthreads();
+            if (tid < 64) find_kth_bin(hist, (int)bm + 1, remaining, s_sel);
+            __syncthreads();
+            prefix |= ((unsigned)s_sel[0]) << sh;
+            pmask |= bm << sh;
+            remaining = s_sel[1];
+            __syncthreads();
+        }
+        const unsigned thr_bits = prefix;
+        const int need_eq = remaining;
+        // ordered selection over the list: scores above the threshold + the first need_eq equal to it (index order)
+        const int lper = (((tot + 15) / 16) + 63) / 64 * 64;
+        const int lb = wave * lper;
+        const int le = lb + lper < tot ? lb + lper : tot;
+        int ngt = 0, neq = 0;
+        for (int t0 = lb; t0 < le; t0 += 64) {
+            const int t = t0 + lane;
+            const unsigned u = t < le ? (unsigned)dec_list[t] : 0u;
+            ngt += __popcll(__ballot(t < le && u > thr_bits));
+            neq += __popcll(__ballot(t < le && u == thr_bits));
+        }
+        int* s_gt = hist;            // reuse: [16] + [16]
+        int* s_eq = hist + 16;
+        if (lane == 0) { s_gt[wave] = ngt; s_eq[wave] = neq; }
+        __syncthreads();
+        int gt_before = 0, eq_before = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < wave) { gt_before += s_gt[i]; eq_before += s_eq[i]; }
+        for (int t0 = lb; t0 < le; t0 += 64) {
+            const int t = t0 + lane;
+            const unsigned long long e = t < le ? dec_list[t] : 0ull;
+            const unsigned u = (unsigned)e;
+            const bool gt = t < le && u > thr_bits, eq = t < le && u == thr_bits;
+            const unsigned long long bgt = __ballot(gt), beq = __ballot(eq);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int g0 = gt_before + __popcll(bgt & lt), e0 = eq_before + __popcll(beq & lt);
+            if (gt || (eq && e0 < need_eq))
+                decode_one(dc, (int)(e >> 32), __uint_as_float(u), g0 + (e0 < need_eq ? e0 : need_eq));
+            gt_before += __popcll(bgt);
+            eq_before += __popcll(beq);
+        }
+        if (tid == 0) lv_count[b * L.n + l] = nms_pre;
+        return;
+    }
+    // ---- slow path (more than DEC_LIST_CAP scores above the threshold): multi-pass over the raw scores
     const int k = tot < nms_pre ? tot : nms_pre;
     // ---- exact k-th largest score by radix select on the (positive) float bits
     unsigned thr_bits = 0u;   // select bits > thr_bits, plus the first `need_eq` with bits == thr_bits
@@ -98,15 +268,7 @@ __global__ __launch_bounds__(1024) void decode_kernel(const float* __restrict__ 
                 }
             }
             __syncthreads();
-            if (tid == 0) {
-                int acc = 0, bin = (int)bm;
-                for (; bin >= 0; --bin) {
-                    if (acc + hist[bin] >= remaining) break;
-                    acc += hist[bin];
-                }
-                s_sel[0] = bin;
-                s_sel[1] = remaining - acc;
-            }
+            if (tid < 64) find_kth_bin(hist, (int)bm + 1, remaining, s_sel);
             __syncthreads();
             prefix |= ((unsigned)s_sel[0]) << sh;
             pmask |= bm << sh;
@@ -225,8 +387,16 @@ extern "C" int radet_decode_candidates(const float* cls, const float* reg_u, con
     float* lv_ctr = (float*)p; p += n * 4;
     int* lv_count = (int*)p;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(decode_kernel, dim3(nlvl, B), dim3(1024), 0, st, cls, reg_u, iou, scales, L, B, num_classes,
-                       score_thr, nms_pre, img_hw, scale_factor, lv_boxes, lv_scores, lv_ctr, lv_labels, lv_count);
+    static bool dec_attr = false;
+    if (!dec_attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                DEC_LIST_CAP * 8) != hipSuccess)
+            return RADET_ERR_LAUNCH;
+        dec_attr = true;
+    }
+    hipLaunchKernelGGL(decode_kernel, dim3(nlvl, B), dim3(1024), DEC_LIST_CAP * 8, st, cls, reg_u, iou, scales, L, B, num_classes,
+                       score_thr, nms_pre, img_hw, scale_factor, lv_boxes, lv_scores, lv_ctr, lv_labels, lv_count,
+                       getenv("RADET_DECODE_SLOW") ? 1 : 0);   // test hook: force the multi-pass path
     hipLaunchKernelGGL(compact_levels_kernel, dim3(B), dim3(256), 0, st, lv_boxes, lv_scores, lv_ctr, lv_labels, lv_count,
                        nlvl, nms_pre, cand_boxes, cand_scores, cand_ctr, cand_labels, cand_count);
     return radet_check_launch();

@@ -207,10 +207,12 @@ def autotune(g, need_dgrad=True, reps=3):
         y = torch.empty(g.lout.rows, g.cout, device=dev)
         ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout, g.lout.rows, g.k * g.k))
         bt = 0
-        if need_dgrad and g.stride == 1 and g.cout % 16 == 0:
+        if need_dgrad and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev)
             bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
         _TUNE_CACHE[key] = (ft, bt)
+        if os.environ.get("RADET_TUNE_LOG"):
+            print(f"[tune igemm] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={ft:#x} dgrad tile={bt:#x}")
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
 
 

@@ -381,6 +381,45 @@ def test_decode_and_nms_vs_reference_golden(K, golden):
             assert np.allclose(osc[i, :k].cpu().numpy(), ref_b[:, 4], rtol=TOL, atol=1e-7)
 
 
+@pytest.mark.parametrize("cls_mean", [-4.0, -2.0, 0.0])
+def test_decode_fast_and_multipass_paths_agree(K, cls_mean):
+    """decode_kernel has a fast path (candidates compacted once into an LDS list, <= 16384 per level and image) and a
+    multi-pass path over the raw scores (denser outputs): both must produce bit-identical candidate lists; at
+    cls_mean = 0 half of all scores pass the threshold, so level 0 takes the multi-pass path by itself."""
+    import os
+    cls, reg, iou = synth_head_outputs(11, 2, cls_mean=cls_mean)
+    dev, B, cap = "cuda", 2, 5000
+    lv = K.Levels(LEVEL_HW, B)
+    ld, nl = K.level_desc(lv, STRIDES)
+    fc, fr, fi = flat(cls).to(dev), flat(reg).to(dev), flat(iou).reshape(-1).contiguous().to(dev)
+    hw = torch.tensor([[480., 640.]] * B, device=dev)
+    outs = []
+    for slow in (False, True):
+        if slow:
+            os.environ["RADET_DECODE_SLOW"] = "1"
+        try:
+            boxes, scores = torch.zeros(B, cap, 4, device=dev), torch.zeros(B, cap, device=dev)
+            ctr, labels = torch.zeros(B, cap, device=dev), torch.zeros(B, cap, dtype=torch.long, device=dev)
+            count = torch.zeros(B, dtype=torch.int32, device=dev)
+            ws = torch.empty(K.decode_ws_bytes(B, 5, 1000), dtype=torch.uint8, device=dev)
+            K.decode_candidates(fc, fr, fi, torch.ones(5, device=dev), ld, nl, B, 21, 0.05, 1000, hw, None, boxes, scores,
+                                ctr, labels, count, ws)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("RADET_DECODE_SLOW", None)
+        outs.append([t.cpu() for t in (count, boxes, scores, ctr, labels)])
+    n_pass = [[int((to_rows(c)[i * h * w:(i + 1) * h * w].sigmoid() > 0.05).sum()) for c, (h, w) in zip(cls, LEVEL_HW)]
+              for i in range(B)]
+    for i in range(B):
+        k = int(outs[0][0][i])
+        assert k == int(outs[1][0][i])
+        assert abs(k - sum(min(1000, n) for n in n_pass[i])) <= 2          # torch's sigmoid may differ by an ulp at 0.05
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert torch.equal(a[i, :k], b[i, :k])
+        s = outs[0][2][i, :k]
+        assert (s > 0.05).all()
+
+
 ASSIGN_TAGS = ["g0", "g1", "g8", "g8b", "g20", "g3"]
 
 

@@ -24,15 +24,22 @@ def build(depth=50):
 def infer(n_images=1000, B=8):
     cfg, det = build(50)
     det.eval()
-    # random-init heads never cross score_thr; shift the cls bias so ~2 % of the logits pass
-    with torch.no_grad():
-        det.bbox_head.atss_cls.bias += 2.6
+    # random-init heads never cross score_thr: shift the cls bias so that a fixed fraction of the cls logits passes
+    # ("a fixed bias so ~2 % of cls logits exceed score_thr"; `dense` = the crowded stress
+    # regime where every level saturates nms_pre and ~4400 candidates per image reach the NMS)
+    frac = float(os.environ.get("RADET_INFER_FRAC", "0.02"))
     rt = det.runtime()
     g = torch.Generator().manual_seed(0)
     imgs = torch.randn(B, 3, 480, 640, generator=g).cuda()
     metas = [dict(img_shape=(480, 640, 3), scale_factor=np.ones(4, np.float32)) for _ in range(B)]
+    rt.detect(imgs, metas, det.test_cfg, rescale=True)
+    with torch.no_grad():
+        logits = rt.engine.buf["cls"].flatten()
+        q = torch.quantile(logits[torch.randperm(logits.numel(), device=logits.device)[:2_000_000]].float(), 1.0 - frac)
+        det.bbox_head.atss_cls.bias += float(np.log(0.05 / 0.95)) - float(q)
     for _ in range(3):
         out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
+    passed = float((torch.sigmoid(rt.engine.buf["cls"]) > 0.05).float().mean())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ndet = 0
@@ -46,7 +53,8 @@ def infer(n_images=1000, B=8):
         c0 = int(rt._post["count"][0].item())
         print("label histogram img0:", torch.bincount(rt._post["labels"][0, :c0], minlength=21).tolist())
     print(f"config4 inference: {n_images / dt:.1f} images/sec, {ndet / dt:.0f} detections/sec "
-          f"(B={B}, {cand / B:.0f} candidates/img into vote-NMS, {ndet / (n_images // B * B):.0f} dets/img)")
+          f"(B={B}, {100 * passed:.1f} % of cls scores > 0.05, {cand / B:.0f} candidates/img into vote-NMS, "
+          f"{ndet / (n_images // B * B):.0f} dets/img)")
 
 
 def r101():

@@ -311,8 +311,32 @@ class Engine:
         self.max_cout = max(c.cout for c in self.convs)
 
     # ------------------------------------------------------------------ per-step parameter transforms
+    _fold_event = None
+
     def fold(self):
-        K.fold_weights(self.table, len(self.convs))
+        """W' = gamma*rstd*W (+ transposed copies) for every conv.  The leading frozen convs (stem, frozen stages) are
+        folded on the current stream; the trainable rest runs on the side stream, concurrently with the frozen part
+        of the forward pass, and `_await_fold()` joins it before the first trainable conv."""
+        n = len(self.convs)
+        nf = 0
+        while nf < n and not self.convs[nf].trainable:
+            nf += 1
+        if self.use_streams and 0 < nf < n and os.environ.get("RADET_FOLD_SIDE", "1") != "0":
+            side = self._side()
+            self._fork(side)
+            with torch.cuda.stream(side):
+                K.fold_weights(self.table[nf * C.sizeof(_lib.RadetConvDesc):], n - nf)
+                ev = self._event()
+                ev.record()
+            K.fold_weights(self.table, nf)
+            self._fold_event = ev
+        else:
+            K.fold_weights(self.table, n)
+
+    def _await_fold(self):
+        if self._fold_event is not None:
+            torch.cuda.current_stream().wait_event(self._fold_event)
+            self._fold_event = None
 
     def unfold(self):
         K.unfold_grads(self.table, len(self.convs), self.max_cout)
@@ -326,6 +350,8 @@ class Engine:
         x = b["pool"]
         outs = []
         for li, blocks in enumerate(self.stages):
+            if blocks[0]["train"]:
+                self._await_fold()            # trainable weights are being folded on the side stream
             for bi, blk in enumerate(blocks):
                 pfx = f"l{li + 1}.{bi}"
                 blk["x"] = x
@@ -343,6 +369,7 @@ class Engine:
         return outs  # C2..C5 row buffers
 
     def neck_forward(self, feats):
+        self._await_fold()
         b, B = self.buf, self.B
         c = feats[1:]
         for i in range(3):

@@ -530,20 +530,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// final per-channel reduce over chunks: dgamma[c], dbeta[c].  8 workgroups x (4 row groups x 64 columns)
-// over the [nchunks][2][256] partials, fixed summation order.
+// final per-channel reduce over chunks: dgamma[c], dbeta[c].  32 workgroups x (16 row groups x 16 columns) over the
+// [nchunks][2][256] partials, fixed summation order (8 workgroups x 4 row groups made a 100-step chain per thread on
+// the critical path of every tower layer's backward).
 __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ cpart, int nchunks,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);   // 0..511 = k*256 + c
-    const int rg = threadIdx.x >> 6;
+    const int lc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + lc;   // 0..511 = k*256 + c
     float a = 0.f;
-    for (int k = rg; k < nchunks; k += 4) a += cpart[(size_t)k * 512 + col];
-    __shared__ float red[4][64];
-    red[rg][threadIdx.x & 63] = a;
+    for (int k = rg; k < nchunks; k += 16) a += cpart[(size_t)k * 512 + col];
+    __shared__ float red[16][16];
+    red[rg][lc] = a;
     __syncthreads();
     if (rg == 0) {
-        const int c = threadIdx.x;
-        const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][lc];
         if (col < 256) dgamma[col] = v; else dbeta[col - 256] = v;
     }
 }
@@ -568,7 +570,7 @@ extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* s
                        segs, B, relu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
                        B, relu);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(8), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(32), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
 }
 

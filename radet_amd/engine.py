@@ -420,7 +420,14 @@ class Engine:
         if not self.use_streams:
             K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
             return None
+        # weight-gradient GEMMs are small grids (250-800 workgroups): alternate them between the side stream and a
+        # second one so that two run concurrently and fill each other's tails
         side = self._side()
+        if self.wgrad_streams > 1:
+            self._wg_i = getattr(self, "_wg_i", 0) + 1
+            if self._wg_i & 1:
+                side = self._side2()
+                self._side2_dirty = True
         self._fork(side)
         with torch.cuda.stream(side):
             K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
@@ -428,9 +435,27 @@ class Engine:
             ev.record()
         return ev   # completes when this weight-gradient GEMM has finished reading dy / x
 
+    wgrad_streams = int(os.environ.get("RADET_WGRAD_STREAMS", "2"))
+    _side2_dirty = False
+
+    def _side2(self):
+        if getattr(self, "_side2_stream", None) is None:
+            self._side()
+            self._side2_stream = torch.cuda.Stream(device=self.dev)
+        return self._side2_stream
+
+    def side_collect(self):
+        """Side stream waits for the wgrads issued on the second wgrad stream (call on the way to a slab reduction)."""
+        if self._side2_dirty:
+            ev = self._event()
+            ev.record(self._side2_stream)
+            self._side().wait_event(ev)
+            self._side2_dirty = False
+
     def join_side(self):
         """Current stream waits for all side-stream work (call before consuming wgrad slabs)."""
         if self.use_streams and getattr(self, "_side_stream", None) is not None:
+            self.side_collect()
             self._join(self._side_stream)
 
     def _tower_fwd_layer(self, t, tower, i, x, ws):

@@ -204,6 +204,7 @@ class DetectorRuntime:
                 # the slab reduction follows the bucket's weight-gradient GEMMs on the side stream, off the
                 # critical path of the dgrad chain; the all-reduce hook keys off the side stream too
                 side = e._side()
+                e.side_collect()
                 e._fork(side)
                 with torch.cuda.stream(side):
                     K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)

@@ -53,6 +53,9 @@ CONV_CASES = [
     (4, 2048, 512, 15, 20, 1, 1, 0),         # layer4 shape: heuristic picks split-K
     (4, 256, 256, 80, 80, 3, 1, 0x203),      # 1600 tiles: the 64 left-over tiles are split along K (tail split)
     (3, 128, 256, 40, 56, 3, 1, 2),          # 53 x 4 = 212... tiles with a ragged last M tile
+    (2, 256, 21, 48, 64, 3, 1, 0),           # predictor heads at M >= 4096: single-wave all-taps wgrad kernel
+    (2, 256, 4, 48, 66, 3, 1, 0),
+    (3, 256, 1, 40, 40, 3, 1, 0),
 ]
 
 

@@ -254,6 +254,7 @@ class Engine:
                 c.geom.math = self.math
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         if tune:
+            K.load_tune_cache()
             for c in self.convs:          # before the slabs are sized: this chooses the number of pixel splits
                 if c.trainable and c.geom is not None and c.cout > 64 and c.cin > 64:
                     K.autotune_wgrad(c.geom)
@@ -278,6 +279,7 @@ class Engine:
                 # the fp32 tower GEMM has a fixed, measured-best tile (TOWER_TAG); in bf16 math it is tuned like the rest
                 if c is not self.stem and c.geom is not None and (self.math or c not in towers):
                     K.autotune(c.geom, need_dgrad=c.need_dgrad)
+            K.save_tune_cache()
 
     def _build_table(self):
         n = len(self.convs)

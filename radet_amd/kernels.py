@@ -161,6 +161,33 @@ def _strided_dgrad_classes(g):
 
 
 _TUNE_CACHE = {}
+_TUNE_DIRTY = False
+
+
+def _tune_file():
+    return os.environ.get("RADET_TUNE_FILE")
+
+
+def load_tune_cache():
+    """RADET_TUNE_FILE=<path>: reuse the (tile, split) choices of an earlier run instead of timing the candidates again
+    (start-up cost, run-to-run identical summation orders, profiles without the tuning launches)."""
+    import pickle
+    f = _tune_file()
+    if f and os.path.exists(f) and not _TUNE_CACHE and not _WTUNE_CACHE:
+        with open(f, "rb") as fh:
+            a, b = pickle.load(fh)
+        _TUNE_CACHE.update(a)
+        _WTUNE_CACHE.update(b)
+
+
+def save_tune_cache():
+    import pickle
+    global _TUNE_DIRTY
+    f = _tune_file()
+    if f and _TUNE_DIRTY:
+        with open(f, "wb") as fh:
+            pickle.dump((_TUNE_CACHE, _WTUNE_CACHE), fh)
+        _TUNE_DIRTY = False
 
 
 def autotune(g, need_dgrad=True, reps=3):
@@ -200,8 +227,10 @@ def autotune(g, need_dgrad=True, reps=3):
                 out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
         return out
 
+    global _TUNE_DIRTY
     key = (g._key, g.cin, g.cout, g.math)
     if key not in _TUNE_CACHE:
+        _TUNE_DIRTY = True
         x = torch.randn(g.lin.rows, g.cin, device=dev)
         w = torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05
         y = torch.empty(g.lout.rows, g.cout, device=dev)
@@ -239,8 +268,10 @@ def autotune_wgrad(g, reps=3):
     split its downstream cost (a weight-sized slab is written here and read again by unfold: ~2 * 4 B / weight at
     ~3 TB/s).  Must run before the slab buffers are sized (it changes g.nsplit)."""
     dev = torch.device("cuda", torch.cuda.current_device())
+    global _TUNE_DIRTY
     key = (g._key, g.cin, g.cout, g.math, "w")
     if key not in _WTUNE_CACHE:
+        _TUNE_DIRTY = True
         M, kk = g.lout.rows, g.k * g.k
         s0 = g.nsplit
         cands = [(0, s0)]

@@ -102,6 +102,12 @@ class ConvGeom:
 _SPLITK_WS = {}
 
 
+def splitk_ws_for(stream):
+    """Create the split-K workspace of `stream` now (e.g. before a hipGraph capture on it)."""
+    with torch.cuda.stream(stream):
+        return splitk_ws()
+
+
 def splitk_ws():
     """One split-K workspace per (device, stream): launches on one stream are ordered, so all convs issued
     there can share it; concurrent streams get their own."""

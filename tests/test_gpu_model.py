@@ -189,3 +189,23 @@ def test_train_harness_and_checkpoint(golden, tmp_path):
     assert torch.equal(lo, ref_losses) and torch.equal(ro.flat.params, ref_params)
     res = inference_detector(other.eval(), batch["img"].cuda())
     assert len(res) == 2 and len(res[0]) == 21 and all(r.shape[1] == 5 for r in res[0])
+
+
+def test_detect_hipgraph_replay_matches_eager():
+    """rt.detect_graph captures fold + forward (two streams) + decode + the NMS pipeline in one hipGraph; replays with
+    new inputs must equal the eager path bit for bit."""
+    import numpy as np
+    det = make_det().eval()
+    rt = det.runtime()
+    with torch.no_grad():
+        det.bbox_head.atss_cls.bias += 2.0
+    metas = [dict(img_shape=(160, 192, 3), scale_factor=np.ones(4, np.float32)) for _ in range(2)]
+    g = torch.Generator().manual_seed(3)
+    for rep in range(3):
+        img = torch.randn(2, 3, 160, 192, generator=g).cuda()
+        a = rt.detect(img, metas, det.test_cfg, rescale=True)
+        b = rt.detect_graph(img, metas, det.test_cfg, rescale=True)
+        assert len(a) == len(b) == 2
+        for (da, la), (db, lb) in zip(a, b):
+            assert torch.equal(da, db) and torch.equal(la, lb)
+        assert sum(d.shape[0] for d, _ in a) > 0

@@ -41,7 +41,18 @@ struct ConvArgs {
     // tail split: tiles [0, n_full) run whole; the T % 256 left-over tiles (which would otherwise occupy a mostly
     // empty last round on the 256 CUs) are cut sk_tail ways along K, their partial tiles reduced by a second pass
     int n_full, sk_tail, it_per_tail;
+    // io = 0: fp32 tensors.  io = 1 / 2 (bf16 storage): x, w, addend, mask are bf16 and Cin counts PAIRS of channels
+    // (a 4-byte unit, so the loaders and LDS layouts are those of the fp32 kernel); y is bf16 (1) or fp32 (2)
+    int io;
 };
+
+__device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
+    return io ? (float)reinterpret_cast<const __bf16*>(p)[o] : p[o];
+}
+__device__ __forceinline__ void st_out(float* p, size_t o, float v, int io) {
+    if (io == 1) reinterpret_cast<__bf16*>(p)[o] = (__bf16)v;      // v_cvt_pk_bf16_f32: round to nearest even
+    else p[o] = v;
+}
 
 __device__ __attribute__((aligned(16))) float radet_zero_page[512];
 
@@ -141,10 +152,10 @@ __device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P
                 if (row >= a.M) continue;
                 const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
                 float v = acc[i][j][r] + bv;
-                if (P.addend) v += P.addend[o];
+                if (P.addend) v += ld_act(P.addend, o, a.io);
                 if (a.relu) v = fmaxf(v, 0.f);
-                if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
-                P.y[o] = v;
+                if (P.mask) v = ld_act(P.mask, o, a.io) > 0.f ? v : 0.f;
+                st_out(P.y, o, v, a.io);
             }
         }
 }
@@ -291,6 +302,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {    // one v_cvt_pk_bf16_f32 (RNE)
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
     constexpr int NS = BK / 8;
     constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
+    constexpr bool H16 = (TAG & 4) != 0;                      // bit 2: bf16 storage (a 16-byte slot = 8 bf16 = one MFMA operand)
     static_assert(WM * WN == 4, "4 waves");
     __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
@@ -463,7 +476,14 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
             for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[pp][i]));
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[pp][j]));
-            if constexpr (BF16) {
+            if constexpr (H16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pp][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[pp][j]), acc[i][j], 0, 0, 0);
+            } else if constexpr (BF16) {
                 s16x4 ab[TM], bb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) ab[i] = cvt_bf16x4(af[pp][i].x, af[pp][i].y, af[pp][i].z, af[pp][i].w);
@@ -506,10 +526,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) 
         const int col = (int)(o % a.Cout);
         const size_t oo = a.out_rows ? (size_t)a.out_rows[o / a.Cout] * a.Cout + col : o;
         if (a.p[0].bias) v += a.p[0].bias[col];
-        if (a.p[0].addend) v += a.p[0].addend[oo];
+        if (a.p[0].addend) v += ld_act(a.p[0].addend, oo, a.io);
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.p[0].mask) v = a.p[0].mask[oo] > 0.f ? v : 0.f;
-        a.p[0].y[oo] = v;
+        if (a.p[0].mask) v = ld_act(a.p[0].mask, oo, a.io) > 0.f ? v : 0.f;
+        st_out(a.p[0].y, oo, v, a.io);
     }
 }
 
@@ -531,10 +551,10 @@ __global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, in
         for (int z = 0; z < a.sk_tail; ++z) v += part[(size_t)z * BM * BN + e];
         const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
         if (P.bias) v += P.bias[col];
-        if (P.addend) v += P.addend[o];
+        if (P.addend) v += ld_act(P.addend, o, a.io);
         if (a.relu) v = fmaxf(v, 0.f);
-        if (P.mask) v = P.mask[o] > 0.f ? v : 0.f;
-        P.y[o] = v;
+        if (P.mask) v = ld_act(P.mask, o, a.io) > 0.f ? v : 0.f;
+        st_out(P.y, o, v, a.io);
     }
 }
 
@@ -1237,7 +1257,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
     static const bool regstage = getenv("RADET_IGEMM_REGSTAGE") != nullptr;
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
-    if (regstage && tag < 2) {
+    if (regstage && tag < 2 && a.io == 0) {
         if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
         else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 16); }
     } else {
@@ -1246,14 +1266,18 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
                 case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); break;
                 case 1: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 32); break;
                 case 2: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 2, 32); break;
-                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 32); break;
+                case 3: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 32); break;
+                case 4: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 4, 32); break;
+                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 5, 32); break;
             }
         } else {
             switch (tag) {
                 case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 16); break;
                 case 1: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 16); break;
                 case 2: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 2, 16); break;
-                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 16); break;
+                case 3: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 3, 16); break;
+                case 4: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 4, 16); break;
+                default: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 5, 16); break;
             }
         }
     }
@@ -1340,8 +1364,14 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
                       const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second) {
+    const int h16 = (tile_override >> 11) & 1;                 // 0x800: bf16 storage, 0x10000: fp32 output from bf16 inputs
+    if (h16) {
+        if (Cin % 32 != 0) return RADET_ERR_ARG;               // 16 channel pairs per K step at least
+        Cin /= 2;                                              // K is counted in channel pairs (4-byte units) from here on
+    }
     if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr || KH * KW > 16) return RADET_ERR_ARG;
     ConvArgs a;
+    a.io = h16 ? (((tile_override >> 16) & 1) ? 2 : 1) : 0;
     a.out_rows = out_rows;
     for (int t = 0; t < 16; ++t) a.tap_ids[t] = tap_ids ? (t < KH * KW ? tap_ids[t] : 0) : t;
     a.KTw = kt_w > 0 ? kt_w : KH * KW;
@@ -1355,7 +1385,8 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.M = M;
     a.Mp = radet_gather_table_rows(M);
     hipStream_t st = (hipStream_t)stream;
-    const int tag = ((tile_override >> 8) & 1) | (((tile_override >> 10) & 1) << 1);   // 0x100 symbol tag, 0x400 bf16 math
+    const int tag = h16 ? (4 | ((tile_override >> 8) & 1))
+                        : (((tile_override >> 8) & 1) | (((tile_override >> 10) & 1) << 1));   // 0x100 symbol tag, 0x400 bf16 math
     int bk = ((tile_override >> 9) & 1) ? 32 : 16;
     if (Cin % 32 != 0) bk = 16;
     int choice = tile_override & 0xFF;

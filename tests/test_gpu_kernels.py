@@ -108,6 +108,66 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
 
 
+H16_CASES = [
+    # B, Cin, Cout, H, W, k, stride, tile
+    (2, 256, 256, 30, 40, 3, 1, 1),
+    (2, 256, 256, 30, 40, 3, 1, 0x203),
+    (4, 256, 256, 80, 80, 3, 1, 0x203),      # tail split
+    (2, 64, 256, 20, 24, 1, 1, 0),
+    (1, 512, 512, 15, 20, 3, 1, 0x3003),     # forced split-K
+    (2, 128, 128, 18, 22, 3, 2, 0),          # strided (parity-class dgrad)
+    (1, 256, 21, 15, 20, 3, 1, 0),           # predictor head: fp32 output from bf16 inputs
+]
+
+
+@pytest.mark.parametrize("case", H16_CASES)
+def test_conv_bf16_storage(K, case):
+    """bf16-storage mode of the implicit-GEMM kernel (tile_override 0x800): bf16 activations / weights / residual /
+    mask in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 (or, +0x10000, fp32) output.  Reference = fp64
+    convolution of the same bf16 values; a bf16 output may differ from the rounded reference by one bf16 step where
+    the fp32 accumulation order moves the value across a rounding boundary."""
+    B, Cin, Cout, H, W, k, s, tile = case
+    g = torch.Generator().manual_seed(sum(case))
+    bf = torch.bfloat16
+    x = torch.randn(B, Cin, H, W, generator=g).to(bf)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(bf)
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    y_ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=pad)
+    Ho, Wo = y_ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g).to(bf)
+    out_ref = F.relu(y_ref + res.double())
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
+    small = Cout < 32
+    y = torch.empty(B * Ho * Wo, Cout, device=dev, dtype=torch.float32 if small else bf)
+    K.conv_fwd(geom, xr, wf, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True,
+               tile=tile | 0x800 | (0x10000 if small else 0))
+    got = from_rows(y.float(), B, Ho, Wo).double().cpu()
+    if small:
+        assert rel_err(got, out_ref) < 1e-5
+    else:
+        err = (got - out_ref).abs()
+        assert (err <= out_ref.abs() * 2.0 ** -7 + 1e-6).all(), float((err / out_ref.abs().clamp_min(1e-3)).max())
+        assert rel_err(got, out_ref) < 5e-3
+    if small:
+        return
+    # dgrad with ReLU mask, bf16 in / out
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).to(bf)
+    gx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride=s, padding=pad)
+    wft = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).contiguous().to(dev)
+    mask = to_rows(torch.randn(B, Cin, H, W, generator=g)).to(bf).to(dev)
+    dx = torch.empty(B * H * W, Cin, device=dev, dtype=bf)
+    K.conv_dgrad(geom, to_rows(dy).to(dev), wft, dx, mask=mask, tile=tile | 0x800)
+    gx_m = gx * (from_rows(mask.float().cpu(), B, H, W) > 0)
+    got = from_rows(dx.float(), B, H, W).double().cpu()
+    err = (got - gx_m).abs()
+    assert (err <= gx_m.abs() * 2.0 ** -7 + 1e-6).all()
+    assert rel_err(got, gx_m) < 5e-3
+
+
 def test_conv_multilevel(K):
     """Five pyramid levels in one launch == per-level convs."""
     B, Cch = 2, 256

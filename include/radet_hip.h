@@ -57,6 +57,7 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * dgrad: x = dy, w = wft (Cin/Cout swapped, dgrad table).
  * Epilogue: y = acc + bias[n] (+ addend[m,n]) ; relu ; then y = mask[m,n] > 0 ? y : 0.
  * tile_override: 0 = heuristic, 1..4 = tile config; +0x100 = tagged kernel symbol (profiling); +0x200 = K step 32;
+ * +0x800 = bf16 storage (x, w, addend, mask are bf16 tensors, Cin % 32 == 0; y bf16, or fp32 with +0x10000);
  * +0x400 = bf16 math mode (operands rounded RNE to bf16 between LDS and the matrix core, fp32 accumulate, fp32
  * tensors in HBM -- the arithmetic of mmcv's fp16 wrapper, `apis/train.py:113-117`, in bf16); bits 12-15 force
  * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats; when given, launches with too
@@ -80,7 +81,8 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bits 4-5: tile override of the one-tap
- * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel. */
+ * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel;
+ * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                        int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);

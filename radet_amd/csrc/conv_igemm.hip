@@ -1204,6 +1204,167 @@ __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, bf16 storage
+// dW[o, tap, c] = sum_m dy[m, o] * x[g(m, tap), c] with bf16 dy / x in HBM, v_mfma_f32_32x32x16_bf16, fp32 slabs.
+// The MFMA wants, per lane, 8 consecutive PIXELS (k) of one channel, but memory is [pixel][channel]: the tiles are
+// brought in by LDS-DMA as 128-byte sub-tiles of [4 pixels][16 channels] (lane -> source address is free, so the
+// image is built for the read), and the operands are fetched with gfx950's transposing LDS read
+// ds_read_b64_tr_b16: within a 16-lane group lane m supplies the address of sub-tile bytes 8m..8m+7 and receives
+// column m, i.e. 4 consecutive pixels of its channel; two reads = one MFMA operand (probed on the device:
+// tools/_probe, lane l <- elements (l&15) + 16 j + 64 (l>>4)).
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
+    constexpr int BP = 32, NW = 4;                          // pixels per stage (two K = 16 MFMA steps)
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int CBA = BM / 16, CBB = BN / 16;             // 16-channel sub-tile columns
+    constexpr int A_INSTR = BP * BM * 2 / 1024, B_INSTR = BP * BN * 2 / 1024;
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BP * BN];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int KT = a.KH * a.KW;
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = (a.Cin + BN - 1) / BN;
+    const int tilesPerSplit = tilesO * tilesC * KT;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO;
+    id /= tilesO;
+    const int tc = id % tilesC;
+    const int tap = id / tilesC;
+    const int o0 = to * BM, c0 = tc * BN;
+    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
+
+    const int p_begin = split * a.chunks_per_split * 16;    // chunks_per_split counts 16-pixel chunks
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    // writer side: lane -> (sub-tile, pixel row, 8-channel half) of every wave load it issues
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    int brow[PER_WAVE];                                     // gather rows of the NEXT stage (x-tile loads)
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int blk = bi * 8 + l_blk;
+            const int m = p_begin + 4 * (blk / CBB) + l_prow;
+            brow[k] = m < p_end ? tab_tap[m] : -1;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int blk = ins * 8 + l_blk;
+                const int m = p0 + 4 * (blk / CBA) + l_prow;
+                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+                const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
+                                                            : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+            } else if (ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int blk = bi * 8 + l_blk;
+                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
+                const void* src = (brow[k] >= 0 && c < a.Cin) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
+                                                              : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+                const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
+                brow[k] = m < p_end ? tab_tap[m] : -1;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
+
+    // reader side (per lane): 16-lane group g16 -> channel sub-tile, m -> bytes 8m of the sub-tile, lh -> pixel half
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    typedef __attribute__((address_space(3))) s16x4v* tr_ptr;
+
+    // the transposing read is not ordered against in-flight LDS-DMA by the compiler: every wave drains its own
+    // loads (vmcnt(0)) before the barrier that publishes the stage
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < BP / 16; ++ks) {
+            s16x8v af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int cb = (wm * TM + i) * 2 + g16;
+                const unsigned short* q = &As[buf][((4 * ks + 2 * lh) * CBA + cb) * 64 + m16 * 4];
+                const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)q);
+                const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(q + CBA * 64));
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cb = (wn * TN + j) * 2 + g16;
+                const unsigned short* q = &Bs[buf][((4 * ks + 2 * lh) * CBB + cb) * 64 + m16 * 4];
+                const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)q);
+                const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(q + CBB * 64));
+                bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                                        __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+        }
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order
+            const int cb = tid >> 4, cc = tid & 15;
+#pragma unroll
+            for (int p = 0; p < BP; ++p)
+                bsum += (float)reinterpret_cast<const __bf16*>(&As[buf][0])[((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + (wn * TN + j) * 32 + li;
+            if (c >= a.Cin) continue;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int o = o0 + (wm * TM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (o >= a.Cout) continue;
+                out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -1504,6 +1665,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || (ld_dy & 3) || ((Cout + 3) / 4) * 4 > ld_dy || M <= 0 ||
         gather_table == nullptr)
         return RADET_ERR_ARG;
+    if ((flags & 2) && ((Cout + 7) / 8) * 8 > ld_dy) return RADET_ERR_ARG;   // whole 8-channel groups per dy row
     WgradArgs a;
     a.ld_dy = ld_dy;
     a.dy = dy; a.x = x; a.slabs = slabs; a.dbias_partials = dbias_partials;
@@ -1517,6 +1679,18 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & 2) {   // bf16 storage: dy / x are bf16 (ld_dy, Cin in elements; 16-byte aligned rows)
+        if ((ld_dy & 7) || (Cin & 7)) return RADET_ERR_ARG;
+        int bm, bn;
+        wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
+        if (bm != 32 && ((flags >> 4) & 3) == 1) bm = bn = 128;
+        if (bm != 32 && ((flags >> 4) & 3) != 1) bm = bn = 64;
+        const int tiles = ((Cout + bm - 1) / bm) * ((Cin + bn - 1) / bn) * KH * KW * S;
+        if (bm == 32) hipLaunchKernelGGL((conv_wgradh_kernel<32, 128, 1, 4>), dim3(tiles), dim3(256), 0, st, a);
+        else if (bm == 64) hipLaunchKernelGGL((conv_wgradh_kernel<64, 64, 2, 2>), dim3(tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgradh_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0, st, a);
+        return radet_check_launch();
+    }
     if (use_wgrad9(M, Cin, Cout, KH, KW) && !(flags & 0x40) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;

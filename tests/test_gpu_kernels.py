@@ -168,6 +168,40 @@ def test_conv_bf16_storage(K, case):
     assert rel_err(got, gx_m) < 5e-3
 
 
+@pytest.mark.parametrize("case", [(2, 256, 256, 30, 40, 3, 1, 0), (1, 128, 512, 33, 21, 1, 1, 0), (2, 128, 128, 18, 22, 3, 2, 0),
+                                  (1, 256, 21, 15, 20, 3, 1, 0), (2, 512, 256, 16, 20, 1, 1, 1 << 4),
+                                  (4, 256, 256, 80, 80, 3, 1, 0)])
+def test_wgrad_bf16_storage(K, case):
+    """bf16-storage wgrad (flags bit 1): bf16 dy / x, transposing LDS reads, fp32 slabs == fp64 wgrad of the same
+    bf16 values (fp32 accumulation tolerance), incl. the fused bias column sums, ragged pixel counts, strided and
+    small-Cout cases."""
+    import ctypes as C
+    from radet_amd import _lib
+    B, Cin, Cout, H, W, k, s, wflags = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    bf = torch.bfloat16
+    x = torch.randn(B, Cin, H, W, generator=g).to(bf)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).to(bf)
+    gw = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), stride=s, padding=pad)
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    ld = (Cout + 7) // 8 * 8
+    dyr = torch.zeros(B * Ho * Wo, ld, device=dev, dtype=bf)
+    dyr[:, :Cout] = to_rows(dy).to(dev)
+    S = geom.nsplit
+    slabs = torch.empty(S, Cout, k * k, Cin, device=dev)
+    bp = torch.empty(S, Cout, device=dev)
+    xr = to_rows(x).to(dev)        # keep alive: a temporary would be freed (and its block reused) before the launch
+    _lib.call("radet_conv2d_wgrad", K._ptr(dyr), K._ptr(xr), K._ptr(slabs), K._ptr(bp), K._ptr(geom.fwd_table),
+              geom.lout.rows, Cin, Cout, ld, k, k, S, 2 | wflags, K._stream())
+    gw_mine = slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert rel_err(gw_mine, gw) < 2e-5
+    assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
+
+
 def test_conv_multilevel(K):
     """Five pyramid levels in one launch == per-level convs."""
     B, Cch = 2, 256

@@ -44,6 +44,7 @@ typedef struct RadetConvDesc {
     float eps;
     int wft_ld;            /* row stride of wft's last dim (>= Cout; zero-padded K for small heads), 0 = Cout */
     int wft_off;           /* column offset inside that padded row */
+    int w16;               /* 1: wf / wft are bf16 buffers (bf16-storage mode); bias_f stays fp32 */
 } RadetConvDesc;
 
 /* Gather table of one conv geometry: table[tap][Mp] = input row feeding (output row m, tap) or -1 (padding /
@@ -107,6 +108,21 @@ int radet_upsample_add(float* dst, const float* src, int B, int Ho, int Wo, int 
 int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
 /* ReLU backward for a junction with no producing GEMM: dx = (dy + addend?) * [act > 0]; n % 4 == 0 */
 int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream);
+/* bf16-storage variants (activation tensors are bf16; parameters, statistics and workspaces stay fp32) and the row
+ * converter used at the fp32 boundaries (loss gradients, module outputs) */
+int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_ohwi, const float* bias, void* y_nhwc, int B, int H,
+                              int W, void* stream);
+int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int radet_gn_relu_fwd_h(const void* z, const float* gamma, const float* beta, void* y, float* stats, float* partial_ws,
+                        int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg, void* stream);
+int radet_gn_relu_bwd_h(const void* dy, const void* z, const float* stats, const float* gamma, const float* beta, void* dz,
+                        float* dgamma, float* dbeta, float* partial_ws, int B, int C, int groups, int relu,
+                        const int* seg_desc, int nseg, void* stream);
+int radet_upsample_add_h(void* dst, const void* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
+int radet_upsample_add_bwd_h(void* dsrc, const void* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream);
+int radet_relu_bwd_h(const void* dy, const void* addend, const void* act, void* dx, size_t n, void* stream);
+int radet_convert_rows(const void* src, void* dst, size_t rows, int ncols, int src_ld, int src_off, int dst_ld,
+                       int dst_off, int to_bf16, void* stream);
 int radet_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int radet_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream);
 

@@ -22,7 +22,7 @@ class RadetConvDesc(C.Structure):
                 ("wf", _p), ("wft", _p), ("bias_f", _p), ("dwf_slabs", _p), ("dbias_partials", _p),
                 ("dw", _p), ("dbias", _p), ("dgamma", _p), ("dbeta", _p),
                 ("cout", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("nsplit", _i), ("eps", _f),
-                ("wft_ld", _i), ("wft_off", _i)]
+                ("wft_ld", _i), ("wft_off", _i), ("w16", _i)]
 
 
 # name -> (restype, argtypes); must list every function of include/radet_hip.h
@@ -56,6 +56,14 @@ SIGNATURES = {
     "radet_nms": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "radet_assign_ws_bytes": (_sz, [_i, _i]),
     "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_stem_conv_bn_relu_h": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "radet_maxpool3x3s2_h": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "radet_gn_relu_fwd_h": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_bwd_h": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "radet_upsample_add_h": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_upsample_add_bwd_h": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_relu_bwd_h": (_i, [_p, _p, _p, _p, _sz, _p]),
+    "radet_convert_rows": (_i, [_p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "radet_mask_max": (_i, [_p, _p, _i, _sz, _p]),
     "radet_mask_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_grid_anchors": (_i, [_p, _p, _i, _i, _p]),

@@ -56,3 +56,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + k;
 }
+
+// ---- activation element access, fp32 or bf16 storage (4 consecutive elements per call; i4 = index of the group)
+typedef float rd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned radet_pack_bf16(float lo, float hi) {          // v_cvt_pk_bf16_f32, round to nearest even
+    const rd_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rd_bf16x2));
+}
+template <class T> __device__ __forceinline__ float4 ld4(const T* p, size_t i4);
+template <> __device__ __forceinline__ float4 ld4<float>(const float* p, size_t i4) {
+    return reinterpret_cast<const float4*>(p)[i4];
+}
+template <> __device__ __forceinline__ float4 ld4<__bf16>(const __bf16* p, size_t i4) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[i4];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xFFFF0000u));
+}
+template <class T> __device__ __forceinline__ void st4(T* p, size_t i4, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, size_t i4, float4 v) {
+    reinterpret_cast<float4*>(p)[i4] = v;
+}
+template <> __device__ __forceinline__ void st4<__bf16>(__bf16* p, size_t i4, float4 v) {
+    reinterpret_cast<uint2*>(p)[i4] = make_uint2(radet_pack_bf16(v.x, v.y), radet_pack_bf16(v.z, v.w));
+}

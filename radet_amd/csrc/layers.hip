@@ -10,8 +10,9 @@
 // ------------------------------------------------------------------------------------------ stem
 // One block = 16x16 output pixels of one image; each thread owns one output pixel and all 64
 // output channels (64 fp32 accumulators).  Input patch (37x37x3) and weights (147x64) sit in LDS.
+template <class T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wf,
-                                                   const float* __restrict__ bias, float* __restrict__ y, int H,
+                                                   const float* __restrict__ bias, T* __restrict__ y, int H,
                                                    int W, int Ho, int Wo) {
     constexpr int TO = 16, TI = 2 * TO + 5;  // 37
     __shared__ float sw[147 * 64];           // [tap*3+c][o]
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
             }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy < Ho && ox < Wo) {
-        float4* dst = reinterpret_cast<float4*>(y + ((size_t)(n * Ho + oy) * Wo + ox) * 64);
+        const size_t dst4 = ((size_t)(n * Ho + oy) * Wo + ox) * 16;
 #pragma unroll
         for (int o4 = 0; o4 < 16; ++o4) {
             float4 v;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
             v.y = fmaxf(acc[o4 * 4 + 1] + bias[o4 * 4 + 1], 0.f);
             v.z = fmaxf(acc[o4 * 4 + 2] + bias[o4 * 4 + 2], 0.f);
             v.w = fmaxf(acc[o4 * 4 + 3] + bias[o4 * 4 + 3], 0.f);
-            dst[o4] = v;
+            st4(y, dst4 + o4, v);
         }
     }
 }
@@ -73,13 +74,23 @@ extern "C" int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_oh
                                        int B, int H, int W, void* stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B);
-    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, (hipStream_t)stream, img_nchw, wf_ohwi, bias, y_nhwc, H, W, Ho,
-                       Wo);
+    hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img_nchw, wf_ohwi, bias, y_nhwc, H, W,
+                       Ho, Wo);
+    return radet_check_launch();
+}
+
+extern "C" int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_ohwi, const float* bias, void* y_nhwc,
+                                         int B, int H, int W, void* stream) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    dim3 grid((Wo + 15) / 16, (Ho + 15) / 16, B);
+    hipLaunchKernelGGL(stem_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, img_nchw, wf_ohwi, bias,
+                       (__bf16*)y_nhwc, H, W, Ho, Wo);
     return radet_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------ maxpool
-__global__ void maxpool_kernel(const float4* __restrict__ x, float4* __restrict__ y, int B, int H, int W, int C4,
+template <class T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C4,
                                int Ho, int Wo) {
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -98,11 +109,11 @@ __global__ void maxpool_kernel(const float4* __restrict__ x, float4* __restrict_
             for (int q = 0; q < 3; ++q) {
                 const int ix = ox * 2 - 1 + q;
                 if (ix < 0 || ix >= W) continue;
-                const float4 v = x[((size_t)(n * H + iy) * W + ix) * C4 + c];
+                const float4 v = ld4(x, ((size_t)(n * H + iy) * W + ix) * C4 + c);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        y[i] = m;
+        st4(y, i, m);
     }
 }
 
@@ -111,8 +122,17 @@ extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W,
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, B,
-                       H, W, C / 4, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4, Ho, Wo);
+    return radet_check_launch();
+}
+
+extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y,
+                       B, H, W, C / 4, Ho, Wo);
     return radet_check_launch();
 }
 
@@ -123,6 +143,10 @@ extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W,
 // transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
 #define FOLD_TO 16
 #define FOLD_TC 32
+__device__ __forceinline__ void stw(float* p, size_t i, float v, int w16) {     // folded weight store, fp32 or bf16
+    if (w16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    else p[i] = v;
+}
 __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
     const int KT = d.kh * d.kw;
@@ -139,8 +163,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             float s = 1.f;
             if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
             const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
-            d.wf[i] = v;
-            if (d.wft) d.wft[((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o] = v;
+            stw(d.wf, i, v, d.w16);
+            if (d.wft) stw(d.wft, ((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o, v, d.w16);
         }
     } else {
         const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + FOLD_TC - 1) / FOLD_TC;
@@ -165,14 +189,14 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             for (int i = tid; i < no * run; i += 256) {
                 const int oo = i / run, r = i - oo * run;
                 const int t = r / nc, cl = r - t * nc;
-                d.wf[((size_t)(o0 + oo) * KT + t) * d.cin + c0 + cl] = tile[oo][cl * KT + t] * ssc[oo];
+                stw(d.wf, ((size_t)(o0 + oo) * KT + t) * d.cin + c0 + cl, tile[oo][cl * KT + t] * ssc[oo], d.w16);
             }
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
                 for (int i = tid; i < no * run; i += 256) {
                     const int oo = i % no, r = i / no;      // r = cl*KT + t
                     const int cl = r / KT, t = r - cl * KT;
-                    d.wft[((size_t)(c0 + cl) * KT + t) * ld_t + d.wft_off + o0 + oo] = tile[oo][r] * ssc[oo];
+                    stw(d.wft, ((size_t)(c0 + cl) * KT + t) * ld_t + d.wft_off + o0 + oo, tile[oo][r] * ssc[oo], d.w16);
                 }
             }
         }
@@ -303,14 +327,15 @@ static int gn_total_chunks(const RadetSegs& segs, int B) {
 }
 
 // partial[chunk][32 groups][2] = (sum, sumsq) over the chunk's pixels x 8 channels
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ z, float* __restrict__ partial,
+template <class T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ z, float* __restrict__ partial,
                                                        const RadetSegs segs, int B) {
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     const int col = tid & 63, prow = tid >> 6;
     float s = 0.f, ss = 0.f;
     for (int p = prow; p < c.npix; p += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(z + (size_t)(c.row0 + p) * 256 + col * 4);
+        const float4 v = ld4(z, (size_t)(c.row0 + p) * 64 + col);
         s += (v.x + v.y) + (v.z + v.w);
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
@@ -351,9 +376,10 @@ __device__ __forceinline__ void gn_reduce_partials(const float* __restrict__ par
 }
 
 // y = relu?((z - mean) * rstd * gamma + beta); the chunk-0 block of each image also publishes (mean, rstd)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ z, const float* __restrict__ partial,
+template <class T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ z, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float* __restrict__ y, float* __restrict__ stats,
+                                                       T* __restrict__ y, float* __restrict__ stats,
                                                        const RadetSegs segs, int B, float eps, int relu) {
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
@@ -376,15 +402,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
     const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
     for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
-        const float4 v = *reinterpret_cast<const float4*>(z + o);
+        const size_t o = (size_t)(c.row0 + p) * 64 + col;
+        const float4 v = ld4(z, o);
         float4 r;
         r.x = (v.x - mean) * rstd * gm.x + bt.x;
         r.y = (v.y - mean) * rstd * gm.y + bt.y;
         r.z = (v.z - mean) * rstd * gm.z + bt.z;
         r.w = (v.w - mean) * rstd * gm.w + bt.w;
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-        *reinterpret_cast<float4*>(y + o) = r;
+        st4(y, o, r);
     }
     if (c.chunk_in_img == 0 && tid < 32) {
         // stats layout: [(seg, n)][32][2]; (seg, n) linear id = sum_{l<seg} B + n
@@ -395,9 +421,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
-extern "C" int radet_gn_relu_fwd(const float* z, const float* gamma, const float* beta, float* y, float* stats,
-                                 float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
-                                 int nseg, void* stream) {
+template <class T>
+static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T* y, float* stats,
+                            float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                            int nseg, void* stream) {
     if (C != 256 || groups != 32) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
@@ -409,10 +436,23 @@ extern "C" int radet_gn_relu_fwd(const float* z, const float* gamma, const float
     }
     const int chunks = gn_total_chunks(segs, B);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks), dim3(256), 0, st, z, partial_ws, segs, B);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks), dim3(256), 0, st, z, partial_ws, gamma, beta, y, stats, segs, B,
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, z, partial_ws, segs, B);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, z, partial_ws, gamma, beta, y, stats, segs, B,
                        eps, relu);
     return radet_check_launch();
+}
+
+extern "C" int radet_gn_relu_fwd(const float* z, const float* gamma, const float* beta, float* y, float* stats,
+                                 float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                                 int nseg, void* stream) {
+    return gn_relu_fwd_impl<float>(z, gamma, beta, y, stats, partial_ws, B, C, groups, eps, relu, seg_desc, nseg, stream);
+}
+
+extern "C" int radet_gn_relu_fwd_h(const void* z, const float* gamma, const float* beta, void* y, float* stats,
+                                   float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                                   int nseg, void* stream) {
+    return gn_relu_fwd_impl<__bf16>((const __bf16*)z, gamma, beta, (__bf16*)y, stats, partial_ws, B, C, groups, eps, relu,
+                                    seg_desc, nseg, stream);
 }
 
 extern "C" int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg) {
@@ -423,7 +463,8 @@ extern "C" int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg) {
 
 // backward pass 1: g = dy * [y > 0] (y recomputed);  per chunk: group sums (sum g*gamma, sum g*gamma*xhat),
 // channel sums (sum g*xhat -> dgamma, sum g -> dbeta)
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ gpart,
@@ -442,9 +483,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     float s1 = 0.f, s2 = 0.f;
     float4 cg = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
-        const float4 v = *reinterpret_cast<const float4*>(z + o);
-        float4 d = *reinterpret_cast<const float4*>(dy + o);
+        const size_t o = (size_t)(c.row0 + p) * 64 + col;
+        const float4 v = ld4(z, o);
+        float4 d = ld4(dy, o);
         float4 xh;
         xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
         if (relu) {
@@ -483,11 +524,12 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 // backward pass 2: dz = rstd * (g*gamma - m1 - xhat*m2), m1/m2 = group means of g*gamma, g*gamma*xhat
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+template <class T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const float* __restrict__ gpart, float* __restrict__ dz,
+                                                           const float* __restrict__ gpart, T* __restrict__ dz,
                                                            const RadetSegs segs, int B, int relu) {
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
@@ -510,9 +552,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
     const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
     for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 256 + col * 4;
-        const float4 v = *reinterpret_cast<const float4*>(z + o);
-        float4 d = *reinterpret_cast<const float4*>(dy + o);
+        const size_t o = (size_t)(c.row0 + p) * 64 + col;
+        const float4 v = ld4(z, o);
+        float4 d = ld4(dy, o);
         float4 xh;
         xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
         if (relu) {
@@ -526,7 +568,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         r.y = rstd * (d.y * gm.y - m1 - xh.y * m2);
         r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
         r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
-        *reinterpret_cast<float4*>(dz + o) = r;
+        st4(dz, o, r);
     }
 }
 
@@ -550,9 +592,10 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
     }
 }
 
-extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* stats, const float* gamma,
-                                 const float* beta, float* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
-                                 int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
+template <class T>
+static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const float* gamma,
+                            const float* beta, T* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
+                            int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
     if (C != 256 || groups != 32) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
@@ -566,12 +609,26 @@ extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* s
     float* gpart = partial_ws;
     float* cpart = partial_ws + (size_t)chunks * 64;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
                        segs, B, relu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
                        B, relu);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(32), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
+}
+
+extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* stats, const float* gamma,
+                                 const float* beta, float* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
+                                 int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
+    return gn_relu_bwd_impl<float>(dy, z, stats, gamma, beta, dz, dgamma, dbeta, partial_ws, B, C, groups, relu, seg_desc,
+                                   nseg, stream);
+}
+
+extern "C" int radet_gn_relu_bwd_h(const void* dy, const void* z, const float* stats, const float* gamma,
+                                   const float* beta, void* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
+                                   int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
+    return gn_relu_bwd_impl<__bf16>((const __bf16*)dy, (const __bf16*)z, stats, gamma, beta, (__bf16*)dz, dgamma, dbeta,
+                                    partial_ws, B, C, groups, relu, seg_desc, nseg, stream);
 }
 
 // ------------------------------------------------------------------------------------------ upsample-add
@@ -581,7 +638,8 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
 }
 
 // dst[n, oy, ox, :] += src[n, nearest(oy), nearest(ox), :]      (F.interpolate(mode='nearest', size=...))
-__global__ void upsample_add_kernel(float4* __restrict__ dst, const float4* __restrict__ src, int B, int Ho, int Wo,
+template <class T>
+__global__ void upsample_add_kernel(T* __restrict__ dst, const T* __restrict__ src, int B, int Ho, int Wo,
                                     int Hi, int Wi, int C4, float sy, float sx) {
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -592,15 +650,16 @@ __global__ void upsample_add_kernel(float4* __restrict__ dst, const float4* __re
         const int oy = (int)(p % Ho);
         const int n = (int)(p / Ho);
         const int iy = nearest_src(oy, sy, Hi), ix = nearest_src(ox, sx, Wi);
-        const float4 s = src[((size_t)(n * Hi + iy) * Wi + ix) * C4 + c];
-        float4 d = dst[i];
+        const float4 s = ld4(src, ((size_t)(n * Hi + iy) * Wi + ix) * C4 + c);
+        float4 d = ld4(dst, i);
         d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
-        dst[i] = d;
+        st4(dst, i, d);
     }
 }
 
 // dsrc[n, iy, ix, :] += sum over dst pixels that read (iy, ix)
-__global__ void upsample_add_bwd_kernel(float4* __restrict__ dsrc, const float4* __restrict__ ddst, int B, int Ho,
+template <class T>
+__global__ void upsample_add_bwd_kernel(T* __restrict__ dsrc, const T* __restrict__ ddst, int B, int Ho,
                                         int Wo, int Hi, int Wi, int C4, float sy, float sx) {
     const size_t total = (size_t)B * Hi * Wi * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -612,16 +671,16 @@ __global__ void upsample_add_bwd_kernel(float4* __restrict__ dsrc, const float4*
         const int n = (int)(p / Hi);
         const int oy_lo = max(0, (int)((float)iy / sy) - 2), oy_hi = min(Ho - 1, (int)((float)(iy + 1) / sy) + 2);
         const int ox_lo = max(0, (int)((float)ix / sx) - 2), ox_hi = min(Wo - 1, (int)((float)(ix + 1) / sx) + 2);
-        float4 a = dsrc[i];
+        float4 a = ld4(dsrc, i);
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
             if (nearest_src(oy, sy, Hi) != iy) continue;
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
                 if (nearest_src(ox, sx, Wi) != ix) continue;
-                const float4 d = ddst[((size_t)(n * Ho + oy) * Wo + ox) * C4 + c];
+                const float4 d = ld4(ddst, ((size_t)(n * Ho + oy) * Wo + ox) * C4 + c);
                 a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
             }
         }
-        dsrc[i] = a;
+        st4(dsrc, i, a);
     }
 }
 
@@ -630,8 +689,17 @@ extern "C" int radet_upsample_add(float* dst, const float* src, int B, int Ho, i
     if (C % 4) return RADET_ERR_ARG;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dst,
-                       (const float4*)src, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, B, Ho, Wo, Hi,
+                       Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return radet_check_launch();
+}
+
+extern "C" int radet_upsample_add_h(void* dst, const void* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample_add_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (__bf16*)dst,
+                       (const __bf16*)src, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
     return radet_check_launch();
 }
 
@@ -640,29 +708,74 @@ extern "C" int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int
     if (C % 4) return RADET_ERR_ARG;
     const size_t total = (size_t)B * Hi * Wi * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)dsrc,
-                       (const float4*)ddst, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dsrc, ddst, B, Ho,
+                       Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return radet_check_launch();
+}
+
+extern "C" int radet_upsample_add_bwd_h(void* dsrc, const void* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                        void* stream) {
+    if (C % 4) return RADET_ERR_ARG;
+    const size_t total = (size_t)B * Hi * Wi * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(upsample_add_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (__bf16*)dsrc,
+                       (const __bf16*)ddst, B, Ho, Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
     return radet_check_launch();
 }
 
 // ------------------------------------------------------------------------------------------ relu backward
 // dx = (dy (+ addend)) * [act > 0]
-__global__ void relu_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ addend,
-                                const float4* __restrict__ act, float4* __restrict__ dx, size_t n4) {
+template <class T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ addend,
+                                const T* __restrict__ act, T* __restrict__ dx, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = dy[i];
-        if (addend) { const float4 a = addend[i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-        const float4 m = act[i];
+        float4 v = ld4(dy, i);
+        if (addend) { const float4 a = ld4(addend, i); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        const float4 m = ld4(act, i);
         v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-        dx[i] = v;
+        st4(dx, i, v);
     }
 }
 extern "C" int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream) {
     if (n % 4) return RADET_ERR_ARG;
     const size_t n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)dy,
-                       (const float4*)addend, (const float4*)act, (float4*)dx, n4);
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, addend, act, dx, n4);
+    return radet_check_launch();
+}
+extern "C" int radet_relu_bwd_h(const void* dy, const void* addend, const void* act, void* dx, size_t n, void* stream) {
+    if (n % 4) return RADET_ERR_ARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(relu_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy,
+                       (const __bf16*)addend, (const __bf16*)act, (__bf16*)dx, n4);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ fp32 <-> bf16 rows
+// dst[r][dst_off + c] = src[r][src_off + c] for c < ncols (row strides in elements); used at the fp32 boundaries of the
+// bf16-storage mode (loss gradients -> bf16 dgrad / wgrad inputs, bf16 features -> fp32 module outputs)
+template <class TS, class TD>
+__global__ void convert_rows_kernel(const TS* __restrict__ src, TD* __restrict__ dst, size_t rows, int ncols, int src_ld,
+                                    int src_off, int dst_ld, int dst_off) {
+    const size_t total = rows * (size_t)ncols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / ncols;
+        const int c = (int)(i - r * ncols);
+        dst[r * dst_ld + dst_off + c] = (TD)(float)src[r * src_ld + src_off + c];
+    }
+}
+extern "C" int radet_convert_rows(const void* src, void* dst, size_t rows, int ncols, int src_ld, int src_off, int dst_ld,
+                                  int dst_off, int to_bf16, void* stream) {
+    if (rows == 0 || ncols <= 0) return RADET_OK;
+    const size_t total = rows * (size_t)ncols;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (to_bf16)
+        hipLaunchKernelGGL((convert_rows_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)src, (__bf16*)dst, rows, ncols, src_ld, src_off, dst_ld, dst_off);
+    else
+        hipLaunchKernelGGL((convert_rows_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)src, (float*)dst, rows, ncols, src_ld, src_off, dst_ld, dst_off);
     return radet_check_launch();
 }
 

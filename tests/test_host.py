@@ -30,7 +30,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/radet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
     _lib.load()
-    assert ctypes.sizeof(_lib.RadetConvDesc) == 15 * 8 + 8 * 4     # 15 pointers + 8 32-bit fields
+    assert ctypes.sizeof(_lib.RadetConvDesc) == 160                 # 15 pointers + 9 32-bit fields, padded to 8
 
 
 def test_host_only_entry_points():

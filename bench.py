@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--math", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--math", choices=("fp32", "bf16", "bf16-storage"), default="fp32",
                     help="fp32 = the headline metric (BASELINE configs[1]); bf16 = configs[2] arithmetic: conv operands "
                          "rounded to bf16 into the matrix cores, fp32 accumulate / storage / optimizer (secondary line)")
     args = ap.parse_args()
@@ -184,7 +184,8 @@ def main():
             "metric": "images/sec train-step, r50_ycbv_pbr 640x480 bs=4/GPU",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.math == "fp32" else "bf16 operands, f32 accumulate (f32 tensors in HBM)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)",
+                      "bf16-storage": "bf16 tensors + operands, f32 accumulate / loss / optimizer"}[args.math], "data": "synthetic",
             "config": {"workload": "r50_ycbv_pbr bs=4 fp32 forward+loss+backward+allreduce+clip+AdamW (BASELINE configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "image": f"{IMG_W}x{IMG_H}",
                        "parallelism": f"dp{world}", "losses": [float(x) for x in losses],

@@ -55,8 +55,14 @@ class Engine:
         their way into the matrix cores, fp32 accumulate, fp32 tensors / GroupNorm / loss / optimizer (the mixed
         precision of BASELINE config 3; env RADET_MATH)."""
         math = math or os.environ.get("RADET_MATH", "fp32")
-        assert math in ("fp32", "bf16"), math
+        assert math in ("fp32", "bf16", "bf16-storage"), math
         self.math = 1 if math == "bf16" else 0
+        # "bf16-storage": activations, folded weights and activation gradients are bf16 tensors in HBM
+        # (v_mfma_f32_32x32x16_bf16, fp32 accumulate); head outputs, loss, statistics, weight gradients, master
+        # weights and optimizer stay fp32
+        self.h16 = math == "bf16-storage"
+        self.math_name = math
+        self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
         self.depth, self.num_classes, self.frozen_stages = depth, num_classes, frozen_stages
         self.strides, self.stacked_convs, self.feat = tuple(strides), stacked_convs, feat
@@ -131,27 +137,31 @@ class Engine:
         self.pred_reg = self._add(Conv("bbox_head.atss_reg", f, 4, 3, 1, 1, bias=True))
         self.pred_iou = self._add(Conv("bbox_head.atss_centerness", f, 1, 3, 1, 1, bias=True))
         # dgrad of the small predictors runs on zero-padded K (GEMM K must be a multiple of 16)
-        self.cls_pad = ((self.num_classes + 15) // 16) * 16
+        kq = 32 if self.h16 else 16           # bf16 storage: K in 32-channel steps, 16-byte aligned dy columns
+        self.cls_pad = ((self.num_classes + kq - 1) // kq) * kq
+        self.ri_pad = kq                      # reg (cols 0-3) + iou share one padded gradient buffer
+        self.iou_col = 8 if self.h16 else 4
         self.pred_cls.wft_ld, self.pred_cls.wft_off = self.cls_pad, 0
-        self.pred_reg.wft_ld, self.pred_reg.wft_off = 16, 0
-        self.pred_iou.wft_ld, self.pred_iou.wft_off = 16, 4
+        self.pred_reg.wft_ld, self.pred_reg.wft_off = self.ri_pad, 0
+        self.pred_iou.wft_ld, self.pred_iou.wft_off = self.ri_pad, self.iou_col
         self.pred_iou.wft_shared = self.pred_reg
 
     def _alloc_folded(self):
         dev = self.dev
         n_wf = sum(c.wsize for c in self.convs)
         n_b = sum(c.cout for c in self.convs)
-        self.wf_arena = torch.zeros(n_wf, device=dev)
+        self.wf_arena = torch.zeros(n_wf, device=dev, dtype=self.act_dtype)
+        self.stem_wf = torch.zeros(self.convs[0].wsize, device=dev)      # the (VALU) stem kernel always reads fp32 weights
         self.bias_arena = torch.zeros(n_b, device=dev)
         n_wft = 0
         for c in self.convs:
             if c.need_dgrad and c.wft_shared is None:
                 ld = c.wft_ld or c.cout
                 n_wft += c.cin * c.k * c.k * ld
-        self.wft_arena = torch.zeros(n_wft, device=dev)
+        self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
         o_w = o_b = o_t = 0
         for c in self.convs:
-            c.wf = self.wf_arena[o_w:o_w + c.wsize]
+            c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
             c.bias_f = self.bias_arena[o_b:o_b + c.cout]
             o_b += c.cout
@@ -176,8 +186,8 @@ class Engine:
         self.stem_hw, self.pool_hw = (h1, w1), (h2, w2)
         self.buf = {}
 
-        def new(name, rows, ch):
-            t = torch.empty(rows, ch, device=dev)
+        def new(name, rows, ch, dtype=None):
+            t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)
             self.buf[name] = t
             return t
 
@@ -238,11 +248,14 @@ class Engine:
             c.geom = ConvGeom(self.plv, f, f, 3, 1, 1)
         for c in (self.pred_cls, self.pred_reg, self.pred_iou):
             c.geom = ConvGeom(self.plv, f, c.cout, 3, 1, 1)
-        new("cls", R, self.num_classes)
-        new("reg_u", R, 4)
-        new("iou", R, 1)
+        new("cls", R, self.num_classes, torch.float32)       # head outputs / their gradients: fp32 (loss is fp32)
+        new("reg_u", R, 4, torch.float32)
+        new("iou", R, 1, torch.float32)
         self.buf["dcls"] = torch.zeros(R, self.cls_pad, device=dev)
         self.buf["dregiou"] = torch.zeros(R, 16, device=dev)
+        if self.h16:                                         # bf16 copies consumed by the predictors' dgrad / wgrad
+            self.buf["dcls16"] = torch.zeros(R, self.cls_pad, device=dev, dtype=torch.bfloat16)
+            self.buf["dregiou16"] = torch.zeros(R, self.ri_pad, device=dev, dtype=torch.bfloat16)
         self.gn_ws = torch.empty(K.gn_ws_floats(self.plv), device=dev)
         self.gn_ws2 = torch.empty(K.gn_ws_floats(self.plv), device=dev)
         self.ldesc, self.nlvl = K.level_desc(self.plv, self.strides)
@@ -252,6 +265,7 @@ class Engine:
         for c in self.convs:
             if c.geom is not None:
                 c.geom.math = self.math
+                c.geom.h16 = self.h16
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         if tune:
             K.load_tune_cache()
@@ -299,6 +313,7 @@ class Engine:
             d.cout, d.cin, d.kh, d.kw = c.cout, c.cin, c.k, c.k
             d.eps = 1e-5
             d.wft_ld, d.wft_off = c.wft_ld, c.wft_off
+            d.w16 = 1 if (self.h16 and c is not self.stem) else 0
             d.nsplit = c.geom.nsplit if c.geom is not None else 1
             if c.trainable and c.geom is not None:
                 d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
@@ -545,7 +560,15 @@ class Engine:
         K.head_loss(b["cls"], b["reg_u"], b["iou"], self.scales_tensor(), gt_boxes, gt_labels, gt_off, p2g, pw, self.ldesc,
                     self.nlvl, self.B, self.num_classes, alpha, gamma, lbw, 1e-6, grad_scale, self.losses, b["dcls"],
                     self.cls_pad, dri, 16, dri.view(-1)[4:], 16, self.dscales, self.loss_ws, labels_out, tgt_out)
+        if self.h16:      # the predictors' dgrad / wgrad read bf16: reg -> cols 0-3, iou -> col 8 (16-byte aligned)
+            K.convert_rows(b["dcls"], b["dcls16"])
+            K.convert_rows(dri, b["dregiou16"], ncols=4)
+            K.convert_rows(dri, b["dregiou16"], ncols=1, src_off=4, dst_off=self.iou_col)
         return self.losses
+
+    def _head_grads(self):
+        b = self.buf
+        return (b["dcls16"], b["dregiou16"]) if self.h16 else (b["dcls"], b["dregiou"])
 
     # ------------------------------------------------------------------ backward
     def _tower_bwd_head(self, t):
@@ -553,16 +576,16 @@ class Engine:
         b = self.buf
         ylast = b[f"{t}.y{self.stacked_convs - 1}"]
         dy = b[f"{t}.dy"]
+        dcls, dri = self._head_grads()
         if t == "cls":
             pc = self.pred_cls
-            K.conv_wgrad(pc.geom, b["dcls"], ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
-            K.conv_dgrad(pc.geom, b["dcls"], pc.wft, dy, k_channels=self.cls_pad)
+            K.conv_wgrad(pc.geom, dcls, ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
+            K.conv_dgrad(pc.geom, dcls, pc.wft, dy, k_channels=self.cls_pad)
         else:
             pr, pi = self.pred_reg, self.pred_iou
-            dri = b["dregiou"]
-            K.conv_wgrad(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=16)
-            K.conv_wgrad(pi.geom, dri.view(-1)[4:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=16)
-            K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=16)
+            K.conv_wgrad(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=self.ri_pad)
+            K.conv_wgrad(pi.geom, dri.view(-1)[self.iou_col:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=self.ri_pad)
+            K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=self.ri_pad)
 
     def _tower_bwd_head_async(self, t):
         """like _tower_bwd_head, with the predictor weight-gradient GEMMs on the side stream"""
@@ -579,16 +602,16 @@ class Engine:
                 with torch.cuda.stream(side):
                     K.conv_wgrad(*a, **k)
 
+        dcls, dri = self._head_grads()
         if t == "cls":
             pc = self.pred_cls
-            wg(pc.geom, b["dcls"], ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
-            K.conv_dgrad(pc.geom, b["dcls"], pc.wft, dy, k_channels=self.cls_pad)
+            wg(pc.geom, dcls, ylast, pc.slabs, pc.dbias_partials, cout=pc.cout, ld_dy=self.cls_pad)
+            K.conv_dgrad(pc.geom, dcls, pc.wft, dy, k_channels=self.cls_pad)
         else:
             pr, pi = self.pred_reg, self.pred_iou
-            dri = b["dregiou"]
-            wg(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=16)
-            wg(pi.geom, dri.view(-1)[4:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=16)
-            K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=16)
+            wg(pr.geom, dri, ylast, pr.slabs, pr.dbias_partials, cout=4, ld_dy=self.ri_pad)
+            wg(pi.geom, dri.view(-1)[self.iou_col:], ylast, pi.slabs, pi.dbias_partials, cout=1, ld_dy=self.ri_pad)
+            K.conv_dgrad(pr.geom, dri, pr.wft, dy, k_channels=self.ri_pad)
 
     def _tower_bwd_layer(self, t, tower, i, ws, dP, addend):
         b, p, g = self.buf, self.p, self.g

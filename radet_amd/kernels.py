@@ -86,6 +86,7 @@ class ConvGeom:
         self.fwd_tile = self.bwd_tile = 0     # 0 = launcher heuristic; set by autotune()
         self.math = 0                         # 1: bf16 math mode (operands rounded to bf16, fp32 accumulate)
         self.wgrad_flags = 0                  # tile override of the wgrad launcher (set by autotune_wgrad)
+        self.h16 = False                      # bf16 tensors in HBM (tuning runs use the matching kernels)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
 
     @property
@@ -234,16 +235,17 @@ def autotune(g, need_dgrad=True, reps=3):
         return out
 
     global _TUNE_DIRTY
-    key = (g._key, g.cin, g.cout, g.math)
+    key = (g._key, g.cin, g.cout, g.math, g.h16)
     if key not in _TUNE_CACHE:
         _TUNE_DIRTY = True
-        x = torch.randn(g.lin.rows, g.cin, device=dev)
-        w = torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05
-        y = torch.empty(g.lout.rows, g.cout, device=dev)
+        dt = torch.bfloat16 if g.h16 else torch.float32
+        x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
+        w = (torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05).to(dt)
+        y = torch.empty(g.lout.rows, g.cout, device=dev, dtype=dt)
         ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout, g.lout.rows, g.k * g.k))
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
-            dx = torch.empty(g.lin.rows, g.cin, device=dev)
+            dx = torch.empty(g.lin.rows, g.cin, device=dev, dtype=dt)
             bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
         _TUNE_CACHE[key] = (ft, bt)
         if os.environ.get("RADET_TUNE_LOG"):
@@ -254,12 +256,23 @@ def autotune(g, need_dgrad=True, reps=3):
 MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
 
 
-def _tile(g, tile, default):
-    return (tile or default) | (MATH_BF16 if g.math else 0)
+STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
+
+
+def _is16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _tile(g, tile, default, x=None, y=None):
+    """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
+    t = (tile or default) | (MATH_BF16 if g.math else 0)
+    if _is16(x):
+        t = (t & ~MATH_BF16) | STORE_BF16 | (OUT_F32 if (y is not None and y.dtype == torch.float32) else 0)
+    return t
 
 
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
-    tile = _tile(g, tile, g.fwd_tile)
+    tile = _tile(g, tile, g.fwd_tile, x, y)
     ws = splitk_ws() if splitk else None
     _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
               g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
@@ -275,7 +288,7 @@ def autotune_wgrad(g, reps=3):
     ~3 TB/s).  Must run before the slab buffers are sized (it changes g.nsplit)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     global _TUNE_DIRTY
-    key = (g._key, g.cin, g.cout, g.math, "w")
+    key = (g._key, g.cin, g.cout, g.math, g.h16, "w")
     if key not in _WTUNE_CACHE:
         _TUNE_DIRTY = True
         M, kk = g.lout.rows, g.k * g.k
@@ -288,8 +301,9 @@ def autotune_wgrad(g, reps=3):
                     S = max(1, min(64, round(blocks / tiles), (M + 127) // 128))
                     cands.append((tflag | 0x40, S))
         cands = sorted(set(cands))
-        dy = torch.randn(M, g.cout, device=dev)
-        x = torch.randn(g.lin.rows, g.cin, device=dev)
+        dt = torch.bfloat16 if g.h16 else torch.float32
+        dy = torch.randn(M, g.cout, device=dev).to(dt)
+        x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         slabs = torch.empty(max(c[1] for c in cands) * g.cout * kk * g.cin, device=dev)
         best = None
         for fl, S in cands:
@@ -319,7 +333,7 @@ def conv_fwd_pair(g, a, b, relu=False, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.fwd_table), g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu),
-              _tile(g, tile, g.fwd_tile), _ptr(ws), C.c_size_t(ws.numel()), _stream())
+              _tile(g, tile, g.fwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
 
 def conv_dgrad_pair(g, a, b, tile=0):
@@ -328,7 +342,7 @@ def conv_dgrad_pair(g, a, b, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.bwd_table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
-              _tile(g, tile, g.bwd_tile), _ptr(ws), C.c_size_t(ws.numel()), _stream())
+              _tile(g, tile, g.bwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
@@ -337,7 +351,7 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
     input positions a strided conv never touches (3/4 of them for a 1x1 / 2) are left alone instead of being
     rewritten by an epilogue-only launch."""
     kc = g.cout if k_channels is None else k_channels
-    tile = _tile(g, tile, g.bwd_tile)
+    tile = _tile(g, tile, g.bwd_tile, dy, dx)
     ws = splitk_ws() if splitk else None
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         for c in _strided_dgrad_classes(g):
@@ -346,7 +360,8 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
                 continue
             # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table
             _lib.call("radet_conv2d_igemm_taps", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
-                      _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"], 16 if c["zero"] else kc, g.cin,
+                      _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"],
+                      (32 if _is16(dy) else 16) if c["zero"] else kc, g.cin,
                       tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
         return
     _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
@@ -356,7 +371,8 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
-              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, (1 if g.math else 0) | g.wgrad_flags, _stream())
+              g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit,
+              (2 if _is16(dy) else (1 if g.math else 0)) | g.wgrad_flags, _stream())
 
 
 def fold_weights(table_dev, n):
@@ -367,12 +383,25 @@ def unfold_grads(table_dev, n, max_cout):
     _lib.call("radet_unfold_grads", _ptr(table_dev), n, max_cout, _stream())
 
 
+def _h(name, t):
+    """entry point for the tensor's storage type"""
+    return name + "_h" if _is16(t) else name
+
+
 def stem(img, wf, bias, y, B, H, W):
-    _lib.call("radet_stem_conv_bn_relu", _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream())
+    _lib.call(_h("radet_stem_conv_bn_relu", y), _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream())
+
+
+def convert_rows(src, dst, ncols=None, src_off=0, dst_off=0):
+    """dst[:, dst_off:dst_off+ncols] = src[:, src_off:src_off+ncols] across fp32 <-> bf16 (2-D row-major tensors)"""
+    assert src.dim() == 2 and dst.dim() == 2 and src.shape[0] == dst.shape[0] and src.dtype != dst.dtype
+    n = src.shape[1] if ncols is None else ncols
+    _lib.call("radet_convert_rows", _ptr(src), _ptr(dst), C.c_size_t(src.shape[0]), n, src.stride(0), src_off,
+              dst.stride(0), dst_off, 1 if dst.dtype == torch.bfloat16 else 0, _stream())
 
 
 def maxpool(x, y, B, H, W, Cch):
-    _lib.call("radet_maxpool3x3s2", _ptr(x), _ptr(y), B, H, W, Cch, _stream())
+    _lib.call(_h("radet_maxpool3x3s2", x), _ptr(x), _ptr(y), B, H, W, Cch, _stream())
 
 
 def gn_ws_floats(levels):
@@ -386,33 +415,44 @@ def _gn_desc(levels):
 
 def gn_relu_fwd(levels, z, gamma, beta, y, stats, ws, eps=1e-5, relu=True):
     d, n = _gn_desc(levels)
-    _lib.call("radet_gn_relu_fwd", _ptr(z), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), levels.B, 256, 32,
+    _lib.call(_h("radet_gn_relu_fwd", z), _ptr(z), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), levels.B, 256, 32,
               eps, int(relu), d, n, _stream())
 
 
 def gn_relu_bwd(levels, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws, relu=True):
     d, n = _gn_desc(levels)
-    _lib.call("radet_gn_relu_bwd", _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr(dgamma),
+    _lib.call(_h("radet_gn_relu_bwd", dy), _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr(dgamma),
               _ptr(dbeta), _ptr(ws), levels.B, 256, 32, int(relu), d, n, _stream())
 
 
 def upsample_add(dst, src, B, ho, wo, hi, wi, ch):
-    _lib.call("radet_upsample_add", _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _stream())
+    _lib.call(_h("radet_upsample_add", dst), _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _stream())
 
 
 def upsample_add_bwd(dsrc, ddst, B, ho, wo, hi, wi, ch):
-    _lib.call("radet_upsample_add_bwd", _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _stream())
+    _lib.call(_h("radet_upsample_add_bwd", dsrc), _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _stream())
 
 
 def relu_bwd(dy, addend, act, dx):
-    _lib.call("radet_relu_bwd", _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _stream())
+    _lib.call(_h("radet_relu_bwd", dy), _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _stream())
 
 
 def nchw_to_nhwc(x, y, B, ch, H, W):
+    """module-API boundary (fp32 NCHW in); a bf16 row buffer is filled through an fp32 staging tensor"""
+    if _is16(y):
+        tmp = torch.empty(y.shape, device=y.device, dtype=torch.float32)
+        _lib.call("radet_nchw_to_nhwc", _ptr(x), _ptr(tmp), B, ch, H, W, _stream())
+        convert_rows(tmp.view(-1, ch), y.view(-1, ch))
+        return
     _lib.call("radet_nchw_to_nhwc", _ptr(x), _ptr(y), B, ch, H, W, _stream())
 
 
 def nhwc_to_nchw(x, y, B, ch, H, W):
+    """module-API boundary (fp32 NCHW out)"""
+    if _is16(x):
+        tmp = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+        convert_rows(x.reshape(-1, ch), tmp.view(-1, ch))
+        x = tmp
     _lib.call("radet_nhwc_to_nchw", _ptr(x), _ptr(y), B, ch, H, W, _stream())
 
 

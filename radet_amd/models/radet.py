@@ -54,7 +54,7 @@ class RADet(nn.Module):
         if math is None and getattr(self, "fp16_enabled", False):
             math = "bf16"
         rt = self._runtime
-        if rt is not None and math is not None and rt.engine.math != (1 if math == "bf16" else 0):
+        if rt is not None and math is not None and rt.engine.math_name != math:
             rt = None
         if rt is None or not rt.flat.still_bound():
             rt = DetectorRuntime(self, depth=self.backbone.depth, num_classes=self.bbox_head.num_classes,

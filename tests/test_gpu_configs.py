@@ -156,3 +156,45 @@ def test_bf16_config3_vs_oracle():
     assert any(abs(lb[k] - res["fp32"][0][k]) > 1e-5 * max(1.0, abs(lb[k])) for k in lb), (lb, res["fp32"][0])
     print(f"bf16 vs oracle-bf16: C2 {rel(c2['bf16'], ores['bf16'][2]):.2e} (bf16 perturbation {gap_c2:.2e}); "
           f"gradient error {e2 ** 0.5:.3f} vs perturbation {g2 ** 0.5:.3f}")
+
+
+def test_bf16_storage_mode_train_step():
+    """math="bf16-storage": bf16 activations / folded weights / activation gradients in HBM.  Same statistical
+    criteria as the bf16 math mode (activations are additionally rounded when stored, so the perturbation is larger):
+    losses within 1e-2, gradient tensors within the bf16-vs-fp32 perturbation of the oracle's bf16 model, finite, and
+    the native step (clip + AdamW) runs."""
+    from oracle import model as om, synth
+    H, W = 224, 224
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2)
+    det = make(50)
+    det.train()
+    rt = det.runtime(math="bf16-storage")
+    assert rt.engine.h16
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    assert det.runtime().engine.h16
+    sum(losses.values()).backward()
+    grads = {n: p.grad.detach().cpu().double() for n, p in det.named_parameters() if p.requires_grad}
+    ores = {}
+    for mode in ("fp32", "bf16"):
+        odet = om.OracleDetector(50, seed=1, math=mode)
+        ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+        om.parse_losses(ol).backward()
+        ores[mode] = ({k: v.item() for k, v in ol.items()}, {n: g.double() for n, g in odet.named_grads().items()})
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - ores["bf16"][0][k]) <= 1e-2 * max(1.0, abs(ores["bf16"][0][k])), (k, losses[k].item())
+    ob, of = ores["bf16"][1], ores["fp32"][1]
+    tot = float(np.sqrt(sum(g.norm().item() ** 2 for g in ob.values())))
+    e2 = g2 = 0.0
+    for n, g in grads.items():
+        assert torch.isfinite(g).all(), n
+        err, gap = (g - ob[n]).norm().item(), (ob[n] - of[n]).norm().item()
+        assert err <= 3.0 * gap + 2e-3 * tot, (n, err, gap)
+        e2, g2 = e2 + err ** 2, g2 + gap ** 2
+    assert e2 < 2.0 ** 2 * g2, (e2 ** 0.5, g2 ** 0.5)
+    print(f"bf16-storage vs oracle-bf16: gradient error {e2 ** 0.5:.3f} vs bf16-math perturbation {g2 ** 0.5:.3f}")
+    # native train step
+    rt.init_optimizer()
+    tg = rt.pack_targets(gt_b, gt_l, p2g, pw)
+    out = rt.train_step(img.cuda(), tg)
+    assert torch.isfinite(out).all()

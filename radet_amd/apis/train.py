@@ -63,10 +63,17 @@ def load_checkpoint(model, path, strict=False, runtime=None):
     return ckpt.get("meta", {}), missing
 
 
-def wrap_fp16_model(model):
-    """Mixed-precision switch with mmcv's name: marks the detector so that its HIP runtime is built in bf16 math
-    mode (conv operands rounded to bf16 into the matrix cores; fp32 accumulate, GroupNorm, loss and optimizer)."""
+def wrap_fp16_model(model, mode="bf16-storage"):
+    """Mixed-precision switch with mmcv's name (the reference: `wrap_fp16_model` + `Fp16OptimizerHook`,
+    apis/train.py:113-117, which keep half-precision activations and fp32 master weights).  Marks the detector so that
+    its HIP runtime is built in `mode`:
+      "bf16-storage" (default): bf16 activations / folded weights / activation gradients in HBM, bf16 matrix cores,
+                                fp32 accumulate, GroupNorm statistics, loss, weight gradients, master weights, AdamW;
+      "bf16":                   fp32 tensors, operands rounded to bf16 on their way into the matrix cores.
+    No loss scaling is needed with bf16's fp32-sized exponent."""
+    assert mode in ("bf16-storage", "bf16")
     model.fp16_enabled = True
+    model.fp16_mode = mode
     return model
 
 

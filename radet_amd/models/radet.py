@@ -52,7 +52,7 @@ class RADet(nn.Module):
         mixed precision (`fp16_enabled`, what mmcv's wrap_fp16_model sets -- apis/train.py:113-117), else RADET_MATH."""
         from ..runtime import DetectorRuntime
         if math is None and getattr(self, "fp16_enabled", False):
-            math = "bf16"
+            math = getattr(self, "fp16_mode", "bf16-storage")
         rt = self._runtime
         if rt is not None and math is not None and rt.engine.math_name != math:
             rt = None

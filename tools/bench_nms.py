@@ -33,4 +33,4 @@ s.record()
 for _ in range(10):
     run()
 e.record(); e.synchronize()
-print(f"N={N} B={B} stop={os.environ.get('RADET_NMS_STOP', '0')}: {s.elapsed_time(e) / 10 * 1e3:.0f} us per launch, heads {oc.tolist()[:4]}")
+print(f"N={N} B={B} {s.elapsed_time(e) / 10 * 1e3:.0f} us per launch, heads {oc.tolist()[:4]}")

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, in
     const ConvPtrs P = a.p[grp];
     const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
     const float* part = a.partial + (size_t)blockIdx.x * a.sk_tail * BM * BN;
-    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    const int quarter = BM * BN / 4;                     // blockIdx.y: quarter of the tile (4x the workgroups)
+    for (int e = blockIdx.y * quarter + threadIdx.x; e < (blockIdx.y + 1) * quarter; e += 256) {
         const int rl = e / BN, cl = e - rl * BN;
         const int row = m0 + rl, col = n0 + cl;
         if (row >= a.M || col >= a.Cout) continue;
@@ -1450,7 +1451,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, a);
     }
     if (a.sk_tail > 1)
-        hipLaunchKernelGGL(tail_epilogue_kernel, dim3(T - a.n_full), dim3(256), 0, st, a, BM, BN);
+        hipLaunchKernelGGL(tail_epilogue_kernel, dim3(T - a.n_full, 4), dim3(256), 0, st, a, BM, BN);
 }
 
 static long igemm_tiles(int M, int N, int choice) {

@@ -185,6 +185,17 @@ int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t*
                         int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw, int* used,
                         void* ws, void* stream);
 
+/* ---- box-to-distance transforms of the mask-free sampler (GenerateDistanceMap(with_gt_mask=False)):
+ *      pybind ops bbox2distance_ext.{MBD, GDT} (radet/ops/bbox2distance/bbox2distance_ext.cpp:127-133, 225-236), batched
+ *      over box crops.  img_desc_dev[n][5] = (pixel offset of the crop in the packed arrays, h, w, first seed, seeds);
+ *      images u8 [px][3] (HWC), dmap f64 [px], cost / dist f32 [px]; seeds as int32.  Bit-identical to the
+ *      reference's sequential raster scans. */
+size_t radet_mbd_ws_bytes(size_t total_px);
+int radet_mbd(const uint8_t* images, const int* img_desc_dev, int nimg, const int* seeds_x, const int* seeds_y, float alpha,
+              int niter, int base_size, double* dmap, size_t total_px, void* ws, void* stream);
+int radet_gdt(const float* cost, const int* img_desc_dev, int nimg, const int* seeds_x, const int* seeds_y, float* dist,
+              void* ws_labels /* int32 [px] */, void* stream);
+
 /* ---- instance-mask path feeding the assigner: BitmapMasks.rescale / resize / flip / pad
  *      (core/mask/structures.py:253-303: mmcv.imresize = cv2.INTER_NEAREST, np.flip, np.pad per mask) fused into one
  *      pass over a [G,Hs,Ws] u8 stack, and LoadAnnotations._load_bop_masks' normalisation (loading.py:419-422).

@@ -1,7 +1,8 @@
 """Build the REAL reference C++ ops into oracle/_ref/ (test infrastructure only).
 
 The three reference extensions are single-file C++ torch extensions
-(/root/reference/radet/ops/{vote/vote_ext.cpp, cluster/cluster_ext.cpp}); they
+(/root/reference/radet/ops/{vote/vote_ext.cpp, cluster/cluster_ext.cpp,
+bbox2distance/bbox2distance_ext.cpp}); they
 compile as-is with g++ against the torch headers of this image.  Sources are
 compiled where they lie (never copied); only the resulting .so files land in
 oracle/_ref/, which is git-ignored but travels to the GPU box with gpurun.
@@ -21,6 +22,7 @@ REFERENCE_ROOT = "/root/reference"
 _SOURCES = {
     "ref_vote_ext": "radet/ops/vote/vote_ext.cpp",
     "ref_cluster_ext": "radet/ops/cluster/cluster_ext.cpp",
+    "ref_bbox2distance_ext": "radet/ops/bbox2distance/bbox2distance_ext.cpp",
 }
 
 

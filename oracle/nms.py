@@ -12,7 +12,8 @@ _LIB = None
 def build():
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "nms.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "dist.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 

@@ -64,6 +64,9 @@ SIGNATURES = {
     "radet_upsample_add_bwd_h": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "radet_relu_bwd_h": (_i, [_p, _p, _p, _p, _sz, _p]),
     "radet_convert_rows": (_i, [_p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_mbd_ws_bytes": (_sz, [_sz]),
+    "radet_mbd": (_i, [_p, _p, _i, _p, _p, _f, _i, _i, _p, _sz, _p, _p]),
+    "radet_gdt": (_i, [_p, _p, _i, _p, _p, _p, _p, _p]),
     "radet_mask_max": (_i, [_p, _p, _i, _sz, _p]),
     "radet_mask_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_grid_anchors": (_i, [_p, _p, _i, _i, _p]),

@@ -22,8 +22,9 @@ def build_pipeline(cfg):
 class GenerateDistanceMap:
     def __init__(self, with_gt_mask=True, **kwargs):
         if not with_gt_mask:
-            raise NotImplementedError("GenerateDistanceMap(with_gt_mask=False) needs the MBD/GDT transforms "
-                                      "(out of scope, SURVEY.md §8f); every BOP config uses with_gt_mask=True")
+            raise NotImplementedError("GenerateDistanceMap(with_gt_mask=False): the MBD / GDT transforms exist "
+                                      "(radet_amd.ops.mbd_batch / gdt_batch), the cv2 crop resize / blur / edge extraction "
+                                      "around them is not restated; every BOP config uses with_gt_mask=True")
 
     def __call__(self, results):
         results["distance_maps"] = results["gt_masks"]

@@ -518,6 +518,19 @@ def nms(boxes, cluster_scores, vote_scores, labels, counts, B, cap, mode, iou_th
               _ptr(out_count), _ptr(aux0), _ptr(aux1), _ptr(ws), _stream())
 
 
+def mbd_ws_bytes(px):
+    return int(_lib.load().radet_mbd_ws_bytes(px))
+
+
+def mbd(images, desc, n, sx, sy, alpha, niter, base_size, dmap, px, ws):
+    _lib.call("radet_mbd", _ptr(images), _ptr(desc), n, _ptr(sx), _ptr(sy), alpha, niter, base_size, _ptr(dmap),
+              C.c_size_t(px), _ptr(ws), _stream())
+
+
+def gdt(cost, desc, n, sx, sy, dist, ws):
+    _lib.call("radet_gdt", _ptr(cost), _ptr(desc), n, _ptr(sx), _ptr(sy), _ptr(dist), _ptr(ws), _stream())
+
+
 def assign_ws_bytes(B, N):
     return int(_lib.load().radet_assign_ws_bytes(B, N))
 

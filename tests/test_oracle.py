@@ -251,3 +251,25 @@ def test_mask_oracle_identities():
     n = om.normalize(np.stack([m[0], np.zeros_like(m[0]), (m[2] > 128).astype(np.uint8) * 255]))
     assert set(np.unique(n)) <= {0, 1} and n[1].max() == 0 and (n[2] == (m[2] > 128)).all()
     assert om.rescale_size((640, 480), (1333, 800)) == (1067, 800) and om.rescale_size((640, 480), 0.5) == (320, 240)
+
+
+def test_distance_oracle_matches_reference_build():
+    """oracle/dist.c (MBD / GDT raster scans) == the reference's bbox2distance_ext.cpp compiled in place (oracle/_ref),
+    bit for bit, on ragged crop sizes incl. crops larger than base_size^2 (integer size factor) and odd niter."""
+    import torch
+    from oracle import build_ref, dist
+    ref = build_ref.load("ref_bbox2distance_ext")
+    if ref is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rs = np.random.RandomState(0)
+    for (h, w, niter, base) in ((150, 200, 4, 300), (37, 53, 4, 300), (64, 41, 3, 40), (2, 2, 4, 300), (90, 90, 5, 30)):
+        img = (rs.rand(h, w, 3) * 255).astype(np.uint8)
+        img[h // 4:3 * h // 4, w // 4:3 * w // 4] //= 3
+        sx, sy = dist.border_seeds(h, w)
+        a = dist.mbd(img, sx, sy, 0.1, niter, base)
+        b = ref.MBD(torch.from_numpy(img), torch.from_numpy(sx), torch.from_numpy(sy), 0.1, niter, base).numpy()
+        assert np.array_equal(a, b), (h, w)
+        cost = rs.rand(h, w).astype(np.float32)
+        c = dist.gdt(cost, sx, sy)
+        d = ref.GDT(torch.from_numpy(cost), torch.from_numpy(sx), torch.from_numpy(sy)).numpy()
+        assert np.array_equal(c, d), (h, w)

@@ -119,17 +119,33 @@ class GradReducer:
     -12 % with a dedicated comm stream, recovered with GPU_MAX_HW_QUEUES=8 or without the stream).  The mean
     (1/world) is applied later, inside the fused clip+AdamW kernel."""
 
-    def __init__(self, grads, device):
-        self.grads, self.device = grads, device
+    def __init__(self, grads, device, bf16=False):
+        """bf16=True: each bucket is exchanged as bf16 (half the bytes on xGMI; the reference's fp16 training also
+        all-reduces half-precision gradients): fp32 -> bf16 staging buffer -> all-reduce -> back into the fp32 arena."""
+        self.grads, self.device, self.bf16 = grads, device, bf16
         self.works = []
+        self.staging = torch.empty(grads.numel(), dtype=torch.bfloat16, device=device) if bf16 else None
+
+    def _convert(self, src, dst):
+        if src.is_cuda:
+            K.convert_rows(src.view(1, -1), dst.view(1, -1))
+        else:
+            dst.copy_(src)
 
     def bucket_ready(self, bucket):
         b, e = bucket["arena"]
-        self.works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, async_op=True))
+        if self.bf16:
+            st = self.staging[b:e]
+            self._convert(self.grads[b:e], st)
+            self.works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True), b, e))
+        else:
+            self.works.append((dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, async_op=True), b, e))
 
     def finish(self):
-        for w in self.works:
+        for w, b, e in self.works:
             w.wait()
+            if self.bf16:
+                self._convert(self.staging[b:e], self.grads[b:e])
         self.works = []
 
 
@@ -253,7 +269,9 @@ class DetectorRuntime:
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
         if use_reducer:
             if self.reducer is None:
-                self.reducer = GradReducer(self.flat.grads, self.dev)
+                # bf16 buckets: opt-in (RADET_BF16_BUCKETS=1) in the mixed-precision modes
+                self.reducer = GradReducer(self.flat.grads, self.dev,
+                                           bf16=os.environ.get("RADET_BF16_BUCKETS") == "1" and self.engine.math_name != "fp32")
             self.backward(self.reducer.bucket_ready)
             self.reducer.finish()
         else:

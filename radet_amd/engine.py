@@ -683,8 +683,13 @@ class Engine:
 
     def _write_scale_grads(self):
         g = self.g
-        for i in range(len(self.strides)):
-            g[f"bbox_head.scales.{i}.scale"].copy_(self.dscales[i])
+        ts = [g[f"bbox_head.scales.{i}.scale"] for i in range(len(self.strides))]
+        base = ts[0].data_ptr()
+        if all(t.data_ptr() == base + 4 * i for i, t in enumerate(ts)):      # contiguous in the gradient arena: one copy
+            torch.as_strided(ts[0], (len(ts),), (1,)).copy_(self.dscales)
+            return
+        for i, t in enumerate(ts):
+            t.copy_(self.dscales[i])
 
     def neck_backward(self, dP):
         b, B, f = self.buf, self.B, self.feat

@@ -335,7 +335,7 @@ __device__ __forceinline__ void lds_wait() {
 // k-quad q ^ swz(r), swz(r) = (r / (64 / BK)) % (BK / 4); the reader of k-quad kq looks in slot kq ^ swz(r).
 // Stage order per K step: issue the next stage's loads into the other buffer, then fragment reads (software
 // pipelined one 8-wide k slice ahead) + MFMAs on the current buffer, then vmcnt(0) + barrier.
-template <int BM, int BN, int WM, int WN, int TAG, int BK>
+template <int BM, int BN, int WM, int WN, int TAG, int BK, int NSTG = 2>
 __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int F4 = BK / 4;            // 16-byte slots per tile row
     constexpr int RPI = 64 / F4;          // tile rows per wave load
@@ -347,8 +347,11 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
     constexpr bool H16 = (TAG & 4) != 0;                      // bit 2: bf16 storage (a 16-byte slot = 8 bf16 = one MFMA operand)
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+    // NSTG LDS stages: loads run NSTG - 1 K steps ahead of the MFMAs.  3 stages hide more L2 latency (+8 % on the
+    // tower GEMM running alone) but cost LDS occupancy, which loses when dgrad and wgrad kernels share the CUs: used
+    // for forward launches only (tile_override 0x20000), chosen per shape by the autotuner
+    __shared__ __attribute__((aligned(16))) float As[NSTG][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[NSTG][BN * BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,8 +436,16 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // vmcnt(LOADS) = "everything except the newest stage's loads has landed" (in-order return); only valid when every
+    // wave owns exactly A_PW + B_PW loads per stage
+    constexpr int LOADS = (A_FULL && B_FULL) ? A_PW + B_PW : 0;
     if (nK > 0) issue_stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NSTG == 3 && nK > 1) {
+        issue_stage(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     // reader side: tile rows wm*TM*32 + i*32 + li; (i*32) % (RPB*F4) == 0 so swz only depends on li.
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     auto stage = [&](auto bufc, int it) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int AO = BUF * BM * BK * 4, BO = BUF * BN * BK * 4, RO = 32 * BK * 4;
-        if (it + 1 < nK) issue_stage(BUF ^ 1);
+        if (it + NSTG - 1 < nK) issue_stage((BUF + NSTG - 1) % NSTG);
         f32x4 af[2][TM], bf[2][TN];
         auto read_s = [&](int s, int pp) {
             lds_read128<AO>(af[pp][0], aaddr[s]);
@@ -507,12 +518,15 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the MFMAs of slice s ahead of the next waits
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA loads have landed
+        if (NSTG == 3 && it + 2 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");   // stage it+1 has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    for (int it = 0; it < nK; it += 2) {
+    for (int it = 0; it < nK; it += NSTG) {
         stage(std::integral_constant<int, 0>{}, it);
         if (it + 1 < nK) stage(std::integral_constant<int, 1>{}, it + 1);
+        if constexpr (NSTG == 3)
+            if (it + 2 < nK) stage(std::integral_constant<int, 2>{}, it + 2);
     }
     igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, tail, tail_slot, wm, wn, li, lh);
 }
@@ -1397,7 +1411,7 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats) {
+static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, bool stages3) {
     ConvArgs a = a_in;
     const int T = a.groups * ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     a.n_full = T; a.sk_tail = 1; a.it_per_tail = a.it_per_split;
@@ -1423,7 +1437,12 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
         else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 16); }
     } else {
-        if (bk == 32) {
+        if (stages3 && tag < 2) {
+#define RADET_LAUNCH_IGEMM3(TAGV, BKV) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, 3>), dim3(tiles, a.sk), dim3(256), 0, st, a)
+            if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
+            else          { if (tag) RADET_LAUNCH_IGEMM3(1, 16); else RADET_LAUNCH_IGEMM3(0, 16); }
+#undef RADET_LAUNCH_IGEMM3
+        } else if (bk == 32) {
             switch (tag) {
                 case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); break;
                 case 1: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 1, 32); break;
@@ -1567,6 +1586,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     // split-K for launches that cannot fill 256 CUs twice over (low-M stages): each split keeps >= 8 K stages
     const int nK = KH * KW * (Cin / bk);
     int sk = 1;
+    const bool stages3 = ((tile_override >> 17) & 1) != 0;   // 0x20000: 3 LDS stages (forward launches that run alone)
     const int sk_force = (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;
     if (splitk_ws != nullptr && a.groups == 1) {
@@ -1583,10 +1603,10 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.it_per_split = (nK + sk - 1) / sk;
     a.partial = splitk_ws;
     switch (choice) {
-        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
-        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
-        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats); break;
-        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats); break;
+        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
+        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
+        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
+        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats, stages3); break;
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();

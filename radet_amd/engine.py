@@ -80,7 +80,11 @@ class Engine:
 
     def _ttile(self, c, bwd=False, tag=True):
         """tile_override of a tower conv launch: fixed tile in fp32, autotuned in bf16 math; + profiling tag"""
-        t = (self.TOWER_TAG & ~0x100) if not self.math else (c.geom.bwd_tile if bwd else c.geom.fwd_tile)
+        if self.math or self.h16:
+            t = c.geom.bwd_tile if bwd else c.geom.fwd_tile
+        else:
+            # fp32: 64x64 tile, K step 32; the forward launches run alone -> 3 LDS stages (+8 %: 112 vs 104 TFLOP/s)
+            t = (self.TOWER_TAG & ~0x100) | (0 if bwd else K.STAGES3)
         return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 

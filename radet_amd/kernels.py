@@ -242,7 +242,10 @@ def autotune(g, need_dgrad=True, reps=3):
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         w = (torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05).to(dt)
         y = torch.empty(g.lout.rows, g.cout, device=dev, dtype=dt)
-        ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), cands(g.cin, g.cout, g.lout.rows, g.k * g.k))
+        fc = cands(g.cin, g.cout, g.lout.rows, g.k * g.k)
+        if not g.math and not g.h16:      # forward launches run alone on the device: 3 LDS stages may pay (0x20000)
+            fc = fc + [t | STAGES3 for t in fc]
+        ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), fc)
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev, dtype=dt)
@@ -256,6 +259,7 @@ def autotune(g, need_dgrad=True, reps=3):
 MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
 
 
+STAGES3 = 0x20000                         # 3 LDS stages in the fp32 implicit-GEMM kernel (forward launches)
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
 
 

@@ -1410,6 +1410,33 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
     return RADET_OK;
 }
 
+// Experiment switches (environment, read once): the register-staged kernels and the launch heuristics they select
+// are kept for A/B measurements; none is needed in normal operation.
+struct RadetSwitches {
+    bool igemm_regstage, wgrad_regstage, wgrad9_regstage, no_tail_split, wgrad9_bm128, no_wgrad9;
+    int wgrad_tile64_m, dbg_wgrad;
+    long wgrad9_blocks, wgrad_blocks;
+};
+static const RadetSwitches& radet_switches() {
+    static const RadetSwitches s = [] {
+        RadetSwitches r;
+        auto on = [](const char* n) { return getenv(n) != nullptr; };
+        auto num = [](const char* n) { const char* e = getenv(n); return e ? atol(e) : 0L; };
+        r.igemm_regstage = on("RADET_IGEMM_REGSTAGE");
+        r.wgrad_regstage = on("RADET_WGRAD_REGSTAGE");
+        r.wgrad9_regstage = on("RADET_WGRAD9_REGSTAGE");
+        r.no_tail_split = on("RADET_NO_TAIL_SPLIT");
+        r.wgrad9_bm128 = on("RADET_WGRAD9_BM128");
+        r.no_wgrad9 = on("RADET_NO_WGRAD9");
+        r.wgrad_tile64_m = (int)num("RADET_WGRAD_TILE64_M");
+        r.dbg_wgrad = (int)num("RADET_DBG_WGRAD");
+        r.wgrad9_blocks = num("RADET_WGRAD9_BLOCKS");
+        r.wgrad_blocks = num("RADET_WGRAD_BLOCKS");
+        return r;
+    }();
+    return s;
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, bool stages3) {
     ConvArgs a = a_in;
@@ -1419,7 +1446,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int rem = T % 256;
     // only for long K loops: on short kernels the extra epilogue launch costs more than the idle tail
     if (a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 1152 &&
-        !getenv("RADET_NO_TAIL_SPLIT")) {
+        !radet_switches().no_tail_split) {
         int skt = 256 / rem;
         if (skt > 8) skt = 8;
         if (skt > nKs / 8) skt = nKs / 8;
@@ -1431,7 +1458,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
-    static const bool regstage = getenv("RADET_IGEMM_REGSTAGE") != nullptr;
+    const bool regstage = radet_switches().igemm_regstage;
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
     if (regstage && tag < 2 && a.io == 0) {
         if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
@@ -1615,18 +1642,18 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
-    if (getenv("RADET_WGRAD_REGSTAGE") && a.math == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
+    if (radet_switches().wgrad_regstage && a.math == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
     else if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
 }
 
-static int wgrad9_bm(int Cout) { return (Cout >= 256 && !getenv("RADET_WGRAD9_BM128")) ? 256 : 128; }
+static int wgrad9_bm(int Cout) { return (Cout >= 256 && !radet_switches().wgrad9_bm128) ? 256 : 128; }
 
 // all-taps kernel: pays off for 3x3 convs with >= 256 output channels and a long pixel dimension (head towers,
 // FPN P3): measured 96.6 vs 84.5 TFLOP/s on the tower shape; for the short-M backbone stages the one-tap kernel
 // with its finer tile grid stays ahead (tools/bench_conv.py)
 static bool use_wgrad9(int M, int Cin, int Cout, int KH, int KW) {
-    return KH == 3 && KW == 3 && Cin % 32 == 0 && Cout >= 256 && M >= 16384 && !getenv("RADET_NO_WGRAD9");
+    return KH == 3 && KW == 3 && Cin % 32 == 0 && Cout >= 256 && M >= 16384 && !radet_switches().no_wgrad9;
 }
 
 
@@ -1639,8 +1666,7 @@ static void wgrad_tile(int M, int Cout, int Cin, int KT, int* bm, int* bn) {
     *bm = 128; *bn = 128;
     const long tiles128 = (long)((Cout + 127) / 128) * ((Cin + 127) / 128) * KT;
     const long s128 = (448 + tiles128 - 1) / tiles128;
-    const char* e = getenv("RADET_WGRAD_TILE64_M");
-    const int mthr = e ? atoi(e) : 0;   // measured: no net gain on R50 640x480 (kept as a switch)
+    const int mthr = radet_switches().wgrad_tile64_m;   // measured: no net gain on R50 640x480 (kept as a switch)
     if (M <= mthr && s128 >= 4) { *bm = 64; *bn = 64; }
 }
 
@@ -1660,10 +1686,9 @@ extern "C" int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int K
         // 8-wave workgroups: one per CU already gives 2 waves per SIMD, and every extra split costs a full
         // weight-sized slab write + read in unfold
         lo = hi = (256 + tiles - 1) / tiles;
-        const char* e9 = getenv("RADET_WGRAD9_BLOCKS");
-        if (e9) lo = hi = (atol(e9) + tiles / 2) / tiles;
+        if (radet_switches().wgrad9_blocks) lo = hi = (radet_switches().wgrad9_blocks + tiles / 2) / tiles;
     }
-    { const char* e = getenv("RADET_WGRAD_BLOCKS"); if (e) lo = hi = (atol(e) + tiles / 2) / tiles; }
+    if (radet_switches().wgrad_blocks) lo = hi = (radet_switches().wgrad_blocks + tiles / 2) / tiles;
     if (lo < 1) lo = 1;
     long S = lo;
     double best = -1.0;
@@ -1695,7 +1720,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     a.M = M;
     a.Mp = radet_gather_table_rows(M);
     a.S = S;
-    { const char* e = getenv("RADET_DBG_WGRAD"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = radet_switches().dbg_wgrad;
     a.math = flags & 1;
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
@@ -1715,12 +1740,12 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (use_wgrad9(M, Cin, Cout, KH, KW) && !(flags & 0x40) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
-            if (getenv("RADET_WGRAD9_REGSTAGE") && a.math == 0) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
+            if (radet_switches().wgrad9_regstage && a.math == 0) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
             else if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 0>), dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
-            if (getenv("RADET_WGRAD9_REGSTAGE")) hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
+            if (radet_switches().wgrad9_regstage) hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad9g_kernel<4, 0>), dim3(tiles), dim3(256), 0, st, a);
         }
         return radet_check_launch();

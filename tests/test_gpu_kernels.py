@@ -585,3 +585,31 @@ def test_anchors(golden):
         sizes = [tuple(int(v) for v in s) for s in g[tag + "_sizes"]]
         a = torch.cat(ag.grid_anchors(sizes, device="cuda")).cpu().numpy()
         assert np.array_equal(a, g[tag])
+
+
+def test_cabi_error_codes(K):
+    """INTEGRATION.md "Error behaviour": bad arguments return -1 (RadetHipError on the Python side), nothing is launched."""
+    from radet_amd import _lib
+    dev = "cuda"
+    lv = K.Levels([(8, 8)], 1)
+    g = K.ConvGeom(lv, 24, 32, 1, 1, 0)                                   # Cin % 16 != 0
+    x, w, y = torch.zeros(64, 24, device=dev), torch.zeros(32, 1, 24, device=dev), torch.zeros(64, 32, device=dev)
+    with pytest.raises(_lib.RadetHipError):
+        K.conv_fwd(g, x, w, None, y)
+    g2 = K.ConvGeom(lv, 48, 32, 1, 1, 0)                                  # bf16 storage needs Cin % 32 == 0
+    with pytest.raises(_lib.RadetHipError):
+        K.conv_fwd(g2, torch.zeros(64, 48, device=dev, dtype=torch.bfloat16), torch.zeros(32, 1, 48, device=dev, dtype=torch.bfloat16),
+                   None, torch.zeros(64, 32, device=dev, dtype=torch.bfloat16))
+    n = 9000                                                              # NMS capacity is 8192 candidates per image
+    z = torch.zeros(1, n, device=dev)
+    with pytest.raises(_lib.RadetHipError):
+        K.nms(torch.zeros(1, n, 4, device=dev), z, z, torch.zeros(1, n, dtype=torch.long, device=dev),
+              torch.tensor([n], dtype=torch.int32, device=dev), 1, n, 0, 0.5, False, 0.025, 100, torch.zeros(1, 100, 4, device=dev),
+              torch.zeros(1, 100, device=dev), torch.zeros(1, 100, dtype=torch.long, device=dev),
+              torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, n, dtype=torch.long, device=dev),
+              torch.zeros(1, n, dtype=torch.long, device=dev), torch.zeros(1024, dtype=torch.uint8, device=dev))
+    with pytest.raises((_lib.RadetHipError, KeyError)):
+        K.mask_transform(torch.zeros(1, 8, 8, dtype=torch.uint8, device=dev), (4, 4), (8, 8))   # pad target smaller than the resized mask
+    with pytest.raises(_lib.RadetHipError):                               # wgrad: dy row stride must hold whole float4s
+        _lib.call("radet_conv2d_wgrad", K._ptr(y), K._ptr(x), K._ptr(y), None, K._ptr(g2.fwd_table), 64, 48, 32, 30, 1, 1, 1, 0,
+                  K._stream())

@@ -1,0 +1,102 @@
+"""Size-independent properties at BASELINE's full sizes (r50_ycbv_pbr, 640x480, batch 4), where the CPU oracle is too
+slow to be the checker for every case: exact linearity of the tower GEMM, idempotence of hard NMS, conservation laws of
+the assigner, sortedness of the NMS output, determinism of the train step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HW5 = [(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)]
+
+
+def test_tower_gemm_is_exactly_linear_in_powers_of_two():
+    """conv(2x) == 2 conv(x) and conv(x, W/4) == conv(x, W)/4 bit for bit (scaling by powers of two commutes with every
+    fp32 rounding), on the full B=4 tower shape incl. the tail-split tiles; fwd, dgrad and wgrad."""
+    from radet_amd import kernels as K
+    lv = K.Levels(HW5, 4)
+    g = K.ConvGeom(lv, 256, 256, 3, 1, 1)
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(lv.rows, 256, generator=gen).cuda()
+    w = (torch.randn(256, 9, 256, generator=gen) * 0.02).cuda()
+    y1, y2 = torch.empty(lv.rows, 256, device="cuda"), torch.empty(lv.rows, 256, device="cuda")
+    for tile in (0x203, 0x203 | K.STAGES3, 1):
+        K.conv_fwd(g, x, w, None, y1, tile=tile)
+        K.conv_fwd(g, 2 * x, w / 4, None, y2, tile=tile)
+        assert torch.equal(y2 * 2, y1)
+    K.conv_dgrad(g, x, w, y1, tile=0x203)
+    K.conv_dgrad(g, x * 0.5, w * 8, y2, tile=0x203)
+    assert torch.equal(y2 * 0.25, y1)
+    S = g.nsplit
+    s1, s2 = torch.empty(S, 256, 9, 256, device="cuda"), torch.empty(S, 256, 9, 256, device="cuda")
+    dy = torch.randn(lv.rows, 256, generator=gen).cuda()
+    K.conv_wgrad(g, dy, x, s1)
+    K.conv_wgrad(g, dy * 4, x * 0.5, s2)
+    assert torch.equal(s2 * 0.5, s1)
+
+
+def test_hard_nms_idempotent_and_sorted():
+    from radet_amd import ops
+    rs = np.random.RandomState(0)
+    n = 5000
+    c = rs.rand(n, 2) * np.array([600.0, 440.0])
+    wh = rs.rand(n, 2) * 120 + 8
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32))
+    scores = torch.from_numpy(rs.rand(n).astype(np.float32))
+    labels = torch.from_numpy(rs.randint(0, 21, n).astype(np.int64))
+    dets, keep = ops.batched_nms(boxes, scores, labels, dict(type="nms", iou_threshold=0.5))
+    assert (dets[:-1, 4] >= dets[1:, 4]).all()                                   # sorted by score
+    dets2, keep2 = ops.batched_nms(dets[:, :4], dets[:, 4], labels[keep], dict(type="nms", iou_threshold=0.5))
+    assert dets2.shape == dets.shape and torch.equal(dets2, dets)                # NMS(NMS(x)) == NMS(x)
+    vb, vl = ops.vote_nms(boxes, scores, labels, dict(type="vote", iou_threshold=0.65, iou_enable=False), score_factor=torch.ones(n),
+                          max_num=100)
+    assert vb.shape[0] == 100 and (vb[:-1, 4] >= vb[1:, 4]).all()
+
+
+def test_assigner_conservation_laws_full_size():
+    """B=4 at 640x480: every point is negative (-1, weight 1), ignored (0, weight 0) or positive (1..G, integer weight);
+    each gt that owns candidates hands out exactly positive_num draws."""
+    import bench
+    from radet_amd.datasets import LabelAssignment
+    rng = np.random.RandomState(5)
+    boxes, masks, rngs = [], [], []
+    for i in range(4):
+        b, _, m = bench.synth_objects(rng, int(rng.randint(1, 9)))
+        boxes.append(b); masks.append(m); rngs.append(np.random.RandomState(i))
+    la = LabelAssignment(neg_threshold=0.2, positive_num=10, adapt_positive_num=False, balance_sample=True)
+    p2g, pw = la.assign_batch(boxes, masks, (480, 640, 3), rngs=rngs)
+    p2g, pw = p2g.cpu().numpy(), pw.cpu().numpy()
+    assert p2g.shape == (4, 6400)
+    for i in range(4):
+        G = boxes[i].shape[0]
+        a, w = p2g[i], pw[i]
+        assert a.min() >= -1 and a.max() <= G
+        assert (w[a == -1] == 1).all() and (w[a == 0] == 0).all()
+        pos = a > 0
+        assert (w[pos] >= 1).all() and (w[pos] == np.round(w[pos])).all()
+        per_gt = np.bincount(a[pos], weights=w[pos], minlength=G + 1)[1:]
+        assert set(np.unique(per_gt)) <= {0.0, 10.0}, per_gt                     # 10 draws per gt (with multiplicity) or none
+        assert per_gt.sum() > 0
+
+
+def test_train_step_is_deterministic():
+    """Two identical runs of the native train step (same tuning) give bit-identical losses and parameters: all
+    reductions (split-K, wgrad slabs, GroupNorm, loss, grad norm) use fixed summation orders, no atomics on floats."""
+    import os
+    import bench
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for rep in range(2):
+        cfg = Config.fromfile(os.path.join(root, "configs", "bop", "r50_ycbv_pbr.py"))
+        cfg.model["pretrained"] = None
+        torch.manual_seed(0)
+        det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        rt = det.runtime()
+        rt.init_optimizer()
+        img, boxes, labels, p2g, pw = bench.make_batch(0, 2, torch.device("cuda"))
+        tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+        for _ in range(2):
+            losses = rt.train_step(img, tg).clone()
+        outs.append((losses.cpu(), rt.flat.params.clone().cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -1380,6 +1380,132 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, bf16 storage
+// conv_wgrad9g_kernel's tiling (256 output channels x 32 input channels x 9 taps per 8-wave workgroup, the dy tile
+// loaded once for all taps) with conv_wgradh_kernel's data path (bf16 [4 pixels][16 channels] sub-tiles by LDS-DMA,
+// ds_read_b64_tr_b16 operands, v_mfma_f32_32x32x16_bf16).
+__global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
+    constexpr int BP = 32, NW = 8, BM = 256, BC = 32, KT = 9;
+    constexpr int CBA = BM / 16, CBB = BC / 16;
+    constexpr int A_INSTR = BP * BM * 2 / 1024;             // 16
+    constexpr int B_TAP = BP * BC * 2 / 1024;               // 2 wave loads per tap tile
+    constexpr int B_INSTR = KT * B_TAP;                     // 18
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 5
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BP * BM];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KT * BP * BC];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    // x-tile load bi = tap * B_TAP + half: sub-tiles blk = half * 8 + l_blk of the tap's [8 pq][2 cb] grid
+    int brow[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int blk = (bi % B_TAP) * 8 + l_blk;
+            const int m = p_begin + 4 * (blk / CBB) + l_prow;
+            brow[k] = m < p_end ? a.rowtab[(size_t)(bi / B_TAP) * a.Mp + m] : -1;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int blk = ins * 8 + l_blk;
+                const int m = p0 + 4 * (blk / CBA) + l_prow;
+                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+                const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
+                                                            : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+            } else if (ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int blk = (bi % B_TAP) * 8 + l_blk;
+                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
+                const void* src = brow[k] >= 0 ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
+                                               : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+                const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
+                brow[k] = m < p_end ? a.rowtab[(size_t)(bi / B_TAP) * a.Mp + m] : -1;
+            }
+        }
+    };
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    typedef __attribute__((address_space(3))) s16x4v* tr_ptr;
+
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < BP / 16; ++ks) {
+            const int pq = 4 * ks + 2 * lh;
+            const unsigned short* qa = &As[buf][(pq * CBA + wave * 2 + g16) * 64 + m16 * 4];
+            const s16x4v alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)qa);
+            const s16x4v ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(qa + CBA * 64));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                const unsigned short* qb = &Bs[buf][t * BP * BC + (pq * CBB + g16) * 64 + m16 * 4];
+                const s16x4v blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)qb);
+                const s16x4v bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(qb + CBB * 64));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    af, __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[t], 0, 0, 0);
+            }
+        }
+        if (want_bias && tid < BM) {
+            const int cb = tid >> 4, cc = tid & 15;
+#pragma unroll
+            for (int p = 0; p < BP; ++p)
+                bsum += (float)reinterpret_cast<const __bf16*>(&As[buf][0])[((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < a.Cout) out[((size_t)o * KT + t) * a.Cin + c] = acc[t][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -1727,6 +1853,11 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     hipStream_t st = (hipStream_t)stream;
     if (flags & 2) {   // bf16 storage: dy / x are bf16 (ld_dy, Cin in elements; 16-byte aligned rows)
         if ((ld_dy & 7) || (Cin & 7)) return RADET_ERR_ARG;
+        if (use_wgrad9(M, Cin, Cout, KH, KW) && wgrad9_bm(Cout) == 256 && !(flags & 0x40) && !radet_switches().no_wgrad9) {
+            const int tiles9 = ((Cout + 255) / 256) * (Cin / 32) * S;
+            hipLaunchKernelGGL(conv_wgrad9h_kernel, dim3(tiles9), dim3(512), 0, st, a);
+            return radet_check_launch();
+        }
         int bm, bn;
         wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
         if (bm != 32 && ((flags >> 4) & 3) == 1) bm = bn = 128;

@@ -144,9 +144,7 @@ def main():
     o = cfg.optimizer
     rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
                       max_norm=float(cfg.optimizer_config.grad_clip.max_norm))
-    head = det.bbox_head
-    rt.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
-                           lbw=float(head.loss_bbox.loss_weight))
+    rt.set_loss_from_head(det.bbox_head)
     B = PER_GPU_BATCH
     img, boxes, labels, p2g, pw = make_batch(rank, B, device)
     tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels],

@@ -139,6 +139,8 @@ int radet_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, voi
  *  (row strides let the gradients land in zero-padded buffers that the dgrad GEMM consumes directly; the
  *  sparse dreg_u / diou rows of non-positive points are zero-filled here); dscales [nlvl];
  *  optional dumps (may be NULL): labels_out i64 [R], bbox_targets_out [R,4].
+ *  flags bit 0: reg_u holds the head's bbox_pred AFTER Scale + ReLU (the tensor `RADetHead.loss` receives,
+ *  radet_head.py:173-181; pass scales = 1): dreg_u is then the gradient w.r.t. that tensor (no ReLU mask).
  *  ws: int32 workspace of radet_head_loss_ws_ints(R) ints. */
 int radet_head_loss_ws_ints(int R);
 int radet_head_loss(const float* cls, const float* reg_u, const float* iou, const float* scales,
@@ -146,7 +148,7 @@ int radet_head_loss(const float* cls, const float* reg_u, const float* iou, cons
                     const float* pw, const int* level_desc, int nlvl, int B, int num_classes, float alpha,
                     float gamma, float loss_bbox_weight, float giou_eps, const float* grad_scale, float* losses,
                     float* dcls, int dcls_ld, float* dreg_u, int dreg_ld, float* diou, int diou_ld, float* dscales,
-                    int64_t* labels_out, float* bbox_targets_out, int* ws, void* stream);
+                    int64_t* labels_out, float* bbox_targets_out, int flags, int* ws, void* stream);
 /* bbox_pred = relu(reg_u * scale_level) materialised for the module API (atss_head.py:143, radet_head.py:29) */
 int radet_scale_relu(const float* reg_u, const float* scales, float* out, const int* level_desc, int nlvl, int B,
                      void* stream);
@@ -204,6 +206,53 @@ int radet_gdt(const float* cost, const int* img_desc_dev, int nimg, const int* s
 int radet_mask_max(const uint8_t* masks, uint32_t* maxes /* [G] */, int G, size_t hw, void* stream);
 int radet_mask_transform(const uint8_t* src, uint8_t* dst, const uint32_t* norm_max, int G, int Hs, int Ws, int Hr, int Wr,
                          int Hd, int Wd, int flip, int pad_val, void* stream);
+
+/* ---- stand-alone box / loss operators behind the registered classes (used on their own; inside the detector the same
+ *      arithmetic runs fused in radet_head_loss / radet_decode_candidates) ------------------------------------------ */
+/* bbox_overlaps / BboxOverlaps2D (radet/core/bbox/iou_calculators/iou2d_calculator.py:43-159): boxes [batch, M, 4] and
+ * [batch, N, 4]; mode 0 iou, 1 iof, 2 giou; aligned: out [batch, M] (M == N) else the M x N matrix out [batch, M, N].
+ * Operation order = the reference's PyTorch expressions, results equal PyTorch-CPU fp32 bit for bit. */
+int radet_bbox_overlaps(const float* bboxes1, const float* bboxes2, float* out, int batch, int M, int N, int mode,
+                        int aligned, float eps, void* stream);
+/* TBLRBBoxCoder.encode / decode = bboxes2tblr / tblr2bboxes (radet/core/bbox/coder/tblr_bbox_coder.py:71-172).
+ * normalizer4 (host): the 4 normalisation factors (a scalar normalizer repeated); decode clamps to
+ * [0, max_w] x [0, max_h] when clip != 0 (clip_border and max_shape given). */
+int radet_tblr_encode(const float* priors, const float* gts, float* out, int n, const float* normalizer4,
+                      int normalize_by_wh, void* stream);
+int radet_tblr_decode(const float* priors, const float* tblr, float* out, int n, const float* normalizer4,
+                      int normalize_by_wh, float max_h, float max_w, int clip, void* stream);
+/* Elementwise losses with `weight_reduce_loss` semantics (radet/models/losses/utils.py:24-51).  Forward: optional
+ * loss_elem = loss * weight * elem_scale per element, optional partials[radet_loss_partials(n_elem)] = per-workgroup sums that
+ * radet_loss_finalize adds in a fixed order: out[0] = sum / avg_factor[0] (device scalar, may be NULL) * scale.
+ * weight_cols: 0 none, 1 per row, C per element.  Backward: d(input) = dloss/dinput * weight * g with
+ * g = grad_elem[i] * scale (reduction 'none') or grad_scalar[0] * scale / avg_factor[0] (reduced); grad_elem,
+ * grad_scalar, avg_factor may each be NULL.
+ *   sigmoid focal  : mmcv.ops.sigmoid_focal_loss as wrapped by radet/models/losses/focal_loss.py:44-86 (target = class
+ *                    index per row, anything outside [0, C) = background)
+ *   bce with logits: radet/models/losses/cross_entropy_loss.py:57-92 (use_sigmoid=True), float targets [N, C]
+ *   giou           : radet/models/losses/iou_loss.py:82-98, boxes [N, 4], weight [N] or NULL, gradient w.r.t. pred */
+int radet_loss_partials(size_t n_elem);
+int radet_loss_finalize(const float* partials, int npartials, const float* avg_factor, float scale, float* out,
+                        void* stream);
+int radet_sigmoid_focal_loss(const float* logits, const int64_t* target, const float* weight, int weight_cols, size_t N,
+                             int C, float gamma, float alpha, float* loss_elem, float elem_scale, float* partials,
+                             void* stream);
+int radet_sigmoid_focal_loss_bwd(const float* logits, const int64_t* target, const float* weight, int weight_cols, size_t N,
+                                 int C, float gamma, float alpha, const float* grad_elem, const float* grad_scalar,
+                                 const float* avg_factor, float scale, float* dlogits, void* stream);
+int radet_bce_logits_loss(const float* logits, const float* target, const float* weight, int weight_cols, size_t N, int C,
+                          float* loss_elem, float elem_scale, float* partials, void* stream);
+int radet_bce_logits_loss_bwd(const float* logits, const float* target, const float* weight, int weight_cols, size_t N,
+                              int C, const float* grad_elem, const float* grad_scalar, const float* avg_factor, float scale,
+                              float* dlogits, void* stream);
+int radet_giou_loss(const float* pred, const float* target, const float* weight, size_t N, float eps, float* loss_elem,
+                    float elem_scale, float* partials, void* stream);
+int radet_giou_loss_bwd(const float* pred, const float* target, const float* weight, size_t N, float eps,
+                        const float* grad_elem, const float* grad_scalar, const float* avg_factor, float scale, float* dpred,
+                        void* stream);
+/* multiclass_nms' score filter (radet/core/post_processing/bbox_nms.py:54-56): idx[0..count) = ascending indices i
+ * with scores[i] > thr (torch.nonzero order); one workgroup, ordered ballot-prefix compaction. */
+int radet_threshold_compact(const float* scores, size_t n, float thr, int64_t* idx, int* count, void* stream);
 
 /* ---- anchors (core/anchor/anchor_generator.py:206-271): [sum h*w, 4], centre (j*stride, i*stride), side 8*stride */
 int radet_grid_anchors(float* out, const int* level_desc, int nlvl, int octave_base_scale, void* stream);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "radet_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "radet_head_loss_ws_ints": (_i, [_i]),
     "radet_head_loss": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _i, _p,
-                             _i, _p, _i, _p, _p, _p, _p, _p]),
+                             _i, _p, _i, _p, _p, _p, _i, _p, _p]),
     "radet_scale_relu": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "radet_decode_ws_bytes": (_sz, [_i, _i, _i]),
     "radet_decode_candidates": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -70,6 +70,18 @@ SIGNATURES = {
     "radet_mask_max": (_i, [_p, _p, _i, _sz, _p]),
     "radet_mask_transform": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_grid_anchors": (_i, [_p, _p, _i, _i, _p]),
+    "radet_bbox_overlaps": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "radet_tblr_encode": (_i, [_p, _p, _p, _i, _p, _i, _p]),
+    "radet_tblr_decode": (_i, [_p, _p, _p, _i, _p, _i, _f, _f, _i, _p]),
+    "radet_loss_partials": (_i, [_sz]),
+    "radet_loss_finalize": (_i, [_p, _i, _p, _f, _p, _p]),
+    "radet_sigmoid_focal_loss": (_i, [_p, _p, _p, _i, _sz, _i, _f, _f, _p, _f, _p, _p]),
+    "radet_sigmoid_focal_loss_bwd": (_i, [_p, _p, _p, _i, _sz, _i, _f, _f, _p, _p, _p, _f, _p, _p]),
+    "radet_bce_logits_loss": (_i, [_p, _p, _p, _i, _sz, _i, _p, _f, _p, _p]),
+    "radet_bce_logits_loss_bwd": (_i, [_p, _p, _p, _i, _sz, _i, _p, _p, _p, _f, _p, _p]),
+    "radet_giou_loss": (_i, [_p, _p, _p, _sz, _f, _p, _f, _p, _p]),
+    "radet_giou_loss_bwd": (_i, [_p, _p, _p, _sz, _f, _p, _p, _p, _f, _p, _p]),
+    "radet_threshold_compact": (_i, [_p, _sz, _f, _p, _p, _p]),
     "radet_sqnorm_partials": (_i, [_p, _sz, _p, _i, _p]),
     "radet_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _i, _p, _p]),
 }

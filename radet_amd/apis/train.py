@@ -41,12 +41,61 @@ class OneCycleLR:
         return self._anneal(self.max_lr, self.min_lr, (step - self.up_end) / (self.down_end - self.up_end))
 
 
+def optimizer_state_dict(model, runtime):
+    """The fused AdamW's state in `torch.optim.AdamW.state_dict()` format ({state, param_groups}; parameter index =
+    position in `model.parameters()`, what mmcv's `build_optimizer` hands to the optimizer), so checkpoints written
+    here resume under the reference's runner and vice versa."""
+    st = runtime.opt_state
+    flat = runtime.flat
+    names = [n for n, _ in model.named_parameters()]
+    state = {}
+    for i, n in enumerate(names):
+        if n in flat.offsets:
+            o, k = flat.offsets[n], flat.p[n].numel()
+            state[i] = dict(step=torch.tensor(float(runtime.step_count)),
+                            exp_avg=st["m"][o:o + k].view(flat.p[n].shape).cpu().clone(),
+                            exp_avg_sq=st["v"][o:o + k].view(flat.p[n].shape).cpu().clone())
+    group = dict(lr=st["lr"], betas=tuple(st["betas"]), eps=st["eps"], weight_decay=st["wd"], amsgrad=False,
+                 params=list(range(len(names))))
+    return dict(state=state, param_groups=[group])
+
+
+def load_optimizer_state_dict(model, runtime, osd):
+    """Accepts the torch / mmcv format above and the flat-arena format of earlier checkpoints of this package."""
+    st = runtime.opt_state
+    if "state" in osd and "param_groups" in osd:
+        flat = runtime.flat
+        names = [n for n, _ in model.named_parameters()]
+        order = [i for g in osd["param_groups"] for i in g["params"]]
+        if len(order) != len(names):
+            raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(names)}")
+        step = 0
+        for pos, key in enumerate(order):
+            entry = osd["state"].get(key)
+            n = names[pos]
+            if entry is None or n not in flat.offsets:
+                continue
+            o, k = flat.offsets[n], flat.p[n].numel()
+            st["m"][o:o + k].copy_(entry["exp_avg"].reshape(-1))
+            st["v"][o:o + k].copy_(entry["exp_avg_sq"].reshape(-1))
+            step = max(step, int(float(entry["step"])))
+        runtime.step_count = step
+    elif "step" in osd:                                   # flat arenas (round-1 checkpoints of this package)
+        if osd["exp_avg"].numel() != st["m"].numel():
+            raise ValueError("flat optimizer state does not match this model's parameter arena")
+        runtime.step_count = int(osd["step"])
+        st["m"].copy_(osd["exp_avg"])
+        st["v"].copy_(osd["exp_avg_sq"])
+    else:
+        raise KeyError("unrecognised optimizer state: expected torch's {state, param_groups} or {step, exp_avg, exp_avg_sq}")
+
+
 def save_checkpoint(model, path, meta=None, runtime=None):
-    """mmcv-style checkpoint: dict(meta=..., state_dict=..., optimizer=...) with reference parameter names."""
+    """mmcv-style checkpoint: dict(meta=..., state_dict=..., optimizer=...) with reference parameter names; the
+    optimizer entry is `torch.optim.AdamW.state_dict()`-compatible."""
     ckpt = dict(meta=dict(meta or {}), state_dict={k: v.detach().cpu() for k, v in model.state_dict().items()})
     if runtime is not None and runtime.opt_state is not None:
-        st = runtime.opt_state
-        ckpt["optimizer"] = dict(step=runtime.step_count, exp_avg=st["m"].cpu(), exp_avg_sq=st["v"].cpu())
+        ckpt["optimizer"] = optimizer_state_dict(model, runtime)
     torch.save(ckpt, path)
     return path
 
@@ -57,9 +106,9 @@ def load_checkpoint(model, path, strict=False, runtime=None):
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     missing = model.load_state_dict(sd, strict=strict)      # copies in place: parameters stay in the flat arena
     if runtime is not None and "optimizer" in ckpt and runtime.opt_state is not None:
-        runtime.step_count = int(ckpt["optimizer"]["step"])
-        runtime.opt_state["m"].copy_(ckpt["optimizer"]["exp_avg"])
-        runtime.opt_state["v"].copy_(ckpt["optimizer"]["exp_avg_sq"])
+        load_optimizer_state_dict(model, runtime, ckpt["optimizer"])
+    if runtime is not None:
+        runtime.sync_replicas()                              # data-parallel: every rank continues from rank 0's state
     return ckpt.get("meta", {}), missing
 
 
@@ -88,9 +137,7 @@ def train_detector(model, batches, cfg, max_iters=None, log=print, checkpoint_pa
     clip = cfg.get("optimizer_config", {}).get("grad_clip") or {}
     rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
                       max_norm=float(clip.get("max_norm", 0.0)))
-    head = model.bbox_head
-    rt.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
-                           lbw=float(head.loss_bbox.loss_weight))
+    rt.set_loss_from_head(model.bbox_head)
     lc = cfg.lr_config
     sched = OneCycleLR(lc.max_lr, lc.total_steps, pct_start=lc.get("pct_start", 0.3),
                        anneal_strategy=lc.get("anneal_strategy", "cos"))

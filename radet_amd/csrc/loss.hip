@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void pos_loss_kernel(const float* __restrict__
                                                        float* __restrict__ losses, float* __restrict__ dreg_u,
                                                        int dreg_ld, float* __restrict__ diou, int diou_ld,
                                                        float* __restrict__ dscales, const int* __restrict__ ws,
-                                                       int n_focal_partials) {
+                                                       int n_focal_partials, int postact) {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const int P = ws[0];
@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void pos_loss_kernel(const float* __restrict__
             const float4 u = *reinterpret_cast<const float4*>(reg_u + (size_t)r * 4);
             // prediction (top, bottom, left, right) after Scale + ReLU
             const float v0 = u.x * sc, v1 = u.y * sc, v2 = u.z * sc, v3 = u.w * sc;
-            const float p0 = fmaxf(v0, 0.f), p1 = fmaxf(v1, 0.f), p2 = fmaxf(v2, 0.f), p3 = fmaxf(v3, 0.f);
+            const float p0 = postact ? v0 : fmaxf(v0, 0.f), p1 = postact ? v1 : fmaxf(v1, 0.f);
+            const float p2 = postact ? v2 : fmaxf(v2, 0.f), p3 = postact ? v3 : fmaxf(v3, 0.f);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
             if (g > 0) {
                 const float* gb = gt_boxes + (size_t)(gt_off[ri.n] + (int)g - 1) * 4;
@@ -281,8 +282,10 @@ __global__ __launch_bounds__(256) void pos_loss_kernel(const float* __restrict__
                 // decode backward: top<-y1(-), bottom<-y2, left<-x1(-), right<-x2 ; times normalizer*size
                 const float k8 = 0.125f * hw8;
                 const float gp0 = -gy1 * k8, gp1 = gy2 * k8, gp2 = -gx1 * k8, gp3 = gx2 * k8;
-                const float gv0 = p0 > 0.f ? gp0 : 0.f, gv1 = p1 > 0.f ? gp1 : 0.f;
-                const float gv2 = p2 > 0.f ? gp2 : 0.f, gv3 = p3 > 0.f ? gp3 : 0.f;
+                // postact: reg_u already is the head's bbox_pred (after Scale + ReLU, the tensor RADetHead.loss receives),
+                // so the gradient is taken w.r.t. that tensor and the ReLU mask does not apply
+                const float gv0 = (postact || p0 > 0.f) ? gp0 : 0.f, gv1 = (postact || p1 > 0.f) ? gp1 : 0.f;
+                const float gv2 = (postact || p2 > 0.f) ? gp2 : 0.f, gv3 = (postact || p3 > 0.f) ? gp3 : 0.f;
                 float4 du;
                 du.x = gv0 * sc; du.y = gv1 * sc; du.z = gv2 * sc; du.w = gv3 * sc;
                 *reinterpret_cast<float4*>(dreg_u + (size_t)r * dreg_ld) = du;
@@ -351,8 +354,8 @@ extern "C" int radet_head_loss(const float* cls, const float* reg_u, const float
                                const float* pw, const int* level_desc, int nlvl, int B, int num_classes, float alpha,
                                float gamma, float loss_bbox_weight, float giou_eps, const float* grad_scale,
                                float* losses, float* dcls, int dcls_ld, float* dreg_u, int dreg_ld, float* diou,
-                               int diou_ld, float* dscales, int64_t* labels_out, float* bbox_targets_out, int* ws,
-                               void* stream) {
+                               int diou_ld, float* dscales, int64_t* labels_out, float* bbox_targets_out, int flags,
+                               int* ws, void* stream) {
     LossLevels L;
     int rc = fill_levels(&L, level_desc, nlvl, B);
     if (rc) return rc;
@@ -369,7 +372,7 @@ extern "C" int radet_head_loss(const float* cls, const float* reg_u, const float
     hipLaunchKernelGGL(zero_sparse_kernel, dim3((R + 255) / 256), dim3(256), 0, st, dreg_u, dreg_ld, diou, diou_ld, R);
     hipLaunchKernelGGL(pos_loss_kernel, dim3(1), dim3(256), 0, st, reg_u, iou, scales, gt_boxes, gt_off, p2g, pw, L, B, N,
                        R, loss_bbox_weight, giou_eps, grad_scale, losses, dreg_u, dreg_ld, diou, diou_ld, dscales, ws,
-                       fb);
+                       fb, flags & 1);
     return radet_check_launch();
 }
 

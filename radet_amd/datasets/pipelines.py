@@ -38,7 +38,9 @@ class LabelAssignment:
 
     RNG: the reference consumes NumPy's global legacy RandomState. Here the stream is drawn on the host
     from `rng` (default: the global np.random, whose state is advanced by exactly the number of uniforms
-    the kernel consumed) and the draw itself runs on the GPU -- results are identical for equal seeds."""
+    the kernel consumed) and the draw itself runs on the GPU -- results are identical for equal seeds.  Images that
+    share one RNG object are assigned one after the other so that each continues the stream where the previous
+    one stopped (the reference's sequential consumption); one RandomState per image runs as a single launch."""
 
     def __init__(self, strides=(8, 16, 32, 64, 128),
                  regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF)), anchor_generator_cfg=None,
@@ -62,6 +64,13 @@ class LabelAssignment:
         np.random.RandomState (or None -> global). Returns (p2g i64[B,N], pw f32[B,N]) device tensors."""
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B = len(gt_bboxes)
+        rngs = list(rngs) if rngs is not None else [None] * B
+        if B > 1 and len({id(r) for r in rngs}) < B:
+            # several images share one RNG object (e.g. the global np.random, as in the reference's loader): image i
+            # must start where image i-1 stopped in that stream, which is only known after i-1 has been assigned ->
+            # one launch per image, in order.  Distinct RandomStates per image (the fast path below) need no ordering.
+            outs = [self.assign_batch([gt_bboxes[i]], [masks[i]], img_shape, rngs=[rngs[i]], device=dev) for i in range(B)]
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         H, W = int(img_shape[0]), int(img_shape[1])
         lv = self._levels(H, W)
         N = lv.rows
@@ -76,7 +85,6 @@ class LabelAssignment:
         else:
             mk = torch.zeros(1, H, W, dtype=torch.uint8, device=dev)
         U = self.uniform_budget
-        rngs = rngs or [None] * B
         states, u = [], np.empty((B, U), np.float64)
         for i, r in enumerate(rngs):
             r = np.random if r is None else r

@@ -109,6 +109,12 @@ class Engine:
 
     def _build_layers(self):
         fs = self.frozen_stages
+        if fs < 0:
+            # the reference trains conv1 / bn1 when frozen_stages = -1 (resnet.py:572-588); the stem has no
+            # weight-gradient / max-pool backward kernels here, and silently leaving its gradients at zero would let
+            # AdamW's weight decay shrink the stem
+            raise NotImplementedError("ResNet(frozen_stages=-1) (trainable stem) is not implemented on MI355X: every "
+                                      "RADet config freezes the stem (frozen_stages >= 0; the BOP configs use 1)")
         self.stem = self._add(Conv("backbone.conv1", 3, 64, 7, 2, 3, bn="backbone.bn1", trainable=fs < 0, dgrad=False))
         self.stages = []
         inpl = 64

@@ -473,11 +473,11 @@ def head_loss_ws_ints(R):
 
 def head_loss(cls, reg_u, iou, scales, gt_boxes, gt_labels, gt_off, p2g, pw, ldesc, nlvl, B, num_classes, alpha, gamma,
               lbw, giou_eps, grad_scale, losses, dcls, dcls_ld, dreg, dreg_ld, diou, diou_ld, dscales, ws,
-              labels_out=None, tgt_out=None):
+              labels_out=None, tgt_out=None, flags=0):
     _lib.call("radet_head_loss", _ptr(cls), _ptr(reg_u), _ptr(iou), _ptr(scales), _ptr(gt_boxes), _ptr(gt_labels),
               _ptr(gt_off), _ptr(p2g), _ptr(pw), ldesc, nlvl, B, num_classes, alpha, gamma, lbw, giou_eps,
               _ptr(grad_scale), _ptr(losses), _ptr(dcls), dcls_ld, _ptr(dreg), dreg_ld, _ptr(diou), diou_ld,
-              _ptr(dscales), _ptr(labels_out), _ptr(tgt_out), _ptr(ws), _stream())
+              _ptr(dscales), _ptr(labels_out), _ptr(tgt_out), flags, _ptr(ws), _stream())
 
 
 def scale_relu(reg_u, scales, out, ldesc, nlvl, B):
@@ -486,6 +486,75 @@ def scale_relu(reg_u, scales, out, ldesc, nlvl, B):
 
 def grid_anchors(out, ldesc, nlvl, base_scale=8):
     _lib.call("radet_grid_anchors", _ptr(out), ldesc, nlvl, base_scale, _stream())
+
+
+# ---------------------------------------------------------------------- stand-alone box / loss operators
+OVERLAP_MODES = dict(iou=0, iof=1, giou=2)
+
+
+def bbox_overlaps(b1, b2, out, batch, M, N, mode, aligned, eps):
+    _lib.call("radet_bbox_overlaps", _ptr(b1), _ptr(b2), _ptr(out), batch, M, N, OVERLAP_MODES[mode], int(aligned), eps,
+              _stream())
+
+
+def _norm4(normalizer):
+    v = [float(normalizer)] * 4 if isinstance(normalizer, (int, float)) else [float(x) for x in normalizer]
+    assert len(v) == 4, "Normalizer must have length = 4"
+    return (C.c_float * 4)(*v)
+
+
+def tblr_encode(priors, gts, out, normalizer, normalize_by_wh=True):
+    _lib.call("radet_tblr_encode", _ptr(priors), _ptr(gts), _ptr(out), priors.shape[0], _norm4(normalizer),
+              int(normalize_by_wh), _stream())
+
+
+def tblr_decode(priors, tblr, out, normalizer, normalize_by_wh=True, max_shape=None, clip_border=True):
+    clip = bool(clip_border and max_shape is not None)
+    mh, mw = (float(max_shape[0]), float(max_shape[1])) if clip else (0.0, 0.0)
+    _lib.call("radet_tblr_decode", _ptr(priors), _ptr(tblr), _ptr(out), priors.shape[0], _norm4(normalizer),
+              int(normalize_by_wh), mh, mw, int(clip), _stream())
+
+
+def loss_partials(n_elem):
+    return _lib.load().radet_loss_partials(n_elem)
+
+
+def loss_finalize(partials, avg_factor, scale, out):
+    _lib.call("radet_loss_finalize", _ptr(partials), partials.numel(), _ptr(avg_factor), scale, _ptr(out), _stream())
+
+
+def sigmoid_focal_loss(x, target, weight, wcols, N, Cc, gamma, alpha, elem, partials, elem_scale=1.0):
+    _lib.call("radet_sigmoid_focal_loss", _ptr(x), _ptr(target), _ptr(weight), wcols, C.c_size_t(N), Cc, gamma, alpha,
+              _ptr(elem), elem_scale, _ptr(partials), _stream())
+
+
+def sigmoid_focal_loss_bwd(x, target, weight, wcols, N, Cc, gamma, alpha, grad_elem, grad_scalar, avg_factor, scale, dx):
+    _lib.call("radet_sigmoid_focal_loss_bwd", _ptr(x), _ptr(target), _ptr(weight), wcols, C.c_size_t(N), Cc, gamma, alpha,
+              _ptr(grad_elem), _ptr(grad_scalar), _ptr(avg_factor), scale, _ptr(dx), _stream())
+
+
+def bce_logits_loss(x, target, weight, wcols, N, Cc, elem, partials, elem_scale=1.0):
+    _lib.call("radet_bce_logits_loss", _ptr(x), _ptr(target), _ptr(weight), wcols, C.c_size_t(N), Cc, _ptr(elem),
+              elem_scale, _ptr(partials), _stream())
+
+
+def bce_logits_loss_bwd(x, target, weight, wcols, N, Cc, grad_elem, grad_scalar, avg_factor, scale, dx):
+    _lib.call("radet_bce_logits_loss_bwd", _ptr(x), _ptr(target), _ptr(weight), wcols, C.c_size_t(N), Cc, _ptr(grad_elem),
+              _ptr(grad_scalar), _ptr(avg_factor), scale, _ptr(dx), _stream())
+
+
+def giou_loss(pred, target, weight, N, eps, elem, partials, elem_scale=1.0):
+    _lib.call("radet_giou_loss", _ptr(pred), _ptr(target), _ptr(weight), C.c_size_t(N), eps, _ptr(elem), elem_scale, _ptr(partials),
+              _stream())
+
+
+def giou_loss_bwd(pred, target, weight, N, eps, grad_elem, grad_scalar, avg_factor, scale, dpred):
+    _lib.call("radet_giou_loss_bwd", _ptr(pred), _ptr(target), _ptr(weight), C.c_size_t(N), eps, _ptr(grad_elem),
+              _ptr(grad_scalar), _ptr(avg_factor), scale, _ptr(dpred), _stream())
+
+
+def threshold_compact(scores, thr, idx, count):
+    _lib.call("radet_threshold_compact", _ptr(scores), C.c_size_t(scores.numel()), thr, _ptr(idx), _ptr(count), _stream())
 
 
 def sqnorm_partials(g, n, partials):

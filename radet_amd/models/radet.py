@@ -40,11 +40,44 @@ class RADet(nn.Module):
         return self.bbox_head is not None
 
     def init_weights(self, pretrained=None):
-        if pretrained is not None and not str(pretrained).startswith("torchvision://"):
-            sd = torch.load(pretrained, map_location="cpu")
-            sd = sd.get("state_dict", sd)
-            self.load_state_dict(sd, strict=False)
-        # 'torchvision://resnet50' needs network access; weights then come from load_state_dict by the caller
+        """single_stage.py:36-52 -> `backbone.init_weights(pretrained)` (resnet.py:590-599): the checkpoint is loaded into
+        the BACKBONE (non-strict, like mmcv's load_checkpoint).  `torchvision://<name>` resolves offline to
+        $RADET_PRETRAINED_DIR/<name>.pth or torch-hub's cache (~/.cache/torch/hub/checkpoints/<name>-*.pth); the
+        reference would download it, here a missing file is an error instead of a silent random init."""
+        if pretrained is None:
+            return
+        import glob
+        import os
+        path = str(pretrained)
+        if path.startswith("torchvision://"):
+            name = path[len("torchvision://"):]
+            cands = []
+            if os.environ.get("RADET_PRETRAINED_DIR"):
+                cands += [os.path.join(os.environ["RADET_PRETRAINED_DIR"], name + ext) for ext in (".pth", ".pt")]
+            hub = os.path.join(os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub", "checkpoints")
+            cands += sorted(glob.glob(os.path.join(hub, name + "-*.pth")))
+            found = [c for c in cands if os.path.exists(c)]
+            if not found:
+                raise FileNotFoundError(
+                    f"pretrained={pretrained!r}: no local copy (looked for $RADET_PRETRAINED_DIR/{name}.pth and "
+                    f"{hub}/{name}-*.pth; there is no network to download it).  Pass pretrained=None for a random init.")
+            path = found[0]
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        if any(k.startswith("backbone.") for k in sd):           # a detector checkpoint: take its backbone
+            sd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+        own = self.backbone.state_dict()
+        hit = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+        if not hit:
+            raise RuntimeError(f"pretrained={pretrained!r}: none of its {len(sd)} entries matches a backbone parameter "
+                               "(expected torchvision-style keys such as 'conv1.weight', 'layer1.0.conv1.weight')")
+        self.backbone.load_state_dict(hit, strict=False)
+        missing = [k for k in own if k not in hit and not k.endswith("num_batches_tracked")]
+        if missing:
+            import warnings
+            warnings.warn(f"pretrained={pretrained!r}: {len(missing)} backbone entries not in the checkpoint "
+                          f"(e.g. {missing[:3]})")
 
     # ------------------------------------------------------------------ runtime
     def runtime(self, math=None):

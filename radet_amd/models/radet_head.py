@@ -75,7 +75,8 @@ class RADetHead(nn.Module):
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, points_to_gt_index=None, points_weight=None,
                       gt_bboxes_ignore=None, proposal_cfg=None, **kwargs):
-        return self._rt().head_forward_train_api(x, img_metas, gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+        return self._rt().head_forward_train_api(x, img_metas, gt_bboxes, gt_labels, points_to_gt_index, points_weight,
+                                                 proposal_cfg=proposal_cfg)
 
     def loss(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, gt_labels, points_to_gt_index, points_weight,
              img_metas, gt_bboxes_ignore=None):
@@ -83,7 +84,8 @@ class RADetHead(nn.Module):
                                         points_weight)
 
     def get_bboxes(self, cls_scores, bbox_preds, centernesses, img_metas, cfg=None, rescale=False, with_nms=True):
-        return self._rt().get_bboxes_api(cls_scores, bbox_preds, centernesses, img_metas, cfg or self.test_cfg, rescale)
+        return self._rt().get_bboxes_api(cls_scores, bbox_preds, centernesses, img_metas, cfg or self.test_cfg, rescale,
+                                         with_nms)
 
     def get_anchors(self, featmap_sizes, img_metas, device="cuda"):
         anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)

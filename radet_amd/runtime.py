@@ -168,6 +168,24 @@ class DetectorRuntime:
         self.buckets = compute_buckets(self.flat, [c.name for c in self.engine.convs],
                                        [c.trainable for c in self.engine.convs])
         self.reducer = None
+        self.sync_replicas()       # data-parallel replicas start from rank 0's parameters (DDP's initial broadcast)
+
+    def sync_replicas(self, src=0):
+        """Broadcast the parameter arenas (trainable + frozen / BN statistics) and, once it exists, the optimizer
+        state from rank `src`: what wrapping the model in MMDistributedDataParallel does at construction in the
+        reference (radet/apis/train.py:73-81) and what a checkpoint loaded on one rank needs.  Collective: every rank
+        of the default process group must call it.  No-op without an initialised group / with a single rank."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return False
+        arenas = [self.flat.params, self.flat.frozen]
+        if self.opt_state is not None:
+            arenas += [self.opt_state["m"], self.opt_state["v"]]
+        for t in arenas:
+            dist.broadcast(t, src)
+        step = torch.tensor([self.step_count], dtype=torch.int64, device=self.dev)
+        dist.broadcast(step, src)
+        self.step_count = int(step.item())
+        return True
 
     # ------------------------------------------------------------------ inputs
     def pack_targets(self, gt_bboxes, gt_labels, points_to_gt_index, points_weight):
@@ -201,8 +219,19 @@ class DetectorRuntime:
         P = e.neck_forward(feats)
         return e.head_forward(P)
 
+    loss_hparams = None
+    loss_weights = None      # device f32[3] = (loss_cls.loss_weight, 1, loss_iou.loss_weight) when either differs from 1
+
+    def set_loss_from_head(self, head):
+        """Take focal alpha / gamma and the three loss weights from the head's loss modules (config values)."""
+        self.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
+                                 lbw=float(head.loss_bbox.loss_weight))
+        wc, wi = float(head.loss_cls.loss_weight), float(head.loss_iou.loss_weight)
+        self.loss_weights = None if (wc == 1.0 and wi == 1.0) else torch.tensor([wc, 1.0, wi], device=self.dev)
+        return self
+
     def loss(self, tg, grad_scale=None, labels_out=None, tgt_out=None):
-        hp = getattr(self, "loss_hparams", None) or dict(alpha=0.25, gamma=2.0, lbw=2.0)
+        hp = self.loss_hparams or dict(alpha=0.25, gamma=2.0, lbw=2.0)
         return self.engine.loss(tg["boxes"], tg["labels"], tg["off"], tg["p2g"], tg["pw"], grad_scale=grad_scale,
                                 labels_out=labels_out, tgt_out=tgt_out, **hp)
 
@@ -210,26 +239,9 @@ class DetectorRuntime:
         """Reverse program. After each parameter group's wgrads are done its slabs are reduced /
         un-folded into the gradient arena and `bucket_hook(bucket)` may start its all-reduce."""
         e = self.engine
-        table, sz = e.table, torch.tensor([], dtype=torch.uint8).element_size()
-        import ctypes as C
-        desc_bytes = C.sizeof(_lib.RadetConvDesc)
 
         def unfold(bucket):
-            a, b = bucket["convs"]
-            if e.use_streams:
-                # the slab reduction follows the bucket's weight-gradient GEMMs on the side stream, off the
-                # critical path of the dgrad chain; the all-reduce hook keys off the side stream too
-                side = e._side()
-                e.side_collect()
-                e._fork(side)
-                with torch.cuda.stream(side):
-                    K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
-                    if bucket_hook is not None:
-                        bucket_hook(bucket)
-            else:
-                K.unfold_grads(table[a * desc_bytes:], b - a, e.max_cout)
-                if bucket_hook is not None:
-                    bucket_hook(bucket)
+            self._unfold_bucket(bucket, bucket_hook)
 
         bk = {b["prefix"]: b for b in self.buckets}
         dP = e.head_backward()
@@ -238,7 +250,27 @@ class DetectorRuntime:
         unfold(bk["neck."])
         e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk[f"backbone.layer{li + 1}."]))
         e.join_side()                           # gradients complete on the current stream from here on
-        del sz
+
+    def _unfold_bucket(self, bucket, bucket_hook=None):
+        """Reduce / un-fold the weight-gradient slabs of one bucket's convs into the gradient arena."""
+        import ctypes as C
+        e = self.engine
+        desc_bytes = C.sizeof(_lib.RadetConvDesc)
+        a, b = bucket["convs"]
+        if e.use_streams:
+            # the slab reduction follows the bucket's weight-gradient GEMMs on the side stream, off the
+            # critical path of the dgrad chain; the all-reduce hook keys off the side stream too
+            side = e._side()
+            e.side_collect()
+            e._fork(side)
+            with torch.cuda.stream(side):
+                K.unfold_grads(e.table[a * desc_bytes:], b - a, e.max_cout)
+                if bucket_hook is not None:
+                    bucket_hook(bucket)
+        else:
+            K.unfold_grads(e.table[a * desc_bytes:], b - a, e.max_cout)
+            if bucket_hook is not None:
+                bucket_hook(bucket)
 
     # ------------------------------------------------------------------ optimiser
     def init_optimizer(self, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0):
@@ -263,7 +295,7 @@ class DetectorRuntime:
         still running; the mean (1/world) is folded into the fused clip+AdamW kernel."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.forward(img)
-        self.loss(tg)
+        self.loss(tg, grad_scale=self.loss_weights)
         # a 1-rank process group still exercises the bucketed exchange when forced (single-GPU test of the RCCL path)
         use_reducer = world > 1 or (world == 1 and dist.is_available() and dist.is_initialized()
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
@@ -277,6 +309,8 @@ class DetectorRuntime:
         else:
             self.backward()
         self.optimizer_step(lr=lr, grad_div=float(world))
+        if self.loss_weights is not None:       # reported values carry the configured loss weights, like the reference's
+            return self.engine.losses * self.loss_weights
         return self.engine.losses
 
 
@@ -307,8 +341,7 @@ def _losses_autograd(self, img, gt_bboxes, gt_labels, points_to_gt_index, points
     det = self.owner()
     head = det.bbox_head
     tg = self.pack_targets(gt_bboxes, gt_labels, points_to_gt_index, points_weight)
-    self.loss_hparams = dict(alpha=float(head.loss_cls.alpha), gamma=float(head.loss_cls.gamma),
-                             lbw=float(head.loss_bbox.loss_weight))
+    self.set_loss_from_head(head)
     weights = torch.tensor([head.loss_cls.loss_weight, 1.0, head.loss_iou.loss_weight], device=self.dev)
     named = dict(det.named_parameters())
     plist = [named[n] for n in self.flat.train_names]
@@ -372,20 +405,23 @@ def _meta_tensors(self, img_metas, rescale):
     return hw, sf
 
 
-def _post_launch(self, hw, sf, test_cfg):
+def _post_launch(self, hw, sf, test_cfg, head_out=None):
     """Device part of the post-processing (no host synchronisation, no host->device copies: capturable in a hipGraph):
-    decode + NMS launches on the engine's head outputs.  Returns the output tensors (boxes, scores, labels, counts)."""
+    decode + NMS launches on the engine's head outputs (or on `head_out` = dict(cls, reg, iou, scales, ldesc, nlvl, B,
+    level_hw) row buffers handed in through the module API).  Returns the output tensors (boxes, scores, labels, counts)."""
     e = self.engine
-    B = e.B
-    b = e.buf
-    nlvl = e.nlvl
+    if head_out is None:
+        head_out = dict(cls=e.buf["cls"], reg=e.buf["reg_u"], iou=e.buf["iou"], scales=e.scales_tensor(), ldesc=e.ldesc,
+                        nlvl=e.nlvl, B=e.B, level_hw=e.plv.hw)
+    ho = head_out
+    B, nlvl = ho["B"], ho["nlvl"]
     nms_pre = int(test_cfg.get("nms_pre", -1))
     if nms_pre <= 0:
-        nms_pre = max(h * w for h, w in e.plv.hw) * self.num_classes
+        nms_pre = max(h * w for h, w in ho["level_hw"]) * self.num_classes
     cap = nlvl * nms_pre
     if cap > 8192:
         raise NotImplementedError(f"nms_pre={nms_pre}: more than 8192 candidates per image exceed the on-chip NMS sort")
-    key = ("post", B, nms_pre)
+    key = ("post", B, nlvl, nms_pre)
     if getattr(self, "_post_key", None) != key:
         dev = self.dev
         self._post = dict(
@@ -397,7 +433,7 @@ def _post_launch(self, hw, sf, test_cfg):
             aux0=torch.zeros(B, cap, dtype=torch.long, device=dev), aux1=torch.zeros(B, cap, dtype=torch.long, device=dev))
         self._post_key = key
     p = self._post
-    K.decode_candidates(b["cls"], b["reg_u"], b["iou"], e.scales_tensor(), e.ldesc, nlvl, B, self.num_classes,
+    K.decode_candidates(ho["cls"], ho["reg"], ho["iou"], ho["scales"], ho["ldesc"], nlvl, B, self.num_classes,
                         float(test_cfg["score_thr"]), nms_pre, hw, sf, p["boxes"], p["scores"], p["ctr"], p["labels"],
                         p["count"], p["dws"])
     ncfg = dict(test_cfg["nms"])
@@ -538,3 +574,160 @@ DetectorRuntime._postprocess = _postprocess
 DetectorRuntime.extract_feat_api = _extract_feat_api
 DetectorRuntime.backbone_api = _backbone_api
 DetectorRuntime.head_forward_api = _head_forward_api
+
+
+# ---------------------------------------------------------------------- RADetHead module API (loss / get_bboxes / forward_train)
+def _lists_to_rows(self, tensors, ch):
+    """list of NCHW level tensors -> (Levels, [R, ch] fp32 row buffer in the head's level-major order)"""
+    B = int(tensors[0].shape[0])
+    lv = K.Levels([(int(t.shape[2]), int(t.shape[3])) for t in tensors], B)
+    rows = torch.empty(lv.rows, ch, device=self.dev)
+    for i, t in enumerate(tensors):
+        assert t.shape[0] == B and t.shape[1] == ch, (tuple(t.shape), B, ch)
+        r0, r1 = lv.level_rows(i)
+        K.nchw_to_nhwc(t.detach().to(self.dev, torch.float32).contiguous(), rows[r0:r1], B, ch, t.shape[2], t.shape[3])
+    return lv, rows
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """RADetHead.loss on NCHW head outputs (bbox_preds AFTER Scale + ReLU, as the reference passes them):
+    fused targets + focal + GIoU + IoU-BCE kernel; backward = the same kernel with the upstream gradients folded in,
+    gradients returned in the inputs' NCHW layout."""
+
+    @staticmethod
+    def forward(ctx, rt, tg, weights, nlv, *tensors):
+        cls, reg, iou = tensors[:nlv], tensors[nlv:2 * nlv], tensors[2 * nlv:]
+        lv, rc = _lists_to_rows(rt, cls, rt.num_classes)
+        _, rr = _lists_to_rows(rt, reg, 4)
+        _, ri = _lists_to_rows(rt, iou, 1)
+        ctx.rt, ctx.tg, ctx.weights, ctx.lv = rt, tg, weights, lv
+        ctx.rows = (rc, rr, ri)
+        ctx.srcs = [t.device for t in tensors]
+        losses = _HeadLossFn.run(ctx, None)[0]
+        out = losses * weights
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def run(ctx, grad_scale):
+        rt, tg, lv = ctx.rt, ctx.tg, ctx.lv
+        rc, rr, ri = ctx.rows
+        R, C = lv.rows, rt.num_classes
+        ldesc, nlvl = K.level_desc(lv, rt.strides)
+        dev = rt.dev
+        hp = rt.loss_hparams or dict(alpha=0.25, gamma=2.0, lbw=2.0)
+        losses = torch.zeros(3, device=dev)
+        dcls, dreg, diou = torch.empty(R, C, device=dev), torch.empty(R, 4, device=dev), torch.empty(R, 1, device=dev)
+        ws = torch.zeros(K.head_loss_ws_ints(R), dtype=torch.int32, device=dev)
+        K.head_loss(rc, rr, ri, torch.ones(nlvl, device=dev), tg["boxes"], tg["labels"], tg["off"], tg["p2g"], tg["pw"], ldesc,
+                    nlvl, lv.B, C, hp["alpha"], hp["gamma"], hp["lbw"], 1e-6, grad_scale, losses, dcls, C, dreg, 4, diou, 1,
+                    torch.zeros(nlvl, device=dev), ws, flags=1)
+        return losses, dcls, dreg, diou
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        rt, lv = ctx.rt, ctx.lv
+        gs = (torch.stack([g0.reshape(()), g1.reshape(()), g2.reshape(())]).to(rt.dev, torch.float32) * ctx.weights).contiguous()
+        _, dcls, dreg, diou = _HeadLossFn.run(ctx, gs)
+        grads = []
+        for rows, ch in ((dcls, rt.num_classes), (dreg, 4), (diou, 1)):
+            grads += _rows_to_nchw(rt, rows, lv, ch)
+        return (None, None, None, None) + tuple(g.to(d) for g, d in zip(grads, ctx.srcs))
+
+
+def _head_loss_api(self, cls_scores, bbox_preds, iou_preds, gt_bboxes, gt_labels, points_to_gt_index, points_weight):
+    """RADetHead.loss (radet/models/dense_heads/radet_head.py:173-288): lists of NCHW tensors per level in,
+    dict(loss_cls, loss_bbox, loss_iou) out, differentiable w.r.t. the three input lists."""
+    head = self.owner().bbox_head
+    assert len(cls_scores) == len(bbox_preds) == len(iou_preds)
+    self.set_loss_from_head(head)
+    tg = self.pack_targets(gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+    weights = torch.tensor([head.loss_cls.loss_weight, 1.0, head.loss_iou.loss_weight], device=self.dev)
+    l0, l1, l2 = _HeadLossFn.apply(self, tg, weights, len(cls_scores), *cls_scores, *bbox_preds, *iou_preds)
+    return dict(loss_cls=l0, loss_bbox=l1, loss_iou=l2)
+
+
+def _get_bboxes_api(self, cls_scores, bbox_preds, centernesses, img_metas, cfg, rescale=False, with_nms=True):
+    """ATSSHead.get_bboxes / RADetHead._get_bboxes_single (atss_head.py:325-387, radet_head.py:55-170): NCHW lists
+    -> [(det_bboxes [k, 5], det_labels [k])] per image (device tensors)."""
+    if not with_nms:
+        raise NotImplementedError("get_bboxes(with_nms=False) only feeds test-time augmentation, which is out of scope "
+                                  "(flip=False in the BOP configs)")
+    assert len(cls_scores) == len(bbox_preds) == len(centernesses)
+    with torch.no_grad():
+        lv, rc = _lists_to_rows(self, cls_scores, self.num_classes)
+        _, rr = _lists_to_rows(self, bbox_preds, 4)
+        _, ri = _lists_to_rows(self, centernesses, 1)
+        ldesc, nlvl = K.level_desc(lv, self.strides)
+        # bbox_preds already carry Scale + ReLU: decode with unit scales (relu is idempotent on them)
+        ho = dict(cls=rc, reg=rr, iou=ri, scales=torch.ones(nlvl, device=self.dev), ldesc=ldesc, nlvl=nlvl, B=lv.B,
+                  level_hw=lv.hw)
+        hw, sf = _meta_tensors(self, img_metas, rescale)
+        return _post_collect(self, *_post_launch(self, hw, sf, cfg, head_out=ho))
+
+
+class _HeadTrainFn(torch.autograd.Function):
+    """RADetHead.forward_train on NCHW pyramid features: head forward + fused loss through the engine; backward =
+    the engine's head reverse program (gradients for the head parameters and for the input features)."""
+
+    @staticmethod
+    def forward(ctx, rt, tg, weights, nfeat, *args):
+        feats = args[:nfeat]
+        e = rt.engine
+        B = int(feats[0].shape[0])
+        for i, f in enumerate(feats):
+            r0, r1 = e.plv.level_rows(i)
+            K.nchw_to_nhwc(f.detach().to(rt.dev, torch.float32).contiguous(), e.buf["P"][r0:r1], B, e.feat, f.shape[2], f.shape[3])
+        e.head_forward(e.buf["P"])
+        losses = rt.loss(tg)
+        ctx.rt, ctx.tg, ctx.weights, ctx.nfeat = rt, tg, weights, nfeat
+        ctx.srcs = [f.device for f in feats]
+        ctx.pnames = [n for n in rt.flat.train_names if n.startswith("bbox_head.")]
+        out = losses * weights
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        rt = ctx.rt
+        e = rt.engine
+        gs = (torch.stack([g0.reshape(()), g1.reshape(()), g2.reshape(())]).to(rt.dev, torch.float32) * ctx.weights).contiguous()
+        rt.loss(ctx.tg, grad_scale=gs)
+        dP = e.head_backward()
+        rt._unfold_bucket({b["prefix"]: b for b in rt.buckets}["bbox_head."])
+        e.join_side()
+        dfe = [g.to(d) for g, d in zip(_rows_to_nchw(rt, dP, e.plv, e.feat), ctx.srcs)]
+        return (None, None, None, None) + tuple(dfe) + tuple(rt.flat.g[n].clone() for n in ctx.pnames)
+
+
+def _head_forward_train_api(self, x, img_metas, gt_bboxes, gt_labels, points_to_gt_index, points_weight, proposal_cfg=None):
+    """RADetHead.forward_train (radet_head.py:32-52): x = NCHW P3..P7 -> losses (and proposals with proposal_cfg)."""
+    if gt_labels is None:
+        raise NotImplementedError("RADetHead.forward_train without gt_labels (RPN use) is not on the RADet path")
+    det = self.owner()
+    head = det.bbox_head
+    e = self.engine
+    B = int(x[0].shape[0])
+    hw = [(int(f.shape[2]), int(f.shape[3])) for f in x]
+    shape = (img_metas[0].get("batch_input_shape") or img_metas[0].get("pad_shape")) if img_metas else None
+    H, W = (int(shape[0]), int(shape[1])) if shape is not None else (hw[0][0] * self.strides[0], hw[0][1] * self.strides[0])
+    e.prepare(B, H, W)
+    if list(e.plv.hw) != hw:
+        raise ValueError(f"feature sizes {hw} do not belong to a {H}x{W} input (expected {list(e.plv.hw)})")
+    e.fold()
+    e._await_fold()
+    self.set_loss_from_head(head)
+    tg = self.pack_targets(gt_bboxes, gt_labels, points_to_gt_index, points_weight)
+    weights = torch.tensor([head.loss_cls.loss_weight, 1.0, head.loss_iou.loss_weight], device=self.dev)
+    named = dict(det.named_parameters())
+    plist = [named[n] for n in self.flat.train_names if n.startswith("bbox_head.")]
+    l0, l1, l2 = _HeadTrainFn.apply(self, tg, weights, len(x), *x, *plist)
+    losses = dict(loss_cls=l0, loss_bbox=l1, loss_iou=l2)
+    if proposal_cfg is None:
+        return losses
+    with torch.no_grad():
+        hwt, sf = _meta_tensors(self, img_metas, False)
+        return losses, _post_collect(self, *_post_launch(self, hwt, sf, proposal_cfg))
+
+
+DetectorRuntime.head_loss_api = _head_loss_api
+DetectorRuntime.get_bboxes_api = _get_bboxes_api
+DetectorRuntime.head_forward_train_api = _head_forward_train_api

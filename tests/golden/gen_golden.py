@@ -144,6 +144,102 @@ def gen_ops():
          logits=logits.numpy(), labels=lab.numpy(), focal=focal.numpy())
 
 
+
+# ----------------------------------------------------------------------------- stand-alone ops, second set
+def gen_ops2():
+    """bbox_overlaps corner cases / iof / batch dims / a bigger M x N matrix, TBLR coder with a 4-vector normalizer,
+    and the three loss MODULES (forward values under every reduction + input gradients)."""
+    from radet.models.builder import build_loss
+    g = torch.Generator().manual_seed(77)
+    out = {}
+
+    def rnd_boxes(n, scale=400.0):
+        xy = torch.rand(n, 2, generator=g) * scale
+        wh = torch.rand(n, 2, generator=g) * 150 + 1
+        return torch.cat([xy, xy + wh], 1)
+
+    # overlaps: iof, batch dims, degenerate boxes (zero area, identical, disjoint, touching), big matrix samples
+    a, b = rnd_boxes(37), rnd_boxes(53)
+    out.update(ov_a=a.numpy(), ov_b=b.numpy(), iof_matrix=bbox_overlaps(a, b, mode="iof").numpy(),
+               iof_aligned=bbox_overlaps(a, b[:37], mode="iof", is_aligned=True).numpy())
+    ab, bb = rnd_boxes(2 * 3 * 9).reshape(2, 3, 9, 4), rnd_boxes(2 * 3 * 5).reshape(2, 3, 5, 4)
+    out.update(ovb_a=ab.numpy(), ovb_b=bb.numpy(), ovb_giou=bbox_overlaps(ab, bb, mode="giou").numpy(),
+               ovb_iou_aligned=bbox_overlaps(ab, ab.flip(2), is_aligned=True).numpy())
+    deg = torch.tensor([[10., 10., 10., 10.], [0., 0., 20., 20.], [0., 0., 20., 20.], [20., 0., 40., 20.],
+                        [100., 100., 120., 130.], [5., 5., 5., 30.], [1e-4, 1e-4, 2e-4, 2e-4]])
+    for mode in ("iou", "iof", "giou"):
+        out["deg_" + mode] = bbox_overlaps(deg, deg, mode=mode).numpy()
+        out["deg_al_" + mode] = bbox_overlaps(deg, deg.roll(1, 0), mode=mode, is_aligned=True).numpy()
+    out["deg"] = deg.numpy()
+    A, B = rnd_boxes(700, 600.0), rnd_boxes(1300, 600.0)
+    big = bbox_overlaps(A, B, mode="giou")
+    idx = torch.randint(0, big.numel(), (4096,), generator=g)
+    out.update(big_a=A.numpy(), big_b=B.numpy(), big_idx=idx.numpy(), big_val=big.reshape(-1)[idx].numpy(),
+               big_sum=big.double().sum().numpy(), big_iou_sum=bbox_overlaps(A, B).double().sum().numpy())
+
+    # TBLR with per-side normalizers, normalize_by_wh on / off, clipping
+    from radet.core.bbox.coder.tblr_bbox_coder import bboxes2tblr, tblr2bboxes
+    pri, gts = rnd_boxes(40), rnd_boxes(40)
+    nm = [0.5, 0.25, 2.0, 4.0]
+    enc4 = bboxes2tblr(pri, gts, normalizer=nm)
+    enc_nowh = bboxes2tblr(pri, gts, normalizer=4.0, normalize_by_wh=False)
+    pred = torch.rand(40, 4, generator=g) * 3
+    out.update(t_pri=pri.numpy(), t_gts=gts.numpy(), t_nm=np.asarray(nm, np.float32), t_enc4=enc4.numpy(),
+               t_enc_nowh=enc_nowh.numpy(), t_pred=pred.numpy(),
+               t_dec4=tblr2bboxes(pri, pred, normalizer=nm, max_shape=(300, 350, 3)).numpy(),
+               t_dec_nowh=tblr2bboxes(pri, pred * 20, normalizer=4.0, normalize_by_wh=False).numpy(),
+               t_dec_noclip=tblr2bboxes(pri, pred, normalizer=1 / 8, max_shape=(300, 350, 3), clip_border=False).numpy())
+
+    # loss modules
+    N, C = 150, 21
+    logits = (torch.randn(N, C, generator=g) * 2).requires_grad_(True)
+    lab = torch.randint(0, C + 1, (N,), generator=g)
+    w_row = torch.rand(N, generator=g)
+    w_el = torch.rand(N, C, generator=g)
+    fl = build_loss(dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.5))
+    out.update(f_logits=logits.detach().numpy(), f_labels=lab.numpy(), f_w_row=w_row.numpy(), f_w_el=w_el.numpy())
+
+    def rec(tag, loss, x):
+        x.grad = None
+        (loss.sum() if loss.dim() else loss).backward()
+        out[tag] = loss.detach().numpy()
+        out[tag + "_g"] = x.grad.numpy().copy()
+
+    rec("f_mean", fl(logits, lab), logits)
+    rec("f_sum_wrow", fl(logits, lab, weight=w_row, reduction_override="sum"), logits)
+    rec("f_avg_wel", fl(logits, lab, weight=w_el.reshape(-1), avg_factor=37.5), logits)
+    rec("f_none_wrow", fl(logits, lab, weight=w_row, reduction_override="none"), logits)
+    fl3 = build_loss(dict(type="FocalLoss", use_sigmoid=True, gamma=1.5, alpha=0.4, loss_weight=1.0))
+    rec("f_g15", fl3(logits, lab, weight=w_row, avg_factor=torch.tensor(12.0)), logits)
+
+    M = 90
+    pb = rnd_boxes(M).requires_grad_(True)
+    tb = (pb.detach() + torch.randn(M, 4, generator=g) * 15)
+    tb = torch.cat([torch.min(tb[:, :2], tb[:, 2:] - 1), tb[:, 2:]], 1)
+    pb.data[:5] = tb[:5]                       # identical boxes: the max / min tie branches of the gradient
+    pb.data[5:8, :2] = tb[5:8, 2:] + 30        # disjoint
+    pb.data[5:8, 2:] = tb[5:8, 2:] + 60
+    gw = torch.rand(M, generator=g)
+    gl = build_loss(dict(type="GIoULoss", loss_weight=2.0))
+    out.update(g_pred=pb.detach().numpy(), g_tgt=tb.numpy(), g_w=gw.numpy())
+    rec("g_mean", gl(pb, tb), pb)
+    rec("g_avg_w", gl(pb, tb, weight=gw, avg_factor=gw.sum()), pb)
+    rec("g_none_w", gl(pb, tb, weight=gw, reduction_override="none"), pb)
+    rec("g_sum", gl(pb, tb, reduction_override="sum"), pb)
+
+    ce = build_loss(dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0))
+    x1 = (torch.randn(M, generator=g) * 2).requires_grad_(True)
+    t1 = torch.rand(M, generator=g)
+    out.update(c_x=x1.detach().numpy(), c_t=t1.numpy())
+    rec("c_avg_w", ce(x1, t1, weight=gw, avg_factor=gw.sum()), x1)
+    rec("c_mean", ce(x1, t1), x1)
+    rec("c_none", ce(x1, t1, weight=gw, reduction_override="none"), x1)
+    x2 = (torch.randn(N, C, generator=g)).requires_grad_(True)      # class-index labels -> one-hot expansion
+    out.update(c_x2=x2.detach().numpy())
+    rec("c_onehot", ce(x2, lab, weight=w_row, avg_factor=20.0), x2)
+    save("ops2", **out)
+
+
 # ----------------------------------------------------------------------------- raw NMS ops
 def synth_nms_boxes(seed, n_base, per, n_labels=21):
     g = torch.Generator().manual_seed(seed)
@@ -336,11 +432,15 @@ def gen_model(det, assign):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ops2":       # only the second op set (the other fixtures stay as committed)
+        gen_ops2()
+        return
     torch.manual_seed(0)
     model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
     gen_anchors()
     assign = gen_assigner()
     gen_ops()
+    gen_ops2()
     gen_nms(test_cfg)
     det = build_detector(model_cfg, train_cfg=train_cfg, test_cfg=test_cfg)
     synth.fill_state_dict(det.state_dict(), seed=0)

@@ -96,3 +96,136 @@ def test_two_rank_gloo_gradient_exchange(bf16):
         p.join(60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res)
+
+
+# ---------------------------------------------------------------------------------------------- train-step control flow
+def _harness(seed):
+    """DetectorRuntime with the GPU compute replaced by host stand-ins: train_step / sync_replicas / GradReducer /
+    bucket order are the real code under test, forward / loss are no-ops, backward fills the gradient arena with a
+    rank-specific pattern and fires the bucket hook in the engine's backward order, optimizer_step is the reference
+    formula of the fused kernel (global-norm clip with grad_div, AdamW)."""
+    from radet_amd.engine import Engine
+    from radet_amd.models import build_detector
+    from radet_amd.runtime import DetectorRuntime, FlatParams, compute_buckets
+    from radet_amd.utils import Config
+
+    class Harness(DetectorRuntime):
+        def __init__(self, det):
+            self.dev = torch.device("cpu")
+            self.flat = FlatParams(det, self.dev)
+            self.engine = Engine(self.flat.p, self.flat.g, depth=50)
+            self.engine.losses = torch.zeros(3)
+            self.buckets = compute_buckets(self.flat, [c.name for c in self.engine.convs], [c.trainable for c in self.engine.convs])
+            self.opt_state, self.step_count, self.reducer = None, 0, None
+            self.order = []
+            self.sync_replicas()
+
+        def forward(self, img, fold=True):
+            pass
+
+        def loss(self, tg, grad_scale=None, **kw):
+            return self.engine.losses
+
+        def backward(self, bucket_hook=None):
+            g = torch.Generator().manual_seed(1000 + dist.get_rank())
+            self.flat.grads.copy_(torch.randn(self.flat.n_train, generator=g) * self.param_mask())
+            for b in self.buckets:                       # head -> neck -> layer4 -> layer3 -> layer2
+                self.order.append(b["prefix"])
+                if bucket_hook is not None:
+                    bucket_hook(b)
+
+        def param_mask(self):
+            """1 on parameter elements, 0 on the (< 4 element) alignment gaps of the arena, which no kernel ever writes"""
+            m = torch.zeros(self.flat.n_train)
+            for n, o in self.flat.offsets.items():
+                m[o:o + self.flat.p[n].numel()] = 1
+            return m
+
+        def init_optimizer(self, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0):
+            n = self.flat.n_train
+            self.opt_state = dict(m=torch.zeros(n), v=torch.zeros(n), lr=lr, betas=betas, eps=eps, wd=weight_decay, max_norm=max_norm)
+
+        def optimizer_step(self, lr=None, grad_div=1.0):
+            st = self.opt_state
+            assert not self.reducer.works, "all-reduces must be finished before the optimizer runs"
+            self.step_count += 1
+            g = self.flat.grads / grad_div
+            norm = g.double().norm().float()
+            g = g * torch.clamp(st["max_norm"] / (norm + 1e-6), max=1.0)
+            b1, b2 = st["betas"]
+            st["m"].mul_(b1).add_(g, alpha=1 - b1)
+            st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+            p = self.flat.params
+            p.mul_(1 - st["lr"] * st["wd"])
+            denom = (st["v"] / (1 - b2 ** self.step_count)).sqrt().add_(st["eps"])
+            p.addcdiv_(st["m"] / (1 - b1 ** self.step_count), denom, value=-st["lr"])
+            self.grad_div = grad_div
+
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    torch.manual_seed(seed)                               # DIFFERENT initial weights per rank
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    return det, Harness(det)
+
+
+def _step_worker(rank, world, port, q, ckpt):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radet_amd.apis import load_checkpoint, save_checkpoint
+    det, rt = _harness(seed=10 + rank)
+    gathered = [torch.zeros_like(rt.flat.params) for _ in range(world)]
+    dist.all_gather(gathered, rt.flat.params)
+    same_start = all(torch.equal(gathered[0], t) for t in gathered)           # sync_replicas() at construction
+    fro = [torch.zeros_like(rt.flat.frozen) for _ in range(world)]
+    dist.all_gather(fro, rt.flat.frozen)
+    same_start = same_start and all(torch.equal(fro[0], t) for t in fro)
+    rt.init_optimizer(max_norm=35.0)
+    p0 = rt.flat.params.clone()
+    for _ in range(2):
+        rt.train_step(None, None, lr=None)
+    # expected: AdamW on the MEAN of the ranks' gradients (same generator seeds as Harness.backward)
+    mean = sum(torch.randn(rt.flat.n_train, generator=torch.Generator().manual_seed(1000 + r)) for r in range(world)) / world
+    mean = mean * rt.param_mask()
+    summed_ok = torch.allclose(rt.flat.grads, mean * world, rtol=0, atol=1e-5)
+    dist.all_gather(gathered, rt.flat.params)
+    same_end = all(torch.equal(gathered[0], t) for t in gathered)
+    moved = float((rt.flat.params - p0).abs().max()) > 0
+    order_ok = rt.order[:5] == ["bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2."]
+    # checkpoint written by rank 0 only, loaded by rank 0 only -> load_checkpoint's broadcast keeps the replicas equal
+    if rank == 0:
+        save_checkpoint(det, ckpt, meta=dict(iter=2), runtime=rt)
+    dist.barrier()
+    det2, rt2 = _harness(seed=50 + rank)
+    rt2.init_optimizer(max_norm=35.0)
+    if rank == 0:
+        sd = torch.load(ckpt, map_location="cpu")
+        det2.load_state_dict(sd["state_dict"])
+        from radet_amd.apis.train import load_optimizer_state_dict
+        load_optimizer_state_dict(det2, rt2, sd["optimizer"])
+    rt2.sync_replicas()
+    resumed = torch.equal(rt2.flat.params, rt.flat.params) and torch.equal(rt2.opt_state["m"], rt.opt_state["m"]) \
+        and torch.equal(rt2.opt_state["v"], rt.opt_state["v"]) and rt2.step_count == 2
+    q.put((rank, bool(same_start), bool(summed_ok), bool(same_end), bool(moved), bool(order_ok), rt.grad_div == float(world),
+           bool(resumed)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_train_step_control_flow(tmp_path):
+    """Ranks start from different seeds; after construction (initial broadcast) and two data-parallel steps they hold
+    identical parameters; the optimizer saw the summed gradient with grad_div = world, after every all-reduce had
+    finished; a checkpoint loaded on rank 0 only reaches every rank through sync_replicas()."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, q, str(tmp_path / "ck.pth"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    for r in res:
+        assert all(r[1:]), r

@@ -65,15 +65,61 @@ def test_config_and_registry_dropin():
         models.build_backbone(dict(type="NoSuchNet"))
 
 
-def test_reference_config_file_loads_unchanged():
+def test_reference_config_file_loads_unchanged(tmp_path, monkeypatch):
+    """The reference's own config file builds the detector; its `pretrained='torchvision://resnet50'` is resolved
+    offline (RADET_PRETRAINED_DIR) and loaded into the BACKBONE (single_stage.py:36-52, resnet.py:590-599); a missing
+    file is an error, never a silent random init."""
     ref = "/root/reference/configs/bop/r50_ycbv_pbr.py"
     if not os.path.exists(ref):
-        pytest.skip("reference tree not present on this box")
+        ref = CFG                      # same keys / values (tests/test_host.py::test_config_matches...), travels to the GPU box
     from radet_amd.models import build_detector
     from radet_amd.utils import Config
     cfg = Config.fromfile(ref)
+    assert cfg.model["pretrained"] == "torchvision://resnet50"
+    monkeypatch.setenv("RADET_PRETRAINED_DIR", str(tmp_path))
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "no_hub"))
+    with pytest.raises(FileNotFoundError):
+        build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    # a torchvision-format checkpoint: bare ResNet keys ('conv1.weight', 'layer1.0.bn1.running_mean', 'fc.weight', ...)
+    cfg.model["pretrained"] = None
+    donor = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    g = torch.Generator().manual_seed(9)
+    tv = {k: torch.randn(v.shape, generator=g) if v.is_floating_point() else v.clone()
+          for k, v in donor.backbone.state_dict().items()}
+    tv["fc.weight"], tv["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    torch.save(tv, tmp_path / "resnet50.pth")
+    cfg.model["pretrained"] = "torchvision://resnet50"
     det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
     assert det.bbox_head.test_cfg.nms.iou_threshold == 0.65 and det.bbox_head.train_cfg.assigner.type == "MaxIoUAssigner"
+    sd = det.backbone.state_dict()
+    assert all(torch.equal(sd[k], tv[k]) for k in sd)
+    assert not det.backbone.conv1.weight.requires_grad and det.backbone.layer2[0].conv1.weight.requires_grad
+    # a detector checkpoint ('backbone.*' keys, mmcv 'state_dict' wrapper) also lands in the backbone
+    torch.save(dict(state_dict={"backbone." + k: v * 2 for k, v in tv.items() if k.startswith(("conv1", "layer"))}),
+               tmp_path / "det.pth")
+    cfg.model["pretrained"] = str(tmp_path / "det.pth")
+    det2 = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    assert torch.equal(det2.backbone.layer3[1].conv2.weight, tv["layer3.1.conv2.weight"] * 2)
+    torch.save({"unrelated.weight": torch.zeros(3)}, tmp_path / "junk.pth")
+    cfg.model["pretrained"] = str(tmp_path / "junk.pth")
+    with pytest.raises(RuntimeError):
+        build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+
+
+def test_trainable_stem_is_refused():
+    """frozen_stages=-1 would train conv1 / bn1 in the reference; there is no stem backward here, so it must not be
+    accepted silently (zero gradients + weight decay would shrink the stem)."""
+    from radet_amd.engine import Engine
+    from radet_amd.models import build_detector
+    from radet_amd.runtime import FlatParams
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(CFG)
+    cfg.model["pretrained"] = None
+    cfg.model["backbone"]["frozen_stages"] = -1
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    flat = FlatParams(det, torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        Engine(flat.p, flat.g, depth=50, frozen_stages=-1)
 
 
 def build(depth=50):

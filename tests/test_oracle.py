@@ -82,6 +82,19 @@ def test_coder_and_overlaps(golden):
     assert np.allclose(f.numpy(), g["focal"], rtol=1e-6, atol=1e-7)
 
 
+def test_overlaps_second_golden_set(golden):
+    """the oracle's M x N / aligned overlaps against the larger reference fixtures (degenerate boxes, 700 x 1300 GIoU)"""
+    g = golden("ops2")
+    deg = torch.from_numpy(g["deg"])
+    for mode in ("iou", "giou"):
+        assert np.array_equal(om.overlaps_matrix(deg, deg, mode).numpy(), g["deg_" + mode])
+        assert np.array_equal(om.overlaps_aligned(deg, deg.roll(1, 0), mode).numpy(), g["deg_al_" + mode])
+    A, B = torch.from_numpy(g["big_a"]), torch.from_numpy(g["big_b"])
+    big = om.overlaps_matrix(A, B, "giou")
+    assert np.array_equal(big.reshape(-1)[torch.from_numpy(g["big_idx"])].numpy(), g["big_val"])
+    assert abs(big.double().sum().item() - float(g["big_sum"])) < 1e-9 * abs(float(g["big_sum"]))
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_nms_ops(golden, tag):
     g = golden("nms")

@@ -61,8 +61,11 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * +0x800 = bf16 storage (x, w, addend, mask are bf16 tensors, Cin % 32 == 0; y bf16, or fp32 with +0x10000);
  * +0x400 = bf16 math mode (operands rounded RNE to bf16 between LDS and the matrix core, fp32 accumulate, fp32
  * tensors in HBM -- the arithmetic of mmcv's fp16 wrapper, `apis/train.py:113-117`, in bf16); bits 12-15 force
- * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats; when given, launches with too
- * few tiles for 256 CUs split the K loop (<= 8 ways) into partial slabs reduced by a second, deterministic pass. */
+ * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
+ * tickets that must be ZERO before the first launch (every launch leaves them zero); when given, launches with too few
+ * tiles for 256 CUs split the K loop (<= 8 ways, or only the left-over tiles of the last round) and the workgroup that
+ * arrives last at a tile sums the partial tiles in split order and applies the epilogue -- one launch, deterministic.
+ * One workspace per stream: concurrent launches must not share it. */
 int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                        float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                        int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream);
@@ -87,6 +90,19 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                        int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);
+/* Grouped wgrad: up to 32 independent weight-gradient GEMMs (one-tap kernel) in ONE launch -- the convs of a backbone
+ * stage / of the neck, whose individual grids are too short to fill 256 CUs.  Each job = the arguments of
+ * radet_conv2d_wgrad (host array; Cout and Cin multiples of the tile).  flags bit 0: bf16 math mode; bits 4-5 = 1:
+ * 128x128 tiles (default 64x64). */
+typedef struct RadetWgradJob {
+    const float* dy;
+    const float* x;
+    float* slabs;
+    float* dbias_partials;
+    const int* gather_table;
+    int M, Cin, Cout, ld_dy, KH, KW, S;
+} RadetWgradJob;
+int radet_conv2d_wgrad_group(const RadetWgradJob* jobs, int njobs, int flags, void* stream);
 int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream);
 int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, void* stream);
 /* stem: 7x7/2 conv (3->64) + folded BN + ReLU, NCHW image in, NHWC out (resnet.py:558-570,627-629) */

@@ -25,6 +25,12 @@ class RadetConvDesc(C.Structure):
                 ("wft_ld", _i), ("wft_off", _i), ("w16", _i)]
 
 
+class RadetWgradJob(C.Structure):
+    """Mirror of `struct RadetWgradJob` (include/radet_hip.h)."""
+    _fields_ = [("dy", _p), ("x", _p), ("slabs", _p), ("dbias_partials", _p), ("gather_table", _p),
+                ("M", _i), ("Cin", _i), ("Cout", _i), ("ld_dy", _i), ("KH", _i), ("KW", _i), ("S", _i)]
+
+
 # name -> (restype, argtypes); must list every function of include/radet_hip.h
 SIGNATURES = {
     "radet_gather_table_rows": (_i, [_i]),
@@ -34,6 +40,7 @@ SIGNATURES = {
     "radet_conv2d_igemm_taps": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_conv2d_wgrad_group": (_i, [_p, _i, _i, _p]),
     "radet_fold_weights": (_i, [_p, _i, _p]),
     "radet_unfold_grads": (_i, [_p, _i, _i, _p]),
     "radet_stem_conv_bn_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

@@ -8,15 +8,18 @@
 // calls behind radet/models/backbones/resnet.py:260-299, necks/fpn.py:170-221 and
 // dense_heads/atss_head.py:118-145 of the reference.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 16 (one tap, 16 channels), LDS rows
-// padded to 20 floats so that the 16-byte fragment reads are bank-conflict free.  A lane (i = l&31,
-// h = l>>5) fetches 4 consecutive k for its row with one ds_read_b128 and feeds 4 MFMAs; the
-// K order inside a step is permuted (lower half-wave takes k 0-3 / 8-11, upper 4-7 / 12-15), which
-// is legal because A and B use the same permutation.  Global->LDS is register-staged and
-// double-buffered: one barrier per K step, next step's loads in flight under 8*TM*TN MFMAs.
+// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 16 or 32 (one tap, 16 / 32 channels).  Tiles go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4) into unpadded rows whose 16-byte slots are XOR-swizzled on the
+// source side, so that the 16-byte fragment reads are bank-conflict free.  A lane (i = l&31, h = l>>5) fetches 4
+// consecutive k for its row with one ds_read_b128 and feeds 4 MFMAs; the K order inside a step is permuted (lower
+// half-wave takes k 0-3 / 8-11, upper 4-7 / 12-15), which is legal because A and B use the same permutation.
+// 2 or 3 LDS stages: one barrier per K step, the next step's loads in flight under 8*TM*TN MFMAs.
 #include "common.h"
+#include "../../include/radet_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+
+#define RADET_SPLIT_COUNTERS 16384     // arrival tickets at the head of the split workspace
 
 struct ConvPtrs {
     const float* x;       // input rows [*, Cin]
@@ -31,7 +34,8 @@ struct ConvArgs {
     ConvPtrs p[2];        // 1 or 2 independent problems of identical geometry in one launch (cls / reg tower)
     int groups;
     const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
-    float* partial;       // split-K: [sk][M][Cout] raw partial sums (epilogue applied by splitk_epilogue_kernel)
+    float* partial;       // split-K / tail split: tile-local partial tiles [split tile][z][BM][BN]
+    int* counters;        // arrival tickets, one per split tile (zero before the launch, left zero by it)
     const int* out_rows;  // optional [M]: output row of GEMM row m (parity-class dgrad of strided convs)
     int tap_ids[16];      // weight tap index of table tap t (identity unless a tap subset is used)
     int KTw;              // taps in the weight tensor (row stride of w is KTw*Cin)
@@ -106,38 +110,69 @@ __device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr,
     return p.base + iy * p.Wi + ix;
 }
 
+// Split episodes (split-K over the whole grid, or the K-split left-over tiles of a tail split) are reduced INSIDE the
+// launch: every workgroup of a tile writes its raw partial tile (tile-local layout), publishes it with one agent-scope
+// release and draws an arrival ticket; the workgroup that draws the last ticket acquires, re-reads all partial tiles in
+// split order z = 0, 1, ... (so the sum does not depend on the arrival order: deterministic, and equal to what a
+// separate reduction pass would produce) and runs the fused epilogue.  This replaces 60-80 reduction launches per
+// train step that sat between dependent GEMMs on the critical chain.  `ws` is any LDS word all waves are done with.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P,
-                                            f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, bool tail,
-                                            int tail_slot, int wm, int wn, int li, int lh) {
+                                            f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int nsplit,
+                                            int ctile, int z, int wm, int wn, int li, int lh, volatile int* ws) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (tail) {       // raw partial tile, tile-local [BM][BN] layout; tail_epilogue_kernel finishes it
-        float* part = a.partial + (size_t)tail_slot * BM * BN;
+    if (nsplit > 1) {
+        // partial tile = register image: [wave][i][j][lane][16 accumulator floats] -> every lane moves 64 contiguous
+        // bytes with 16-byte accesses.  The stores are write-through (sc1), so publishing needs no L2 write-back
+        // (a release fence here flushes every dirty line of the XCD's L2, i.e. the outputs of all concurrently running
+        // kernels: measured slower than the separate reduction launches it replaced).
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        float* base = a.partial + (size_t)ctile * nsplit * BM * BN;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)z * BM * BN, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = ((((wave * TM + i) * TN + j) * 64 + lane) * 16) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off + 16 * q, 0, 16);   // aux 16 = sc1
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            ws[0] = __hip_atomic_fetch_add(&a.counters[ctile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ws[0] != nsplit - 1) return;                       // uniform: not the last arriver of this tile
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&a.counters[ctile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    part[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + (wn * TN + j) * 32 + li] = acc[i][j][r];
-        return;
-    }
-    if (a.sk > 1) {   // split-K: raw partial sums, epilogue runs in splitk_epilogue_kernel
-        float* part = a.partial + (size_t)blockIdx.y * a.M * a.Cout;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int zz = 0; zz < nsplit; ++zz) {
+            const float* pz = base + (size_t)zz * BM * BN;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + (wn * TN + j) * 32 + li;
-                if (col >= a.Cout) continue;
+                for (int j = 0; j < TN; ++j) {
+                    const float4* src = reinterpret_cast<const float4*>(pz + (((wave * TM + i) * TN + j) * 64 + lane) * 16);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < a.M) part[(size_t)row * a.Cout + col] = acc[i][j][r];
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = src[q];
+                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+                    }
                 }
-            }
-        return;
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -158,136 +193,6 @@ __device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P
                 st_out(P.y, o, v, a.io);
             }
         }
-}
-
-// TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
-// K = 2304) so that rocprofv3 --stats reports it on its own line (bench.py's roofline kernel).
-template <int BM, int BN, int WM, int WN, int TAG, int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int LD = BK + 4;            // 20 / 36 floats: conflict-free 16-byte fragment reads
-    constexpr int F4 = BK / 4;            // float4 per tile row
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_UNITS = (BM * F4) / 256;
-    constexpr int B_UNITS = (BN * F4 + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(A_UNITS >= 1, "BM * BK >= 1024");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LD];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int tilesN = (a.Cout + BN - 1) / BN;
-    const bool tail = (int)blockIdx.x >= a.n_full;
-    const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;       // = tail_tile * sk_tail + k_slice
-    int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
-    const int tilesG = ((a.M + BM - 1) / BM) * tilesN;       // tiles per group
-    const int grp = id >= tilesG ? 1 : 0;
-    id -= grp * tilesG;
-    const ConvPtrs P = a.p[grp];
-    const int m0 = (id / tilesN) * BM;
-    const int n0 = (id % tilesN) * BN;
-
-    const int k4 = (tid % F4) * 4;
-    constexpr int RPU = 256 / F4;         // tile rows covered by one 256-thread load unit
-    const int KT = a.KH * a.KW;
-    const int cpt = a.Cin / BK;
-    const int per = tail ? a.it_per_tail : a.it_per_split;
-    const int it0 = (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
-    int nK = KT * cpt - it0;
-    if (nK > per) nK = per;
-
-    // loop-carried load state: (tap, c0) of the NEXT stage to fetch, rows of the current tap
-    int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
-    int arow[A_UNITS];
-    const int* tabp = a.rowtab + m0 + (tid / F4);
-#pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * RPU] : -1;
-    const float* wp[B_UNITS];
-#pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-        const int unit = tid + u * 256;
-        const int n = n0 + (unit / F4);
-        wp[u] = ((unit < BN * F4) && (n < a.Cout)) ? P.w + (size_t)n * a.KTw * a.Cin + k4 : nullptr;
-    }
-
-    float4 ra[A_UNITS], rb[B_UNITS];
-    auto load_stage = [&]() {
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u)
-            ra[u] = arow[u] >= 0 ? *reinterpret_cast<const float4*>(P.x + (size_t)arow[u] * a.Cin + ld_c0 + k4)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int woff = a.tap_ids[ld_tap] * a.Cin + ld_c0;
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u)
-            rb[u] = wp[u] ? *reinterpret_cast<const float4*>(wp[u] + woff) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ld_c0 += BK;
-        if (ld_c0 == a.Cin) {
-            ld_c0 = 0;
-            ++ld_tap;
-            if (ld_tap < KT) {
-#pragma unroll
-                for (int u = 0; u < A_UNITS; ++u) arow[u] = nK > 0 ? tabp[(size_t)ld_tap * a.Mp + u * RPU] : -1;
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u)
-            *reinterpret_cast<float4*>(&As[buf][((tid + u * 256) / F4) * LD + k4]) = ra[u];
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            if (unit < BN * F4) *reinterpret_cast<float4*>(&Bs[buf][(unit / F4) * LD + k4]) = rb[u];
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (nK > 0) {
-        load_stage();
-        store_stage(0);
-    }
-    __syncthreads();
-
-    const int a_row0 = (wm * TM * 32 + li) * LD + 4 * lh;
-    const int b_row0 = (wn * TN * 32 + li) * LD + 4 * lh;
-
-    for (int it = 0; it < nK; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nK) load_stage();
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const float4*>(&As[buf][a_row0 + i * 32 * LD + 8 * s]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_row0 + j * 32 * LD + 8 * s]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (it + 1 < nK) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, tail, tail_slot, wm, wn, li, lh);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -328,13 +233,15 @@ __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// LDS-DMA variant of conv_igemm_kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
+// Implicit-GEMM kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
 // global_load_lds_dwordx4, no staging registers and no ds_write pass.  A wave load writes 1 KiB lane-linearly, so
 // the LDS rows are unpadded [row][BK]; bank conflicts of the 16-byte fragment reads are avoided by an XOR swizzle
 // of the 16-byte slot inside a row, applied on the SOURCE side: the lane that fills slot q of tile row r fetches
 // k-quad q ^ swz(r), swz(r) = (r / (64 / BK)) % (BK / 4); the reader of k-quad kq looks in slot kq ^ swz(r).
 // Stage order per K step: issue the next stage's loads into the other buffer, then fragment reads (software
 // pipelined one 8-wide k slice ahead) + MFMAs on the current buffer, then vmcnt(0) + barrier.
+// TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
+// K = 2304) so that rocprofv3 --stats reports it on its own line (bench.py's roofline kernel).
 template <int BM, int BN, int WM, int WN, int TAG, int BK, int NSTG = 2>
 __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int F4 = BK / 4;            // 16-byte slots per tile row
@@ -528,49 +435,12 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
         if constexpr (NSTG == 3)
             if (it + 2 < nK) stage(std::integral_constant<int, 2>{}, it + 2);
     }
-    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, tail, tail_slot, wm, wn, li, lh);
-}
-
-// split-K second pass: y = epilogue(sum_z partial[z])   (fixed summation order -> deterministic)
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs a) {
-    const size_t total = (size_t)a.M * a.Cout;
-    for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int z = 0; z < a.sk; ++z) v += a.partial[(size_t)z * total + o];
-        const int col = (int)(o % a.Cout);
-        const size_t oo = a.out_rows ? (size_t)a.out_rows[o / a.Cout] * a.Cout + col : o;
-        if (a.p[0].bias) v += a.p[0].bias[col];
-        if (a.p[0].addend) v += ld_act(a.p[0].addend, oo, a.io);
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (a.p[0].mask) v = ld_act(a.p[0].mask, oo, a.io) > 0.f ? v : 0.f;
-        st_out(a.p[0].y, oo, v, a.io);
-    }
-}
-
-// tail-split second pass: one workgroup per left-over tile sums its sk_tail partial tiles (fixed order) + epilogue
-__global__ __launch_bounds__(256) void tail_epilogue_kernel(const ConvArgs a, int BM, int BN) {
-    const int tilesN = (a.Cout + BN - 1) / BN;
-    int id = a.n_full + blockIdx.x;
-    const int tilesG = ((a.M + BM - 1) / BM) * tilesN;
-    const int grp = id >= tilesG ? 1 : 0;
-    id -= grp * tilesG;
-    const ConvPtrs P = a.p[grp];
-    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
-    const float* part = a.partial + (size_t)blockIdx.x * a.sk_tail * BM * BN;
-    const int quarter = BM * BN / 4;                     // blockIdx.y: quarter of the tile (4x the workgroups)
-    for (int e = blockIdx.y * quarter + threadIdx.x; e < (blockIdx.y + 1) * quarter; e += 256) {
-        const int rl = e / BN, cl = e - rl * BN;
-        const int row = m0 + rl, col = n0 + cl;
-        if (row >= a.M || col >= a.Cout) continue;
-        float v = 0.f;
-        for (int z = 0; z < a.sk_tail; ++z) v += part[(size_t)z * BM * BN + e];
-        const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
-        if (P.bias) v += P.bias[col];
-        if (P.addend) v += ld_act(P.addend, o, a.io);
-        if (a.relu) v = fmaxf(v, 0.f);
-        if (P.mask) v = ld_act(P.mask, o, a.io) > 0.f ? v : 0.f;
-        st_out(P.y, o, v, a.io);
-    }
+    // split episode of this workgroup: (number of splits, split-tile index, my split)
+    const int nsplit = tail ? a.sk_tail : a.sk;
+    const int ctile = tail ? tail_slot / a.sk_tail : id + grp * tilesG;
+    const int zsplit = tail ? tail_slot % a.sk_tail : (int)blockIdx.y;
+    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, nsplit, ctile, zsplit, wm, wn, li, lh,
+                                reinterpret_cast<volatile int*>(&As[0][0]));
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -588,310 +458,16 @@ struct WgradArgs {
     int math;         // 0: fp32 MFMA; 1: operands rounded to bf16, fp32 accumulate (LDS-DMA kernels only)
 };
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int BP = 16;  // pixels per stage
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int A_UNITS = (BP * BM / 4 + 255) / 256;
-    constexpr int B_UNITS = (BP * BN / 4 + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BP * BN];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int KT = a.KH * a.KW;
-    const int tilesO = (a.Cout + BM - 1) / BM;
-    const int tilesC = (a.Cin + BN - 1) / BN;
-    const int tilesPerSplit = tilesO * KT * tilesC;
-    int id = blockIdx.x;
-    const int split = id / tilesPerSplit;   // (debug: bit 12 of S = skip global loads after the first stage)
-    id -= split * tilesPerSplit;
-    const int to = id % tilesO;
-    id /= tilesO;
-    const int tc = id % tilesC;
-    const int tap = id / tilesC;
-    const int o0 = to * BM, c0 = tc * BN;
-    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
-
-    const int p_begin = split * a.chunks_per_split * BP;
-    int p_end = p_begin + a.chunks_per_split * BP;
-    if (p_end > a.M) p_end = a.M;
-    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
-
-    float4 ra[A_UNITS], rb[B_UNITS];
-    float4 bsum[A_UNITS];
-#pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) bsum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int brow[B_UNITS];
-    bool bvalid[B_UNITS];
-#pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-        const int unit = tid + u * 256;
-        const int m = p_begin + unit / (BN / 4);
-        bvalid[u] = unit < BP * BN / 4 && m < p_end;
-        brow[u] = tab_tap[bvalid[u] ? m : 0];
-    }
-    // Loads are UNCONDITIONAL (addresses clamped to a valid location) and masked when they are written to
-    // LDS: a "load or zero" select at load time makes hipcc branch around each load and drain vmcnt(0)
-    // before the MFMAs (cdna_hip_programming.md, ".s-level traps" (c)), which serialises the pipeline.
-    bool am[A_UNITS], bm[B_UNITS];
-    auto load_stage = [&](int it) {
-        const int p0 = p_begin + it * BP;
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            const int j = unit / (BM / 4), o = o0 + (unit % (BM / 4)) * 4;
-            const int m = p0 + j;
-            am[u] = (unit < BP * BM / 4) && (m < p_end) && (o < a.Cout);
-            const float* src = a.dy + (am[u] ? (size_t)m * a.ld_dy + o : (size_t)0);
-            ra[u] = *reinterpret_cast<const float4*>(src);
-        }
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            const int j = unit / (BN / 4), c = c0 + (unit % (BN / 4)) * 4;
-            const int m = p0 + j;
-            const bool live = unit < BP * BN / 4 && c < a.Cin;
-            bm[u] = live && bvalid[u] && brow[u] >= 0;
-            const float* src = a.x + (bm[u] ? (size_t)brow[u] * a.Cin + c : (size_t)0);
-            rb[u] = *reinterpret_cast<const float4*>(src);
-            // gather-table entry of the NEXT stage (raw; validity kept separately so that nothing consumes
-            // the loaded value before the next stage): its latency overlaps this stage's data loads
-            bvalid[u] = live && (m + BP < p_end);
-            brow[u] = tab_tap[bvalid[u] ? m + BP : 0];
-        }
-    };
-    auto store_stage = [&](int buf) {
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            float4 v = am[u] ? ra[u] : z4;
-            // channels beyond Cout inside the last float4 of a padded row are zero in the buffer already
-            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[buf][unit * 4]) = v;
-            // fused bias gradient: consume the dy tile here (data has landed), never at load time
-            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
-        }
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            if (unit < BP * BN / 4) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = bm[u] ? rb[u] : z4;
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
-
-    if (nIt > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nIt; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nIt && !(a.dbg && it > 0)) load_stage(it + 1);
-        // all fragments of the stage are issued to LDS first, so the MFMAs wait with counted lgkmcnt only
-        float af[BP / 2][TM], bf[BP / 2][TN];
-#pragma unroll
-        for (int kk = 0; kk < BP / 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[kk][i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[kk][j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads ahead of the MFMA block (hipcc otherwise sinks them)
-#pragma unroll
-        for (int kk = 0; kk < BP / 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
-        if (it + 1 < nIt) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    if (a.dbias_partials && tap == 0 && tc == 0) {  // fused column sums of dy over this split's pixels
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const int unit = tid + u * 256;
-            if (unit < BP * BM / 4) *reinterpret_cast<float4*>(&As[0][unit * 4]) = bsum[u];
-        }
-        __syncthreads();
-        if (tid < BM && o0 + tid < a.Cout) {
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < BP; ++j) t += As[0][j * BM + tid];
-            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
-        }
-    }
-
-    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = c0 + (wn * TN + j) * 32 + li;
-            if (c >= a.Cin) continue;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int o = o0 + (wm * TM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                if (o >= a.Cout) continue;
-                out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
-            }
-        }
-}
-
 // ------------------------------------------------------------------------------------------ wgrad, all 9 taps
 // 3x3 convs: one workgroup owns a (128 output-channel) x (32 input-channel) tile of ALL nine taps for its pixel
 // split.  The dy tile is loaded once per stage instead of once per tap, and the nine shifted x tiles overlap
 // in L1 (they read the same 3x(16+2) pixel rows), so the L2->LDS traffic per MAC drops ~2.4x against the
 // one-tap kernel above, and 72 MFMAs (9 taps x 8 K steps) run between barriers instead of 32.
 // Wave w owns output channels [32w, 32w+32): 9 accumulator tiles (144 AGPRs), one A fragment feeds 9 MFMAs.
-template <int NW>   // NW waves: block tile = (32*NW output channels) x 32 input channels x 9 taps
-__global__ __launch_bounds__(NW * 64) void conv_wgrad9_kernel(const WgradArgs a) {
-    constexpr int BP = 16, BM = 32 * NW, BC = 32, KT = 9, NT = NW * 64;
-    constexpr int A_UNITS = BP * BM / 4 / NT;             // 2
-    constexpr int B_TOTAL = KT * BP * BC / 4;             // 1152 float4 per stage
-    constexpr int B_UNITS = (B_TOTAL + NT - 1) / NT;      // 5 (4 waves) / 3 (8 waves)
-    __shared__ __attribute__((aligned(16))) float As[2][BP * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][KT * BP * BC];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-
-    const int tilesO = (a.Cout + BM - 1) / BM;
-    const int tilesC = a.Cin / BC;
-    const int tilesPerSplit = tilesO * tilesC;
-    int id = blockIdx.x;
-    const int split = id / tilesPerSplit;
-    id -= split * tilesPerSplit;
-    const int to = id % tilesO, tc = id / tilesO;
-    const int o0 = to * BM, c0 = tc * BC;
-
-    const int p_begin = split * a.chunks_per_split * BP;
-    int p_end = p_begin + a.chunks_per_split * BP;
-    if (p_end > a.M) p_end = a.M;
-    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
-
-    float4 ra[A_UNITS], rb[B_UNITS];
-    bool am[A_UNITS], bm[B_UNITS];
-    float4 bsum[A_UNITS];
-#pragma unroll
-    for (int u = 0; u < A_UNITS; ++u) bsum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // per-unit constants of the x-tile loads: tap, pixel-in-stage, channel offset
-    int brow[B_UNITS];
-    bool bvalid[B_UNITS];
-    // unit -> (tap, pixel-in-stage, channel) are shifts of the unit index (128 float4 per tap tile, 8 per pixel)
-#define W9_TAP(unit) ((unit) >> 7)
-#define W9_PIX(unit) (((unit) & 127) >> 3)
-#define W9_CH(unit) (c0 + ((unit) & 7) * 4)
-#pragma unroll
-    for (int u = 0; u < B_UNITS; ++u) {
-        const int unit = tid + u * NT;
-        const int m = p_begin + W9_PIX(unit);
-        bvalid[u] = unit < B_TOTAL && m < p_end;
-        brow[u] = a.rowtab[(size_t)(bvalid[u] ? W9_TAP(unit) : 0) * a.Mp + (bvalid[u] ? m : 0)];
-    }
-    auto load_stage = [&](int it) {
-        const int p0 = p_begin + it * BP;
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const int unit = tid + u * NT;
-            const int j = unit / (BM / 4), o = o0 + (unit % (BM / 4)) * 4;
-            const int m = p0 + j;
-            am[u] = (m < p_end) && (o < a.Cout);
-            ra[u] = *reinterpret_cast<const float4*>(a.dy + (am[u] ? (size_t)m * a.ld_dy + o : (size_t)0));
-        }
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * NT;
-            const int m = p0 + W9_PIX(unit);
-            bm[u] = bvalid[u] && brow[u] >= 0;
-            rb[u] = *reinterpret_cast<const float4*>(a.x + (bm[u] ? (size_t)brow[u] * a.Cin + W9_CH(unit) : (size_t)0));
-            bvalid[u] = unit < B_TOTAL && (m + BP < p_end);
-            brow[u] = a.rowtab[(size_t)(bvalid[u] ? W9_TAP(unit) : 0) * a.Mp + (bvalid[u] ? m + BP : 0)];
-        }
-    };
-    auto store_stage = [&](int buf) {
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) {
-            const float4 v = am[u] ? ra[u] : z4;
-            *reinterpret_cast<float4*>(&As[buf][(tid + u * NT) * 4]) = v;
-            bsum[u].x += v.x; bsum[u].y += v.y; bsum[u].z += v.z; bsum[u].w += v.w;
-        }
-#pragma unroll
-        for (int u = 0; u < B_UNITS; ++u) {
-            const int unit = tid + u * NT;
-            if (unit < B_TOTAL) *reinterpret_cast<float4*>(&Bs[buf][unit * 4]) = bm[u] ? rb[u] : z4;
-        }
-    };
-
-    f32x16 acc[KT];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    if (nIt > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nIt; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nIt) load_stage(it + 1);
-#pragma unroll
-        for (int kk = 0; kk < BP / 2; ++kk) {
-            const float af = As[buf][(2 * kk + lh) * BM + wave * 32 + li];
-            float bf[KT];
-#pragma unroll
-            for (int t = 0; t < KT; ++t) bf[t] = Bs[buf][(t * BP + 2 * kk + lh) * BC + li];
-#pragma unroll
-            for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[t], acc[t], 0, 0, 0);
-        }
-        if (it + 1 < nIt) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    if (a.dbias_partials && tc == 0) {
-#pragma unroll
-        for (int u = 0; u < A_UNITS; ++u) *reinterpret_cast<float4*>(&As[0][(tid + u * NT) * 4]) = bsum[u];
-        __syncthreads();
-        if (tid < BM && o0 + tid < a.Cout) {
-            float t = 0.f;
-#pragma unroll
-            for (int j = 0; j < BP; ++j) t += As[0][j * BM + tid];
-            a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = t;
-        }
-    }
-    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
-    const int c = c0 + li;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (o < a.Cout) out[((size_t)o * KT + t) * a.Cin + c] = acc[t][r];
-        }
-}
-
-// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, LDS-DMA
-// Same tiling as conv_wgrad9_kernel, but the dy tile and the nine x tiles go global -> LDS directly
+// The dy tile and the nine x tiles go global -> LDS directly
 // (global_load_lds_dwordx4: each wave instruction lands 1 KiB lane-linearly, which is exactly one 256-channel dy
-// row or eight 32-channel x rows of the unpadded tiles).  No staging VGPRs (the register-staged version spills its
-// prefetch registers next to 144 accumulators), no ds_write pass; padding / out-of-range rows are read from a zero page.
+// row or eight 32-channel x rows of the unpadded tiles).  No staging VGPRs next to the 144 accumulators, no ds_write
+// pass; padding / out-of-range rows are read from a zero page.
 
 
 template <int NW, int MATH>   // MATH 1: bf16 operands (rounded from the fp32 tiles), fp32 accumulate
@@ -1064,10 +640,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
 }
 
 // ------------------------------------------------------------------------------------------ wgrad, one tap, LDS-DMA
-// conv_wgrad_kernel with the dy / x tiles brought in by global_load_lds (see conv_wgrad9g_kernel): the unpadded
+// One (tap, 64x64 or 128x128 output x input channel tile, pixel split) per workgroup; the dy / x tiles are brought in
+// by global_load_lds (see conv_wgrad9g_kernel): the unpadded
 // [pixel][channel] tiles are lane-linear images of 1-KiB wave loads, so no staging registers and no ds_write pass.
 template <int BM, int BN, int WM, int WN, int MATH>
-__global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     constexpr int BP = 16, NW = 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_INSTR = BP * BM * 4 / 1024, B_INSTR = BP * BN * 4 / 1024;
@@ -1087,7 +664,6 @@ __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
     const int tilesO = (a.Cout + BM - 1) / BM;
     const int tilesC = (a.Cin + BN - 1) / BN;
     const int tilesPerSplit = tilesO * tilesC * KT;
-    int id = blockIdx.x;
     const int split = id / tilesPerSplit;
     id -= split * tilesPerSplit;
     const int to = id % tilesO;
@@ -1217,6 +793,31 @@ __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
                 out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN, int MATH>
+__global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
+    wgradg_body<BM, BN, WM, WN, MATH>(a, blockIdx.x);
+}
+
+// Grouped launch: up to WG_MAX independent weight-gradient GEMMs (the convs of one backbone stage / of the neck, all
+// off the critical path of the backward chain) in ONE grid.  Each conv alone is a 150-1000 workgroup launch whose
+// ramp-up and tail leave most of the 256 CUs idle, and filling the chip per conv needs many pixel splits (every
+// split = one more weight-sized slab written here and read again by the reduction); a group keeps every CU busy with a
+// few long workgroups per conv instead.  Problem descriptors travel in the kernel argument segment.
+#define WG_MAX 32
+struct WgradGroup {
+    int n;
+    int begin[WG_MAX + 1];      // first workgroup of problem i; begin[n] = grid size
+    WgradArgs p[WG_MAX];
+};
+
+template <int BM, int BN, int WM, int WN, int MATH>
+__global__ __launch_bounds__(256) void conv_wgradg_group_kernel(const WgradGroup g) {
+    int pi = 0;
+    for (int i = 1; i < g.n; ++i)
+        if ((int)blockIdx.x >= g.begin[i]) pi = i;      // uniform: scalar compares on kernel arguments
+    wgradg_body<BM, BN, WM, WN, MATH>(g.p[pi], (int)blockIdx.x - g.begin[pi]);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad, bf16 storage
@@ -1536,10 +1137,9 @@ static int fill_segs(RadetSegs* out, const int* seg_desc, int nseg, int B, int o
     return RADET_OK;
 }
 
-// Experiment switches (environment, read once): the register-staged kernels and the launch heuristics they select
-// are kept for A/B measurements; none is needed in normal operation.
+// Experiment switches (environment, read once) of the launch heuristics; none is needed in normal operation.
 struct RadetSwitches {
-    bool igemm_regstage, wgrad_regstage, wgrad9_regstage, no_tail_split, wgrad9_bm128, no_wgrad9;
+    bool no_tail_split, wgrad9_bm128, no_wgrad9, no_splitk;
     int wgrad_tile64_m, dbg_wgrad;
     long wgrad9_blocks, wgrad_blocks;
 };
@@ -1548,10 +1148,8 @@ static const RadetSwitches& radet_switches() {
         RadetSwitches r;
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n) { const char* e = getenv(n); return e ? atol(e) : 0L; };
-        r.igemm_regstage = on("RADET_IGEMM_REGSTAGE");
-        r.wgrad_regstage = on("RADET_WGRAD_REGSTAGE");
-        r.wgrad9_regstage = on("RADET_WGRAD9_REGSTAGE");
         r.no_tail_split = on("RADET_NO_TAIL_SPLIT");
+        r.no_splitk = on("RADET_NO_SPLITK");
         r.wgrad9_bm128 = on("RADET_WGRAD9_BM128");
         r.no_wgrad9 = on("RADET_NO_WGRAD9");
         r.wgrad_tile64_m = (int)num("RADET_WGRAD_TILE64_M");
@@ -1567,6 +1165,12 @@ template <int BM, int BN, int WM, int WN>
 static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, bool stages3) {
     ConvArgs a = a_in;
     const int T = a.groups * ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    // split-K partial tiles are tile-local [tile][z][BM][BN]: shrink the split until they (and the tickets) fit
+    while (a.sk > 1 && ((size_t)T * a.sk * BM * BN > ws_floats || T > RADET_SPLIT_COUNTERS)) --a.sk;
+    if (a.sk != a_in.sk) {
+        const int nKs0 = a.KH * a.KW * (a.Cin / bk);
+        a.it_per_split = (nKs0 + a.sk - 1) / a.sk;
+    }
     a.n_full = T; a.sk_tail = 1; a.it_per_tail = a.it_per_split;
     const int nKs = a.KH * a.KW * (a.Cin / bk);
     const int rem = T % 256;
@@ -1576,7 +1180,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         int skt = 256 / rem;
         if (skt > 8) skt = 8;
         if (skt > nKs / 8) skt = nKs / 8;
-        while (skt > 1 && (size_t)rem * skt * BM * BN > ws_floats) --skt;
+        while (skt > 1 && ((size_t)rem * skt * BM * BN > ws_floats || rem > RADET_SPLIT_COUNTERS)) --skt;
         if (skt >= 2) {
             a.n_full = T - rem;
             a.sk_tail = skt;
@@ -1584,12 +1188,8 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
-    const bool regstage = radet_switches().igemm_regstage;
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
-    if (regstage && tag < 2 && a.io == 0) {
-        if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 32); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 32); }
-        else          { if (tag) RADET_LAUNCH_IGEMM(conv_igemm_kernel, 1, 16); else RADET_LAUNCH_IGEMM(conv_igemm_kernel, 0, 16); }
-    } else {
+    {
         if (stages3 && tag < 2) {
 #define RADET_LAUNCH_IGEMM3(TAGV, BKV) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, 3>), dim3(tiles, a.sk), dim3(256), 0, st, a)
             if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
@@ -1616,14 +1216,6 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
 #undef RADET_LAUNCH_IGEMM
-    if (a.sk > 1) {
-        const size_t total = (size_t)a.M * a.Cout;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, st, a);
-    }
-    if (a.sk_tail > 1)
-        hipLaunchKernelGGL(tail_epilogue_kernel, dim3(T - a.n_full, 4), dim3(256), 0, st, a, BM, BN);
 }
 
 static long igemm_tiles(int M, int N, int choice) {
@@ -1742,19 +1334,28 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     const bool stages3 = ((tile_override >> 17) & 1) != 0;   // 0x20000: 3 LDS stages (forward launches that run alone)
     const int sk_force = (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;
-    if (splitk_ws != nullptr && a.groups == 1) {
+    if (splitk_ws != nullptr && a.groups == 1 && !radet_switches().no_splitk) {
         if (sk_force) sk = sk_force;
         else if (tiles < 384) {
             sk = (int)((512 + tiles - 1) / tiles);
             if (sk > nK / 8) sk = nK / 8;
             if (sk > 8) sk = 8;
         }
-        while (sk > 1 && (size_t)sk * a.M * Cout > splitk_ws_floats) --sk;
         if (sk < 1) sk = 1;
     }
     a.sk = sk;
     a.it_per_split = (nK + sk - 1) / sk;
-    a.partial = splitk_ws;
+    // workspace = RADET_SPLIT_COUNTERS arrival tickets (ints, zero between launches) followed by the partial tiles
+    a.counters = (int*)splitk_ws;
+    a.partial = nullptr;
+    if (splitk_ws != nullptr && splitk_ws_floats > RADET_SPLIT_COUNTERS) {
+        a.partial = splitk_ws + RADET_SPLIT_COUNTERS;
+        splitk_ws_floats -= RADET_SPLIT_COUNTERS;
+    } else {
+        a.sk = 1;
+        a.it_per_split = nK;
+        splitk_ws_floats = 0;
+    }
     switch (choice) {
         case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
         case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
@@ -1768,8 +1369,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
-    if (radet_switches().wgrad_regstage && a.math == 0) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, st, a);
-    else if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
+    if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
 }
 
@@ -1871,13 +1471,11 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (use_wgrad9(M, Cin, Cout, KH, KW) && !(flags & 0x40) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
-            if (radet_switches().wgrad9_regstage && a.math == 0) hipLaunchKernelGGL(conv_wgrad9_kernel<8>, dim3(tiles), dim3(512), 0, st, a);
-            else if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
+            if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 0>), dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;
-            if (radet_switches().wgrad9_regstage) hipLaunchKernelGGL(conv_wgrad9_kernel<4>, dim3(tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_wgrad9g_kernel<4, 0>), dim3(tiles), dim3(256), 0, st, a);
+            hipLaunchKernelGGL((conv_wgrad9g_kernel<4, 0>), dim3(tiles), dim3(256), 0, st, a);
         }
         return radet_check_launch();
     }
@@ -1888,5 +1486,39 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
     else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
     else launch_wgrad<128, 128, 2, 2>(a, st);
+    return radet_check_launch();
+}
+
+// Grouped one-tap wgrad (see conv_wgradg_group_kernel): jobs[i] describes one conv exactly like the arguments of
+// radet_conv2d_wgrad.  flags bit 0: bf16 math mode; bits 4-5: tile (1 = 128x128, otherwise 64x64).
+extern "C" int radet_conv2d_wgrad_group(const RadetWgradJob* jobs, int njobs, int flags, void* stream) {
+    if (njobs < 1 || njobs > WG_MAX || jobs == nullptr) return RADET_ERR_ARG;
+    const int bm = ((flags >> 4) & 3) == 1 ? 128 : 64;
+    WgradGroup g;
+    g.n = njobs;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const RadetWgradJob& j = jobs[i];
+        if (j.Cin % 4 != 0 || j.S < 1 || j.ld_dy < j.Cout || (j.ld_dy & 3) || j.M <= 0 || j.gather_table == nullptr ||
+            j.Cout % bm != 0 || j.Cin % bm != 0)
+            return RADET_ERR_ARG;
+        WgradArgs& a = g.p[i];
+        a.dy = j.dy; a.x = j.x; a.slabs = j.slabs; a.dbias_partials = j.dbias_partials; a.rowtab = j.gather_table;
+        a.M = j.M; a.Mp = radet_gather_table_rows(j.M); a.Cin = j.Cin; a.Cout = j.Cout; a.KH = j.KH; a.KW = j.KW;
+        a.ld_dy = j.ld_dy; a.S = j.S; a.dbg = 0; a.math = flags & 1;
+        const int chunks = (j.M + 15) / 16;
+        a.chunks_per_split = (chunks + j.S - 1) / j.S;
+        g.begin[i] = total;
+        total += (j.Cout / bm) * (j.Cin / bm) * j.KH * j.KW * j.S;
+    }
+    g.begin[njobs] = total;
+    hipStream_t st = (hipStream_t)stream;
+    if (bm == 128) {
+        if (flags & 1) hipLaunchKernelGGL((conv_wgradg_group_kernel<128, 128, 2, 2, 1>), dim3(total), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgradg_group_kernel<128, 128, 2, 2, 0>), dim3(total), dim3(256), 0, st, g);
+    } else {
+        if (flags & 1) hipLaunchKernelGGL((conv_wgradg_group_kernel<64, 64, 2, 2, 1>), dim3(total), dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((conv_wgradg_group_kernel<64, 64, 2, 2, 0>), dim3(total), dim3(256), 0, st, g);
+    }
     return radet_check_launch();
 }

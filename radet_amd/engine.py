@@ -39,6 +39,7 @@ class Conv:
         self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
         self.bn, self.bias, self.trainable, self.need_dgrad = bn, bias, trainable, dgrad
         self.wft_ld, self.wft_off, self.wft_shared = 0, 0, None
+        self.grouped = False          # weight gradient issued through the stage's grouped launch (Engine._plan_wgrad_groups)
         self.geom = None
         self.wf = self.wft = self.bias_f = self.slabs = self.dbias_partials = None
 
@@ -277,10 +278,14 @@ class Engine:
                 c.geom.math = self.math
                 c.geom.h16 = self.h16
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
+        self._plan_wgrad_groups()
         if tune:
             K.load_tune_cache()
             for c in self.convs:          # before the slabs are sized: this chooses the number of pixel splits
-                if c.trainable and c.geom is not None and c.cout > 64 and c.cin > 64:
+                # the head towers keep the launcher's choice (the all-taps kernel): timed alone, the one-tap kernel ties with
+                # it on this shape and a noisy pick costs 60 % on the 8 tower launches once they share the chip
+                if c.trainable and c.geom is not None and c.cout > 64 and c.cin > 64 and not c.grouped \
+                        and c not in self.cls_tower and c not in self.reg_tower:
                     K.autotune_wgrad(c.geom)
         # wgrad slabs / bias partials + descriptor table
         n_slab = sum(c.geom.nsplit * c.wsize for c in self.convs if c.trainable)
@@ -304,6 +309,59 @@ class Engine:
                 if c is not self.stem and c.geom is not None and (self.math or c not in towers):
                     K.autotune(c.geom, need_dgrad=c.need_dgrad)
             K.save_tune_cache()
+
+    # ------------------------------------------------------------------ grouped weight-gradient launches (optional schedule)
+    # The weight-gradient GEMMs of the backbone and the neck are independent of each other and off the critical path;
+    # each one alone is a short grid (150-1000 workgroups incl. pixel splits).  RADET_WGRAD_GROUP=1 collects them while
+    # the dgrad chain of a stage runs and issues ONE grouped launch per stage (radet_conv2d_wgrad_group) on the side
+    # stream: the chip stays full with a few long workgroups per conv, so far fewer pixel splits (= slabs) are needed.
+    # Measured on r50 640x480 bs 4: wgrad kernel time 5.0 -> 3.3 ms per step (42.8 -> 60 TFLOP/s in-step), slab
+    # reduction 0.78 -> 0.50 ms, but the step itself 16.0 -> 16.3 ms: the long-lived workgroups of a group hold their
+    # CU slots for ~0.6 ms and the dependent dgrad chain on the main stream waits for slots more often than next to the
+    # 50 short launches (HIP stream priorities did not change that).  Hence off by default; kept as a tested option
+    # for configurations where the side streams carry more work than the chain (e.g. communication-heavy runs).
+    wgrad_group = os.environ.get("RADET_WGRAD_GROUP", "0") == "1"
+    wgrad_group_tile = int(os.environ.get("RADET_WGRAD_GROUP_TILE", "128"))
+    wgrad_group_slots = int(os.environ.get("RADET_WGRAD_GROUP_SLOTS", "512"))
+    wgrad_flush_blocks = int(os.environ.get("RADET_WGRAD_FLUSH_BLOCKS", "0"))   # blocks per grouped launch; 0: the whole stage
+
+    def _plan_wgrad_groups(self):
+        for c in self.convs:
+            c.grouped = False
+        self._pending_wgrad = []
+        if not self.wgrad_group or self.h16:
+            return
+        t = self.wgrad_group_tile
+        fb = self.wgrad_flush_blocks
+        groups = []
+        for blocks in self.stages:                     # launch groups = runs of `fb` blocks in backward order (0: whole stage)
+            rev = list(reversed(blocks))
+            step = fb if fb > 0 else len(rev)
+            for i in range(0, len(rev), step):
+                groups.append([c for blk in rev[i:i + step] for c in (blk["c1"], blk["c2"], blk["c3"], blk["ds"])
+                               if c is not None and c.trainable])
+        groups.append(list(self.lat) + list(self.fpn))
+        for grp in groups:
+            grp = [c for c in grp if c.cout % t == 0 and c.cin % t == 0]
+            if not grp:
+                continue
+            for c, s in zip(grp, K.group_splits([c.geom for c in grp], tile=t, slots=self.wgrad_group_slots)):
+                c.grouped = True
+                c.geom.nsplit = s
+
+    def flush_wgrads(self):
+        """Issue the collected weight-gradient GEMMs as grouped launches on the side stream (their inputs are complete
+        on the current stream at this point)."""
+        jobs, self._pending_wgrad = self._pending_wgrad, []
+        if not jobs:
+            return
+        if not self.use_streams:
+            K.conv_wgrad_group(jobs, tile=self.wgrad_group_tile, math=self.math)
+            return
+        side = self._side()
+        self._fork(side)
+        with torch.cuda.stream(side):
+            K.conv_wgrad_group(jobs, tile=self.wgrad_group_tile, math=self.math)
 
     def _build_table(self):
         n = len(self.convs)
@@ -442,8 +500,12 @@ class Engine:
         ev.record(side)
         torch.cuda.current_stream().wait_event(ev)
 
-    def _wgrad_async(self, geom, dy, x, slabs, dbias_partials=None):
-        """Weight-gradient GEMM off the critical path: issued on the side stream once `dy` is ready."""
+    def _wgrad_async(self, geom, dy, x, slabs, dbias_partials=None, conv=None):
+        """Weight-gradient GEMM off the critical path: issued on the side stream once `dy` is ready (or collected
+        for the stage's grouped launch, see flush_wgrads)."""
+        if conv is not None and conv.grouped:
+            self._pending_wgrad.append(dict(g=geom, dy=dy, x=x, slabs=slabs, dbias=dbias_partials))
+            return None
         if not self.use_streams:
             K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
             return None
@@ -709,14 +771,14 @@ class Engine:
         tmp = b["dP_tmp"]
         # P7 = conv4(P6); P6 = conv3(P5)
         c4, c3 = self.fpn[4], self.fpn[3]
-        self._wgrad_async(c4.geom, sl(dP, 4), sl(P, 3), c4.slabs, c4.dbias_partials)
+        self._wgrad_async(c4.geom, sl(dP, 4), sl(P, 3), c4.slabs, c4.dbias_partials, conv=c4)
         K.conv_dgrad(c4.geom, sl(dP, 4), c4.wft, sl(tmp, 3), addend=sl(dP, 3))
-        self._wgrad_async(c3.geom, sl(tmp, 3), sl(P, 2), c3.slabs, c3.dbias_partials)
+        self._wgrad_async(c3.geom, sl(tmp, 3), sl(P, 2), c3.slabs, c3.dbias_partials, conv=c3)
         K.conv_dgrad(c3.geom, sl(tmp, 3), c3.wft, sl(tmp, 2), addend=sl(dP, 2))
         srcs = [sl(dP, 0), sl(dP, 1), sl(tmp, 2)]
         for i in range(3):
             c = self.fpn[i]
-            self._wgrad_async(c.geom, srcs[i], b[f"lat{i}"], c.slabs, c.dbias_partials)
+            self._wgrad_async(c.geom, srcs[i], b[f"lat{i}"], c.slabs, c.dbias_partials, conv=c)
             K.conv_dgrad(c.geom, srcs[i], c.wft, b[f"d_lat{i}"])
         hw = self.plv.hw
         for i in (1, 2):
@@ -725,9 +787,10 @@ class Engine:
         for i in range(3):
             c = self.lat[i]
             x = b[f"l{i + 2}.{len(self.stages[i + 1]) - 1}.out"]
-            self._wgrad_async(c.geom, b[f"d_lat{i}"], x, c.slabs, c.dbias_partials)
+            self._wgrad_async(c.geom, b[f"d_lat{i}"], x, c.slabs, c.dbias_partials, conv=c)
             K.conv_dgrad(c.geom, b[f"d_lat{i}"], c.wft, b[f"d_c{i}"])
         del feats
+        self.flush_wgrads()
         return [b["d_c0"], b["d_c1"], b["d_c2"]]
 
     def backbone_backward(self, d_feats, after_stage=None):
@@ -764,14 +827,17 @@ class Engine:
                 blk["d_pre"], blk["d_o1"] = d_pre, d_o1
                 # ---- inside the block
                 c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
-                self._wgrad_async(c3.geom, d_pre, o2, c3.slabs, c3.dbias_partials)
+                self._wgrad_async(c3.geom, d_pre, o2, c3.slabs, c3.dbias_partials, conv=c3)
                 K.conv_dgrad(c3.geom, d_pre, c3.wft, d_o2, mask=o2)
-                self._wgrad_async(c2.geom, d_o2, o1, c2.slabs, c2.dbias_partials)
+                self._wgrad_async(c2.geom, d_o2, o1, c2.slabs, c2.dbias_partials, conv=c2)
                 K.conv_dgrad(c2.geom, d_o2, c2.wft, d_o1, mask=o1)
-                self._wgrad_async(c1.geom, d_o1, blk["x"], c1.slabs, c1.dbias_partials)
+                self._wgrad_async(c1.geom, d_o1, blk["x"], c1.slabs, c1.dbias_partials, conv=c1)
                 if ds is not None:
-                    self._wgrad_async(ds.geom, d_pre, blk["x"], ds.slabs, ds.dbias_partials)
+                    self._wgrad_async(ds.geom, d_pre, blk["x"], ds.slabs, ds.dbias_partials, conv=ds)
                 nxt = blk
+                if self.wgrad_flush_blocks and (len(blocks) - bi) % self.wgrad_flush_blocks == 0:
+                    self.flush_wgrads()
+            self.flush_wgrads()
             if after_stage is not None:
                 after_stage(li)
         return None

@@ -116,7 +116,8 @@ def splitk_ws():
     key = (dev, torch.cuda.current_stream().cuda_stream)
     t = _SPLITK_WS.get(key)
     if t is None:
-        t = torch.empty(16 * 1024 * 1024, device=torch.device("cuda", dev))   # 64 MiB
+        # 64 MiB; zero-initialised: the first words are the arrival tickets of the in-launch split-K reduction
+        t = torch.zeros(16 * 1024 * 1024, device=torch.device("cuda", dev))
         _SPLITK_WS[key] = t
     return t
 
@@ -377,6 +378,34 @@ def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
               g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit,
               (2 if _is16(dy) else (1 if g.math else 0)) | g.wgrad_flags, _stream())
+
+
+def conv_wgrad_group(jobs, tile=128, math=0):
+    """jobs: list of dict(g=ConvGeom, dy, x, slabs, dbias) -- one grouped launch per <= 32 jobs (longest first)."""
+    jobs = sorted(jobs, key=lambda j: -(j["g"].lout.rows // j["g"].nsplit))
+    for i in range(0, len(jobs), 32):
+        part = jobs[i:i + 32]
+        arr = (_lib.RadetWgradJob * len(part))()
+        for a, j in zip(arr, part):
+            g = j["g"]
+            a.dy, a.x, a.slabs = _ptr(j["dy"]), _ptr(j["x"]), _ptr(j["slabs"])
+            a.dbias_partials, a.gather_table = _ptr(j.get("dbias")), _ptr(g.fwd_table)
+            a.M, a.Cin, a.Cout, a.ld_dy, a.KH, a.KW, a.S = g.lout.rows, g.cin, g.cout, g.cout, g.k, g.k, g.nsplit
+        _lib.call("radet_conv2d_wgrad_group", arr, len(part), (1 if math else 0) | ((1 if tile == 128 else 2) << 4), _stream())
+
+
+def group_splits(geoms, tile=128, slots=512):
+    """Pixel splits S per conv of one wgrad group: S = round(M / px) with the pixel target px chosen so that the group's
+    workgroup count fills `slots` resident workgroups (2 per CU) in whole rounds; ties -> fewer splits (fewer slabs)."""
+    best = None
+    for px in (6400, 4800, 3200, 2400, 1600, 1200, 800, 600, 400):
+        S = [max(1, min(64, round(g.lout.rows / px), (g.lout.rows + 127) // 128)) for g in geoms]
+        blocks = sum((g.cout // tile) * (g.cin // tile) * g.k * g.k * s for g, s in zip(geoms, S))
+        eff = blocks / (slots * -(-blocks // slots))
+        cost = -eff + 0.02 * sum(S) / len(S)            # every split is a slab written here and read by the reduction
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, S)
+    return best[1]
 
 
 def fold_weights(table_dev, n):

@@ -108,6 +108,41 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
 
 
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("math", [0, 1], ids=["fp32", "bf16math"])
+def test_wgrad_group_launch(K, tile, math):
+    """radet_conv2d_wgrad_group: several convs' weight gradients in one grid == exact convolution gradients, and
+    bit-identical to the per-conv launches of the same kernel (same tile, same pixel splits)."""
+    cases = [(2, 256, 128, 15, 20, 1, 1), (2, 128, 128, 18, 22, 3, 2), (1, 128, 256, 30, 40, 3, 1), (3, 512, 128, 8, 10, 1, 1),
+             (2, 128, 128, 4, 5, 3, 2)]
+    g = torch.Generator().manual_seed(11)
+    jobs, refs, singles = [], [], []
+    for (B, Cin, Cout, H, W, k, s) in cases:
+        x = torch.randn(B, Cin, H, W, generator=g)
+        pad = k // 2
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+        r = (lambda t: t.bfloat16().double()) if math else (lambda t: t.double())
+        refs.append((torch.nn.grad.conv2d_weight(r(x), (Cout, Cin, k, k), r(dy), stride=s, padding=pad), dy.double().sum((0, 2, 3))))
+        geom = K.ConvGeom(K.Levels([(H, W)], B), Cin, Cout, k, s, pad)
+        geom.math = math
+        geom.nsplit = max(1, min(3, (B * Ho * Wo) // 256))
+        S = geom.nsplit
+        xr, dyr = to_rows(x).cuda(), to_rows(dy).cuda()
+        slabs, bp = torch.zeros(S, Cout, k * k, Cin, device="cuda"), torch.zeros(S, Cout, device="cuda")
+        jobs.append(dict(g=geom, dy=dyr, x=xr, slabs=slabs, dbias=bp))
+        s1, b1 = torch.zeros_like(slabs), torch.zeros_like(bp)
+        geom.wgrad_flags = ((1 if tile == 128 else 2) << 4) | 0x40
+        K.conv_wgrad(geom, dyr, xr, s1, b1)
+        singles.append((s1, b1))
+    K.conv_wgrad_group(jobs, tile=tile, math=math)
+    for j, (gw, gb), (s1, b1), (B, Cin, Cout, H, W, k, s) in zip(jobs, refs, singles, cases):
+        mine = j["slabs"].sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        assert rel_err(mine, gw) < 2e-5
+        assert rel_err(j["dbias"].sum(0), gb) < 2e-5
+        assert torch.equal(j["slabs"], s1) and torch.equal(j["dbias"], b1)
+
+
 H16_CASES = [
     # B, Cin, Cout, H, W, k, stride, tile
     (2, 256, 256, 30, 40, 3, 1, 1),

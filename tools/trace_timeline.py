@@ -1,0 +1,80 @@
+"""Timeline view of a rocprofv3 (rocpd sqlite) kernel trace of bench.py: where one steady-state train step spends its
+time.  Steps are delimited by `adamw_kernel`; for the median of the last N steps it prints the wall time, the time
+the GPU ran >= 1 kernel (union), the summed kernel time, per-queue busy time, the largest idle gaps (with the kernels
+around them) and a per-kernel table (sum / calls / share of the union).
+
+Usage: python tools/trace_timeline.py <results.db> [n_steps=5] [out.txt]"""
+import collections
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name).replace("void ", "")
+    return name[:70]
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cs, ce = 0, None, None
+    gaps = []
+    for s, e in iv:
+        if cs is None:
+            cs, ce = s, e
+        elif s <= ce:
+            ce = max(ce, e)
+        else:
+            tot += ce - cs
+            gaps.append((s - ce, ce, s))
+            cs, ce = s, e
+    if cs is not None:
+        tot += ce - cs
+    return tot, gaps
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    rows = db.execute("select name, start, end, queue_id from kernels order by start").fetchall()
+    rows = [(short(a), s, e, q) for a, s, e, q in rows]
+    ends = [e for a, s, e, q in rows if a.startswith("adamw_kernel")]
+    if len(ends) < n + 1:
+        raise SystemExit(f"only {len(ends)} steps in the trace")
+    out = []
+    steps = []
+    for i in range(len(ends) - n, len(ends)):
+        t0, t1 = ends[i - 1], ends[i]
+        ks = [r for r in rows if r[1] >= t0 and r[2] <= t1]
+        busy, gaps = union([(s, e) for _, s, e, _ in ks])
+        steps.append((t1 - t0, busy, sum(e - s for _, s, e, _ in ks), ks, gaps, t0))
+    steps.sort(key=lambda x: x[0])
+    wall, busy, ksum, ks, gaps, t0 = steps[len(steps) // 2]
+    out.append(f"median of last {n} steps: wall {wall / 1e6:.3f} ms | GPU busy (union) {busy / 1e6:.3f} ms | idle {(wall - busy) / 1e6:.3f} ms | "
+               f"summed kernel time {ksum / 1e6:.3f} ms (overlap x{ksum / busy:.2f}) | {len(ks)} launches")
+    out.append("all steps wall ms: " + " ".join(f"{s[0] / 1e6:.2f}" for s in steps))
+    perq = collections.defaultdict(int)
+    for _, s, e, q in ks:
+        perq[q] += e - s
+    out.append("per-queue busy ms: " + ", ".join(f"q{q}: {v / 1e6:.2f}" for q, v in sorted(perq.items())))
+    gaps.sort(reverse=True)
+    out.append(f"idle gaps: {len(gaps)}; > 5 us: {sum(1 for g in gaps if g[0] > 5000)} totalling {sum(g[0] for g in gaps if g[0] > 5000) / 1e6:.3f} ms; top 12:")
+    for g, a, b in gaps[:12]:
+        before = [r[0] for r in ks if r[2] == a][:1]
+        after = [r[0] for r in ks if r[1] == b][:1]
+        out.append(f"   {g / 1e3:8.1f} us at +{(a - t0) / 1e6:6.3f} ms   after {before}  before {after}")
+    agg = collections.defaultdict(lambda: [0, 0])
+    for a, s, e, q in ks:
+        agg[a][0] += 1
+        agg[a][1] += e - s
+    out.append(f"{'kernel':72s} calls   sum_ms  avg_us  %busy")
+    for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append(f"{k:72s} {c:5d} {d / 1e6:8.3f} {d / c / 1e3:7.1f} {100.0 * d / busy:6.1f}")
+    txt = "\n".join(out)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(txt + "\n")
+    print(txt)
+
+
+if __name__ == "__main__":
+    main()

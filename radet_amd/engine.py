@@ -80,12 +80,15 @@ class Engine:
     TOWER_TAG = 0x100 | 0x200 | 3
 
     def _ttile(self, c, bwd=False, tag=True):
-        """tile_override of a tower conv launch: fixed tile in fp32, autotuned in bf16 math; + profiling tag"""
-        if self.math or self.h16:
-            t = c.geom.bwd_tile if bwd else c.geom.fwd_tile
+        """tile_override of a tower conv launch + profiling tag.  Forward: the measured-best 64x64 tile with a 32-deep K
+        step in every arithmetic mode (the forward launches are grouped cls + reg pairs, which the single-conv timing of
+        the autotuner does not represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch); fp32
+        forward launches run alone on the device -> 3 LDS stages (+8 %: 112 vs 104 TFLOP/s).  Backward: fixed tile in
+        fp32, autotuned in the bf16 modes (single launches, as tuned)."""
+        if bwd and (self.math or self.h16):
+            t = c.geom.bwd_tile
         else:
-            # fp32: 64x64 tile, K step 32; the forward launches run alone -> 3 LDS stages (+8 %: 112 vs 104 TFLOP/s)
-            t = (self.TOWER_TAG & ~0x100) | (0 if bwd else K.STAGES3)
+            t = (self.TOWER_TAG & ~0x100) | (K.STAGES3 if (not bwd and not self.math and not self.h16) else 0)
         return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 
@@ -185,11 +188,43 @@ class Engine:
                     o_t += n
 
     # ------------------------------------------------------------------ geometry-dependent plan
+    # Geometry plans: everything that depends on (B, H, W) -- activation / gradient buffers, conv geometries and their
+    # tuned tiles, slab arenas, the descriptor table -- is kept per geometry in a small LRU, so a harness that alternates
+    # e.g. training at B = 4 with validation at B = 1 neither reallocates nor re-tunes after the first pass.
+    max_plans = int(os.environ.get("RADET_MAX_PLANS", "4"))
+    _PLAN_ATTRS = ("B", "H", "W", "stem_hw", "pool_hw", "buf", "plv", "R", "gn_ws", "gn_ws2", "ldesc", "nlvl", "loss_ws",
+                   "losses", "dscales", "slab_arena", "bp_arena", "table", "_table_keepalive", "max_cout", "_pending_wgrad")
+
+    def _snapshot(self):
+        return dict(attrs={k: getattr(self, k) for k in self._PLAN_ATTRS},
+                    convs=[(c.geom, c.slabs, c.dbias_partials, c.grouped) for c in self.convs],
+                    blocks=[[(blk.get("lin"), blk.get("lout")) for blk in blocks] for blocks in self.stages])
+
+    def _restore(self, plan):
+        for k, v in plan["attrs"].items():
+            setattr(self, k, v)
+        for c, (g, sl, bp, gr) in zip(self.convs, plan["convs"]):
+            c.geom, c.slabs, c.dbias_partials, c.grouped = g, sl, bp, gr
+        for blocks, saved in zip(self.stages, plan["blocks"]):
+            for blk, (lin, lout) in zip(blocks, saved):
+                blk["lin"], blk["lout"] = lin, lout
+
     def prepare(self, B, H, W):
         key = (B, H, W)
         if self.geo_key == key:
             return
+        if not hasattr(self, "_plans"):
+            import collections
+            self._plans = collections.OrderedDict()
+        if self.geo_key is not None:
+            self._plans[self.geo_key] = self._snapshot()          # most recently used goes last
+            while len(self._plans) >= max(self.max_plans, 1):
+                self._plans.popitem(last=False)                   # evict the least recently used plan (frees its buffers)
         self.geo_key = key
+        if key in self._plans:
+            self._restore(self._plans.pop(key))
+            return
+        self.plans_built = getattr(self, "plans_built", 0) + 1
         dev = self.dev
         self.B, self.H, self.W = B, H, W
         h1, w1 = conv_out_hw(H, W, 7, 2, 3)

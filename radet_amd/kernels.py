@@ -52,7 +52,21 @@ def _desc(pairs):
     return (C.c_int * len(flat))(*flat), len(pairs)
 
 
-_TABLE_CACHE = {}
+class _LRU(dict):
+    """dict with a size bound: the oldest insertions are dropped first (a dropped gather table / tune entry is simply
+    rebuilt on its next use)."""
+
+    def __init__(self, cap):
+        super().__init__()
+        self.cap = cap
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        while len(self) > self.cap:
+            del self[next(iter(self))]
+
+
+_TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometry (~80 per (B, H, W) plan)
 STRIDED_DGRAD_CLASSES = True   # parity-class dgrad for strided convs (False = one dense launch)
 
 
@@ -168,56 +182,96 @@ def _strided_dgrad_classes(g):
     return out
 
 
-_TUNE_CACHE = {}
+_TUNE_CACHE = _LRU(8192)
 _TUNE_DIRTY = False
+TUNE_RUNS = 0                  # number of shapes actually timed in this process (tests: no re-tune after the first pass)
+
+
+# Tile / split choices are persisted per conv geometry:
+#   1. radet_amd/tune_gfx950.json -- shipped with the package: the choices for the standard geometries (r50 640x480 at
+#      B = 1, 2, 4, 8 in the three arithmetic modes, r101 800x800 B = 2), produced by tools/make_tune.py on an MI355X, so
+#      that identical runs pick identical tiles (reproducible losses, no start-up tuning);
+#   2. the user file ($RADET_TUNE_FILE, default ~/.cache/radet_amd/tune_gfx950.json) -- shapes tuned on this machine.
+# Unknown shapes are timed once and appended to the user file.  RADET_AUTOTUNE=0 disables tuning AND the files
+# (launcher heuristics only).
+_PACKAGED_TUNE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_gfx950.json")
+_TUNE_LOADED = False
 
 
 def _tune_file():
-    return os.environ.get("RADET_TUNE_FILE")
+    return os.environ.get("RADET_TUNE_FILE") or os.path.join(os.path.expanduser("~"), ".cache", "radet_amd", "tune_gfx950.json")
+
+
+def _read_tune(path):
+    import ast
+    import json
+    with open(path) as fh:
+        d = json.load(fh)
+    return ({ast.literal_eval(k): tuple(v) for k, v in d.get("igemm", {}).items()},
+            {ast.literal_eval(k): tuple(v) for k, v in d.get("wgrad", {}).items()})
 
 
 def load_tune_cache():
-    """RADET_TUNE_FILE=<path>: reuse the (tile, split) choices of an earlier run instead of timing the candidates again
-    (start-up cost, run-to-run identical summation orders, profiles without the tuning launches)."""
-    import pickle
-    f = _tune_file()
-    if f and os.path.exists(f) and not _TUNE_CACHE and not _WTUNE_CACHE:
-        with open(f, "rb") as fh:
-            a, b = pickle.load(fh)
-        _TUNE_CACHE.update(a)
-        _WTUNE_CACHE.update(b)
+    global _TUNE_LOADED
+    if _TUNE_LOADED:
+        return
+    _TUNE_LOADED = True
+    for path in (_PACKAGED_TUNE, _tune_file()):
+        if os.path.exists(path):
+            try:
+                a, b = _read_tune(path)
+            except (ValueError, SyntaxError, OSError):
+                continue                      # unreadable cache: tune again
+            for k, v in a.items():
+                _TUNE_CACHE[k] = v
+            for k, v in b.items():
+                _WTUNE_CACHE[k] = v
 
 
-def save_tune_cache():
-    import pickle
+def save_tune_cache(path=None):
+    """Write every known choice (packaged + tuned here) to the user file; silent if the location is not writable."""
+    import json
     global _TUNE_DIRTY
-    f = _tune_file()
-    if f and _TUNE_DIRTY:
-        with open(f, "wb") as fh:
-            pickle.dump((_TUNE_CACHE, _WTUNE_CACHE), fh)
+    if not _TUNE_DIRTY and path is None:
+        return
+    f = path or _tune_file()
+    try:
+        os.makedirs(os.path.dirname(f) or ".", exist_ok=True)
+        tmp = f + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as fh:
+            json.dump(dict(igemm={repr(k): list(v) for k, v in _TUNE_CACHE.items()},
+                           wgrad={repr(k): list(v) for k, v in _WTUNE_CACHE.items()}), fh, indent=0, sort_keys=True)
+        os.replace(tmp, f)
         _TUNE_DIRTY = False
+    except OSError:
+        pass
 
 
-def autotune(g, need_dgrad=True, reps=3):
+TUNE_REPS = int(os.environ.get("RADET_TUNE_REPS", "3"))      # timed launches per candidate (median)
+
+
+def autotune(g, need_dgrad=True, reps=None):
     """Pick the fastest (block tile, K step) of the implicit-GEMM kernel for this geometry by timing the
     candidates once (results cached per shape, so identical layers and identical models agree)."""
     dev = torch.device("cuda", torch.cuda.current_device())
+    reps = reps or TUNE_REPS
 
     def best_of(fn, cands):
-        out = []
+        """fastest candidate: `reps` interleaved rounds over all candidates (clock / cache drift hits every candidate
+        alike), each candidate scored by its fastest round"""
         for t in cands:
             fn(t)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(reps):
+        torch.cuda.synchronize()
+        best = [float("inf")] * len(cands)
+        for _ in range(reps):
+            for i, t in enumerate(cands):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 fn(t)
                 e.record()
                 e.synchronize()
-                ts.append(s.elapsed_time(e))
-            out.append((sorted(ts)[len(ts) // 2], t))
-        return min(out)[1]
+                best[i] = min(best[i], s.elapsed_time(e))
+        return cands[min(range(len(cands)), key=lambda i: (best[i], i))]
 
     def cands(kdim, n, m, taps):
         tiles = [4] if n <= 32 else [1, 2, 3]
@@ -235,10 +289,11 @@ def autotune(g, need_dgrad=True, reps=3):
                 out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
         return out
 
-    global _TUNE_DIRTY
+    global _TUNE_DIRTY, TUNE_RUNS
     key = (g._key, g.cin, g.cout, g.math, g.h16)
     if key not in _TUNE_CACHE:
         _TUNE_DIRTY = True
+        TUNE_RUNS += 1
         dt = torch.bfloat16 if g.h16 else torch.float32
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         w = (torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05).to(dt)
@@ -284,18 +339,20 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
               _stream())
 
 
-_WTUNE_CACHE = {}
+_WTUNE_CACHE = _LRU(8192)
 
 
-def autotune_wgrad(g, reps=3):
+def autotune_wgrad(g, reps=None):
     """Pick (tile, pixel splits S) of the one-tap wgrad kernel for this geometry: time the candidates and charge each
     split its downstream cost (a weight-sized slab is written here and read again by unfold: ~2 * 4 B / weight at
     ~3 TB/s).  Must run before the slab buffers are sized (it changes g.nsplit)."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    global _TUNE_DIRTY
+    reps = reps or TUNE_REPS
+    global _TUNE_DIRTY, TUNE_RUNS
     key = (g._key, g.cin, g.cout, g.math, g.h16, "w")
     if key not in _WTUNE_CACHE:
         _TUNE_DIRTY = True
+        TUNE_RUNS += 1
         M, kk = g.lout.rows, g.k * g.k
         s0 = g.nsplit
         cands = [(0, s0)]
@@ -310,20 +367,23 @@ def autotune_wgrad(g, reps=3):
         dy = torch.randn(M, g.cout, device=dev).to(dt)
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         slabs = torch.empty(max(c[1] for c in cands) * g.cout * kk * g.cin, device=dev)
-        best = None
         for fl, S in cands:
             g.wgrad_flags, g.nsplit = fl, S
             conv_wgrad(g, dy, x, slabs)
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(reps):
+        torch.cuda.synchronize()
+        tbest = [float("inf")] * len(cands)
+        for _ in range(reps):
+            for i, (fl, S) in enumerate(cands):
+                g.wgrad_flags, g.nsplit = fl, S
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 conv_wgrad(g, dy, x, slabs)
                 e.record()
                 e.synchronize()
-                ts.append(s.elapsed_time(e))
-            cost = sorted(ts)[len(ts) // 2] + S * g.cout * kk * g.cin * 8 / 3e12 * 1e3
+                tbest[i] = min(tbest[i], s.elapsed_time(e))
+        best = None
+        for (fl, S), t in zip(cands, tbest):
+            cost = t + S * g.cout * kk * g.cin * 8 / 3e12 * 1e3
             if best is None or cost < best[0]:
                 best = (cost, fl, S)
         _WTUNE_CACHE[key] = best[1:]

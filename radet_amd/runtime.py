@@ -422,17 +422,19 @@ def _post_launch(self, hw, sf, test_cfg, head_out=None):
     if cap > 8192:
         raise NotImplementedError(f"nms_pre={nms_pre}: more than 8192 candidates per image exceed the on-chip NMS sort")
     key = ("post", B, nlvl, nms_pre)
-    if getattr(self, "_post_key", None) != key:
+    posts = self.__dict__.setdefault("_posts", {})
+    if key not in posts:
+        if len(posts) >= 8:
+            posts.pop(next(iter(posts)))
         dev = self.dev
-        self._post = dict(
+        posts[key] = dict(
             boxes=torch.empty(B, cap, 4, device=dev), scores=torch.empty(B, cap, device=dev),
             ctr=torch.empty(B, cap, device=dev), labels=torch.empty(B, cap, dtype=torch.long, device=dev),
             count=torch.zeros(B, dtype=torch.int32, device=dev), cscore=torch.empty(B, cap, device=dev),
             dws=torch.empty(K.decode_ws_bytes(B, nlvl, nms_pre), dtype=torch.uint8, device=dev),
             nws=torch.empty(K.nms_ws_bytes(B, cap), dtype=torch.uint8, device=dev),
             aux0=torch.zeros(B, cap, dtype=torch.long, device=dev), aux1=torch.zeros(B, cap, dtype=torch.long, device=dev))
-        self._post_key = key
-    p = self._post
+    p = posts[key]
     K.decode_candidates(ho["cls"], ho["reg"], ho["iou"], ho["scales"], ho["ldesc"], nlvl, B, self.num_classes,
                         float(test_cfg["score_thr"]), nms_pre, hw, sf, p["boxes"], p["scores"], p["ctr"], p["labels"],
                         p["count"], p["dws"])
@@ -484,7 +486,10 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
         img = img.to(self.dev)
         key = (tuple(img.shape), bool(rescale), repr(sorted(dict(test_cfg).items(), key=str)))
         cache = self.__dict__.setdefault("_graphs", {})
+        self.engine.prepare(img.shape[0], img.shape[2], img.shape[3])
         g = cache.get(key)
+        if g is not None and g["plan"] is not self.engine.buf:    # the geometry plan was evicted and rebuilt: stale pointers
+            g = None
         if g is None:
             hw, sf = _meta_tensors(self, img_metas, rescale)
             static_img = img.clone()
@@ -498,7 +503,7 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
             with torch.cuda.graph(graph, stream=cap_stream):
                 self.forward(static_img)
                 outs = _post_launch(self, hw, sf, test_cfg)
-            g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs)
+            g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs, plan=self.engine.buf)
         else:
             hw, sf = _meta_tensors(self, img_metas, rescale)
             g["hw"].copy_(hw)

@@ -209,3 +209,47 @@ def test_detect_hipgraph_replay_matches_eager():
         for (da, la), (db, lb) in zip(a, b):
             assert torch.equal(da, db) and torch.equal(la, lb)
         assert sum(d.shape[0] for d, _ in a) > 0
+
+
+def test_multi_geometry_plans_no_retune_no_realloc():
+    """Engine keeps a plan per (B, H, W): alternating training at B = 4 with detection at B = 1 (a harness that
+    interleaves validation) builds each plan once -- no second autotune, no reallocation, identical results."""
+    from oracle import synth
+    from radet_amd import kernels as K
+    det = make_det().train()
+    rt = det.runtime()
+    rt.init_optimizer(max_norm=35.0)
+    rt.set_loss_from_head(det.bbox_head)
+    img4 = synth.synth_images(3, 4).cuda()
+    img1 = synth.synth_images(4, 1).cuda()
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "assigner.npz"))
+    tags = ("g8", "g3", "g1", "g20")
+    tg = rt.pack_targets([torch.from_numpy(a[t + "_boxes"]) for t in tags], [torch.from_numpy(a[t + "_labels"]) for t in tags],
+                         [torch.from_numpy(a[t + "_p2g"].astype(np.int64)) for t in tags], [torch.from_numpy(a[t + "_w"]) for t in tags])
+    metas = synth.img_metas(1)
+    rt.train_step(img4, tg, lr=1e-5)
+    first = rt.detect(img1, metas, det.test_cfg)
+    torch.cuda.synchronize()
+    built, tuned = rt.engine.plans_built, K.TUNE_RUNS
+    ptr4 = None
+    mem = None
+    for it in range(10):
+        rt.train_step(img4, tg, lr=0.0)                       # lr = 0 and wd * lr = 0: weights stay put
+        p = rt.engine.buf["P"].data_ptr()
+        assert ptr4 is None or p == ptr4
+        ptr4 = p
+        res = rt.detect(img1, metas, det.test_cfg)
+        assert rt.engine.buf["P"].data_ptr() != ptr4           # the B = 1 plan has its own buffers
+        torch.cuda.synchronize()
+        if it == 1:
+            mem = torch.cuda.memory_allocated()
+        if it > 1:
+            assert torch.cuda.memory_allocated() == mem
+    assert rt.engine.plans_built == built == 2 and K.TUNE_RUNS == tuned
+    assert torch.equal(res[0][0], first[0][0]) and torch.equal(res[0][1], first[0][1])
+    # LRU bound: a 5th geometry evicts the oldest plan, which is rebuilt (not corrupted) when it comes back
+    for hw in ((128, 160), (160, 128), (96, 128), (128, 96)):
+        rt.detect(synth.synth_images(5, 1, *hw).cuda(), synth.img_metas(1, *hw), det.test_cfg)
+    assert len(rt.engine._plans) <= rt.engine.max_plans
+    again = rt.detect(img1, metas, det.test_cfg)
+    assert torch.equal(again[0][0], first[0][0])

@@ -94,9 +94,113 @@ def test_train_step_is_deterministic():
         det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
         rt = det.runtime()
         rt.init_optimizer()
-        img, boxes, labels, p2g, pw = bench.make_batch(0, 2, torch.device("cuda"))
+        img, boxes, labels, p2g, pw = bench.make_batch(0, 4, torch.device("cuda"))     # the headline batch (bs = 4)
         tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
         for _ in range(2):
             losses = rt.train_step(img, tg).clone()
         outs.append((losses.cpu(), rt.flat.params.clone().cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs 3 / 5 at full size
+def _synth_batch(B, H, W, seed):
+    """images + 1..8 boxes with elliptical visible masks per image + GPU-assigned points, like bench.make_batch"""
+    import bench
+    from radet_amd.datasets import LabelAssignment
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, H, W, generator=g).cuda()
+    boxes, labels, masks, rngs = [], [], [], []
+    for i in range(B):
+        b, l, m = bench.synth_objects(rng, int(rng.randint(1, 9)), H, W)
+        boxes.append(b); labels.append(l); masks.append(m); rngs.append(np.random.RandomState(seed * 10 + i))
+    la = LabelAssignment(neg_threshold=0.2, positive_num=10, adapt_positive_num=False, balance_sample=True)
+    p2g, pw = la.assign_batch(boxes, masks, (H, W, 3), rngs=rngs)
+    return img, boxes, labels, p2g, pw
+
+
+def _runtime(depth, math, seed=0):
+    import os
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    cfg.model["backbone"]["depth"] = depth
+    torch.manual_seed(seed)
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+    rt = det.runtime(math=math)
+    rt.init_optimizer()
+    rt.set_loss_from_head(det.bbox_head)
+    return det, rt
+
+
+def test_config5_r101_800x800_bs2_full_size():
+    """BASELINE configs[4]: ResNet-101, 800 x 800, bs 2 (levels 100^2 ... 7^2, N = 13 343 points / image, 26 686 head rows):
+    the tile / split-K / tail-split choices of this geometry are driven through a whole train step -- finite losses,
+    a loss that goes down, two runs bit-identical; the 100 x 100-level GEMM of this geometry is exactly linear under
+    power-of-two scalings (fwd / dgrad / wgrad), whatever tile the tuner picked for it."""
+    from radet_amd import kernels as K
+    outs = []
+    for rep in range(2):
+        det, rt = _runtime(101, "fp32")
+        img, boxes, labels, p2g, pw = _synth_batch(2, 800, 800, seed=7)
+        assert p2g.shape == (2, 13343)
+        tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+        hist = [rt.train_step(img, tg, lr=1e-4).clone() for _ in range(4)]
+        assert rt.engine.R == 26686 and all(torch.isfinite(h).all() for h in hist)
+        assert float(hist[-1].sum()) < float(hist[0].sum())
+        outs.append((torch.stack(hist).cpu(), rt.flat.params.clone().cpu()))
+        if rep == 0:
+            e = rt.engine
+            g = e.cls_tower[0].geom                                    # all five levels of the 800 x 800 pyramid, B = 2
+            gen = torch.Generator().manual_seed(1)
+            x = torch.randn(g.lin.rows, 256, generator=gen).cuda()
+            w = (torch.randn(256, 9, 256, generator=gen) * 0.02).cuda()
+            y1, y2 = torch.empty(g.lout.rows, 256, device="cuda"), torch.empty(g.lout.rows, 256, device="cuda")
+            K.conv_fwd(g, x, w, None, y1, tile=e._ttile(e.cls_tower[0], tag=False))
+            K.conv_fwd(g, 2 * x, w / 4, None, y2, tile=e._ttile(e.cls_tower[0], tag=False))
+            assert torch.equal(y2 * 2, y1)
+            K.conv_dgrad(g, x, w, y1, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False))
+            K.conv_dgrad(g, x * 0.5, w * 8, y2, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False))
+            assert torch.equal(y2 * 0.25, y1)
+            S = g.nsplit
+            s1, s2 = torch.empty(S, 256, 9, 256, device="cuda"), torch.empty(S, 256, 9, 256, device="cuda")
+            K.conv_wgrad(g, y1, x, s1)
+            K.conv_wgrad(g, y1 * 4, x * 0.5, s2)
+            assert torch.equal(s2 * 0.5, s1)
+            lg = e.stages[2][5]["c2"].geom                             # a layer3 3x3 (50 x 50, M = 5000: split-K territory)
+            x3 = torch.randn(lg.lin.rows, lg.cin, generator=gen).cuda()
+            w3 = (torch.randn(lg.cout, 9, lg.cin, generator=gen) * 0.02).cuda()
+            a1, a2 = torch.empty(lg.lout.rows, lg.cout, device="cuda"), torch.empty(lg.lout.rows, lg.cout, device="cuda")
+            K.conv_fwd(lg, x3, w3, None, a1, relu=True)
+            K.conv_fwd(lg, x3 * 2, w3 * 0.5, None, a2, relu=True)
+            assert torch.equal(a1, a2)
+        del det, rt
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_config3_bf16_storage_640x480_bs4_full_size():
+    """BASELINE configs[2] arithmetic at the headline size: bf16 tensors in HBM, bs 4, 640 x 480.  Finite losses, two runs
+    bit-identical, and the first-step loss triple within the bf16 bound of the fp32 engine on the same weights / batch
+    (bf16 has 8 mantissa bits: relative differences of a few 1e-3 after ~60 rounded layers; bound 3e-2)."""
+    img, boxes, labels, p2g, pw = _synth_batch(4, 480, 640, seed=3)
+    ref = None
+    res = {}
+    for math in ("fp32", "bf16-storage", "bf16-storage"):
+        det, rt = _runtime(50, math)
+        tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+        hist = torch.stack([rt.train_step(img, tg, lr=1e-4).clone() for _ in range(3)]).cpu()
+        assert torch.isfinite(hist).all()
+        res.setdefault(math, []).append((hist, rt.flat.params.clone().cpu()))
+        if math == "fp32":
+            ref = hist[0]
+        else:
+            assert rt.engine.buf["P"].dtype == torch.bfloat16 and rt.engine.B == 4
+            rel = ((hist[0] - ref).abs() / ref.abs().clamp_min(1e-6)).max().item()
+            assert rel < 3e-2, (hist[0], ref)
+        del det, rt
+        torch.cuda.empty_cache()
+    (h1, p1), (h2, p2) = res["bf16-storage"]
+    assert torch.equal(h1, h2) and torch.equal(p1, p2)

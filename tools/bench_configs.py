@@ -48,10 +48,11 @@ def infer(n_images=1000, B=8):
         ndet += sum(int(d.shape[0]) for d, _ in out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    cand = int(rt._post["count"].sum().item())
+    post = next(iter(rt._posts.values()))           # the decode / NMS buffers of this (B, nms_pre)
+    cand = int(post["count"].sum().item())
     if os.environ.get("RADET_DBG_LABELS"):
-        c0 = int(rt._post["count"][0].item())
-        print("label histogram img0:", torch.bincount(rt._post["labels"][0, :c0], minlength=21).tolist())
+        c0 = int(post["count"][0].item())
+        print("label histogram img0:", torch.bincount(post["labels"][0, :c0], minlength=21).tolist())
     print(f"config4 inference: {n_images / dt:.1f} images/sec, {ndet / dt:.0f} detections/sec "
           f"(B={B}, {100 * passed:.1f} % of cls scores > 0.05, {cand / B:.0f} candidates/img into vote-NMS, "
           f"{ndet / (n_images // B * B):.0f} dets/img)")

@@ -203,6 +203,13 @@ int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t*
                         int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw, int* used,
                         void* ws, void* stream);
 
+/* same with float per-box distance maps f32 [sumG, H, W] (mask-free sampler: MBD / GDT output mapped into the image,
+ * radet/datasets/pipelines/loading.py:586-645, read as np.float32 by label_assignment.py:85-92) */
+int radet_assign_points_f(const float* gt_boxes, const int* gt_off, const float* distance_maps, int H, int W,
+                          const double* uniforms, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
+                          int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw, int* used,
+                          void* ws, void* stream);
+
 /* ---- box-to-distance transforms of the mask-free sampler (GenerateDistanceMap(with_gt_mask=False)):
  *      pybind ops bbox2distance_ext.{MBD, GDT} (radet/ops/bbox2distance/bbox2distance_ext.cpp:127-133, 225-236), batched
  *      over box crops.  img_desc_dev[n][5] = (pixel offset of the crop in the packed arrays, h, w, first seed, seeds);
@@ -213,6 +220,23 @@ int radet_mbd(const uint8_t* images, const int* img_desc_dev, int nimg, const in
               int niter, int base_size, double* dmap, size_t total_px, void* ws, void* stream);
 int radet_gdt(const float* cost, const int* img_desc_dev, int nimg, const int* seeds_x, const int* seeds_y, float* dist,
               void* ws_labels /* int32 [px] */, void* stream);
+
+/* ---- image processing around those transforms (radet/ops/bbox2distance/bbox2distance_wrapper.py:80-93, 118-130,
+ *      170-181: cv2.resize / cv2.GaussianBlur / cv2.cvtColor / cv2.Sobel / cv2.addWeighted), batched over packed crops:
+ *      *_desc (device) = ncrop x 3 ints {pixel offset, height, width}; max_*_px = the largest crop's pixel count (grid).
+ *      OpenCV's generic algorithms restated (cv2 is absent: parity unpinned against cv2, pinned by oracle/imgproc.py):
+ *      8-bit INTER_LINEAR with 11-bit fixed-point coefficients, float / double INTER_LINEAR, 9x9 Gaussian (sigma 1.7,
+ *      kernel5 (host) = centre tap + 4 taps, BORDER_REFLECT_101, round to nearest even; tmp = 3 floats per pixel), and
+ *      the Sobel edge map (3x3 Gaussian, RGB2GRAY, |0.5 d/dx + 0.5 d/dy| / max; gray_ws 1 byte per pixel, max_ws
+ *      one word per crop). */
+int radet_resize_linear_u8(const uint8_t* src, const int* src_desc, uint8_t* dst, const int* dst_desc, int ncrop,
+                           int max_dst_px, int channels, void* stream);
+int radet_resize_linear_f(const void* src, const int* src_desc, void* dst, const int* dst_desc, int ncrop, int max_dst_px,
+                          int is_f64, void* stream);
+int radet_gaussian_blur9_u8(const uint8_t* src, const int* desc, uint8_t* dst, float* tmp, const float* kernel5, int ncrop,
+                            int max_px, void* stream);
+int radet_sobel_edge(const uint8_t* src, const int* desc, float* edge, uint8_t* gray_ws, uint32_t* max_ws, int ncrop,
+                     int max_px, void* stream);
 
 /* ---- instance-mask path feeding the assigner: BitmapMasks.rescale / resize / flip / pad
  *      (core/mask/structures.py:253-303: mmcv.imresize = cv2.INTER_NEAREST, np.flip, np.pad per mask) fused into one

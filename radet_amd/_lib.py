@@ -63,6 +63,11 @@ SIGNATURES = {
     "radet_nms": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "radet_assign_ws_bytes": (_sz, [_i, _i]),
     "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_assign_points_f": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_resize_linear_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "radet_resize_linear_f": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "radet_gaussian_blur9_u8": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "radet_sobel_edge": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "radet_stem_conv_bn_relu_h": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "radet_maxpool3x3s2_h": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "radet_gn_relu_fwd_h": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),

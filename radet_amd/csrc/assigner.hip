@@ -97,8 +97,11 @@ __device__ __forceinline__ int upper_bound_d(const double* cdf, int n, double x)
     return lo;
 }
 
+// MT = uint8_t: visible instance masks (GenerateDistanceMap(with_gt_mask=True)); float: the per-box distance maps of
+// the mask-free sampler (MBD / GDT transforms, loading.py:586-645), read as np.float32 like label_assignment.py:85-92
+template <class MT>
 __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ gt_boxes, const int* __restrict__ gt_off,
-                                                     const uint8_t* __restrict__ masks, int H, int W,
+                                                     const MT* __restrict__ masks, int H, int W,
                                                      const double* __restrict__ uniforms, int U, const AsgLevels L,
                                                      int K, float neg_thr, int64_t* __restrict__ p2g_all,
                                                      float* __restrict__ pw_all, int* __restrict__ used_out,
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         const int g = order[oi];
         const float* bb = gt_boxes + (size_t)(g0 + g) * 4;
         const float x1 = bb[0], y1 = bb[1], x2 = bb[2], y2 = bb[3];
-        const uint8_t* mk = masks + (size_t)(g0 + g) * H * W;
+        const MT* mk = masks + (size_t)(g0 + g) * H * W;
         // ---- candidates, ordered
         int nc = 0;
         float pmax = 0.f;
@@ -282,10 +285,10 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
 
 extern "C" size_t radet_assign_ws_bytes(int B, int N) { return (size_t)B * (((size_t)N * 32 + 255) / 256 * 256); }
 
-extern "C" int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
-                                   const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
-                                   int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw,
-                                   int* used, void* ws, void* stream) {
+template <class MT>
+static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks, int H, int W, const double* uniforms, int U,
+                       const int* level_desc, const float* regress_ranges, int nlvl, int B, int positive_num,
+                       float neg_threshold, int64_t* p2g, float* pw, int* used, void* ws, void* stream) {
     if (nlvl < 1 || nlvl > RADET_MAX_SEG || positive_num < 1 || positive_num > ASG_MAXK || B < 1) return RADET_ERR_ARG;
     AsgLevels L;
     L.n = nlvl;
@@ -299,7 +302,23 @@ extern "C" int radet_assign_points(const float* gt_boxes, const int* gt_off, con
     L.pt_off[nlvl] = pt;
     for (int l = nlvl; l < RADET_MAX_SEG; ++l) { L.h[l] = 1; L.w[l] = 1; L.stride[l] = 1; L.lo[l] = 0.f; L.hi[l] = 0.f; }
     const size_t per = ((size_t)pt * 32 + 255) / 256 * 256;
-    hipLaunchKernelGGL(assign_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_off, masks, H, W, uniforms,
+    hipLaunchKernelGGL(assign_kernel<MT>, dim3(B), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_off, masks, H, W, uniforms,
                        U, L, positive_num, neg_threshold, p2g, pw, used, (char*)ws, per);
     return radet_check_launch();
+}
+
+extern "C" int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
+                                   const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
+                                   int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw,
+                                   int* used, void* ws, void* stream) {
+    return assign_impl<uint8_t>(gt_boxes, gt_off, masks, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B, positive_num,
+                                neg_threshold, p2g, pw, used, ws, stream);
+}
+
+extern "C" int radet_assign_points_f(const float* gt_boxes, const int* gt_off, const float* distance_maps, int H, int W,
+                                     const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
+                                     int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw,
+                                     int* used, void* ws, void* stream) {
+    return assign_impl<float>(gt_boxes, gt_off, distance_maps, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B,
+                              positive_num, neg_threshold, p2g, pw, used, ws, stream);
 }

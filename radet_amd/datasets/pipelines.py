@@ -1,6 +1,7 @@
 """Data-pipeline stages that belong to the detector hot path: the visibility-guided label assigner
-(radet/datasets/pipelines/label_assignment.py:15-201) on the GPU, batched over images, and the
-GenerateDistanceMap(with_gt_mask=True) pass-through (loading.py:579-581)."""
+(radet/datasets/pipelines/label_assignment.py:15-201) on the GPU, batched over images, and GenerateDistanceMap
+(loading.py:543-650): the pass-through of the visible masks and the mask-free variant built on the GPU box-to-distance
+transforms."""
 import ctypes as C
 import math
 
@@ -20,14 +21,70 @@ def build_pipeline(cfg):
 
 @PIPELINES.register_module()
 class GenerateDistanceMap:
-    def __init__(self, with_gt_mask=True, **kwargs):
+    """radet/datasets/pipelines/loading.py:543-650.  with_gt_mask=True (every BOP config): the visible masks are the
+    sampling maps.  with_gt_mask=False (mask-free sampler): every gt box is cropped with `pad_ratio` padding (random fill
+    colour outside the image, Python's `random` like the reference), the crops go through the GDT / MBD box-to-distance
+    transform on the GPU (radet_amd.ops.GDT_box2distance / MBD_box2distance, all crops of the image batched) and the
+    resulting maps are pasted into zero images: `distance_maps` = f32 [G, img_h, img_w] on the device."""
+
+    def __init__(self, with_gt_mask=True, small_object_size=32 ** 2, pad_ratio=0.05, distance_transform="gdt", **kwargs):
+        self.with_gt_mask, self.small_object_size = with_gt_mask, small_object_size
         if not with_gt_mask:
-            raise NotImplementedError("GenerateDistanceMap(with_gt_mask=False): the MBD / GDT transforms exist "
-                                      "(radet_amd.ops.mbd_batch / gdt_batch), the cv2 crop resize / blur / edge extraction "
-                                      "around them is not restated; every BOP config uses with_gt_mask=True")
+            from ..ops import GDT_box2distance, MBD_box2distance
+            self.pad_ratio = pad_ratio
+            if distance_transform == "gdt":
+                self.distance_transform = GDT_box2distance(**kwargs)
+            elif distance_transform == "mbd":
+                self.distance_transform = MBD_box2distance(**kwargs)
+            else:
+                raise RuntimeError(f"Unexpected distance transform type, expect 'mbd' or 'gdt', got{distance_transform}")
+
+    def forward_with_gt_mask(self, results):
+        return results["gt_masks"]
+
+    def crop_boxes(self, img, img_shape, gt_bboxes):
+        """loading.py:596-634: padded box crops, the box's own region inside each crop, and which boxes are large enough"""
+        import random
+        img_h, img_w = int(img_shape[0]), int(img_shape[1])
+        areas = (gt_bboxes[:, 2] - gt_bboxes[:, 0] + 1) * (gt_bboxes[:, 3] - gt_bboxes[:, 1] + 1)
+        maskenable = areas > self.small_object_size
+        boxes = gt_bboxes.copy().astype(np.int_)
+        box_images, regions = [], np.zeros_like(boxes)
+        for i, xyxy in enumerate(boxes):
+            pad_x = math.ceil((xyxy[2] - xyxy[0]) * self.pad_ratio)
+            pad_y = math.ceil((xyxy[3] - xyxy[1]) * self.pad_ratio)
+            box_image = np.zeros((xyxy[3] - xyxy[1] + 2 * pad_y, xyxy[2] - xyxy[0] + 2 * pad_x, 3), dtype=np.uint8)
+            box_image[:, :, :] = [random.randint(0, 255) for _ in range(3)]
+            bh, bw = box_image.shape[:2]
+            o = xyxy.copy()
+            xyxy += np.array([-pad_x, -pad_y, pad_x, pad_y], dtype=xyxy.dtype)
+            rx1, ry1 = np.clip(xyxy[0], 0, img_w - 1), np.clip(xyxy[1], 0, img_h - 1)
+            rx2, ry2 = np.clip(xyxy[2], 0, img_w - 1), np.clip(xyxy[3], 0, img_h - 1)
+            bx1, by1 = rx1 - xyxy[0], ry1 - xyxy[1]
+            bx2, by2 = bw - (xyxy[2] - rx2), bh - (xyxy[3] - ry2)
+            box_image[by1:by2, bx1:bx2] = img[ry1:ry2, rx1:rx2]
+            regions[i] = np.array([o[0] - xyxy[0], o[1] - xyxy[1], bw - (xyxy[2] - o[2]), bh - (xyxy[3] - o[3])])
+            box_images.append(box_image)
+        return box_images, maskenable, regions
+
+    def forward_wo_gt_mask(self, results):
+        img = results["img"]
+        img_h, img_w, _ = results["img_shape"]
+        assert isinstance(img, np.ndarray), f"image should be numpy.ndarray, got {type(img)}"
+        assert img.dtype == np.uint8, f"image dtype should be np.uint8, got{img.dtype}"
+        assert img.ndim == 3, f"image should have three channel and BGR format, got{img.ndim} channels"
+        gt_bboxes = results["gt_bboxes"]
+        box_images, maskenable, regions = self.crop_boxes(img, (img_h, img_w), gt_bboxes)
+        maps = self.distance_transform(box_images, maskenable, regions)
+        dev = maps[0].device if maps else torch.device("cuda", torch.cuda.current_device())
+        out = torch.zeros(len(maps), img_h, img_w, dtype=torch.float32, device=dev)
+        for k, (m, bbox) in enumerate(zip(maps, gt_bboxes)):
+            b = bbox.astype(np.int_)
+            out[k, b[1]:b[3], b[0]:b[2]] = m.to(torch.float32)
+        return out
 
     def __call__(self, results):
-        results["distance_maps"] = results["gt_masks"]
+        results["distance_maps"] = self.forward_with_gt_mask(results) if self.with_gt_mask else self.forward_wo_gt_mask(results)
         return results
 
 
@@ -80,8 +137,11 @@ class LabelAssignment:
         tot = int(off[-1])
         boxes = np.concatenate([np.asarray(b, np.float32).reshape(-1, 4) for b in gt_bboxes]) if tot else np.zeros((1, 4), np.float32)
         if tot:
-            mk = torch.cat([torch.as_tensor(np.asarray(m) if not isinstance(m, torch.Tensor) else m).reshape(-1, H, W).to(torch.uint8)
-                            for m, c in zip(masks, counts) if c > 0]).to(dev).contiguous()
+            ts = [torch.as_tensor(np.asarray(m) if not isinstance(m, torch.Tensor) else m).reshape(-1, H, W)
+                  for m, c in zip(masks, counts) if c > 0]
+            # visible masks are bytes; the mask-free sampler hands float distance maps (read as float32 like the reference)
+            mdt = torch.float32 if any(t.is_floating_point() for t in ts) else torch.uint8
+            mk = torch.cat([t.to(dev, mdt) for t in ts]).contiguous()
         else:
             mk = torch.zeros(1, H, W, dtype=torch.uint8, device=dev)
         U = self.uniform_budget
@@ -111,7 +171,14 @@ class LabelAssignment:
     def __call__(self, results):
         h, w, _ = results["img_shape"]
         dm = results["distance_maps"]
-        dm = dm.to_ndarray() if hasattr(dm, "to_ndarray") else np.asarray(dm)
+        if hasattr(dm, "masks") and isinstance(dm.masks, torch.Tensor):
+            dm = dm.masks                                     # device-resident BitmapMasks
+        elif hasattr(dm, "to_ndarray"):
+            dm = dm.to_ndarray()
+        elif isinstance(dm, (list, tuple)) and len(dm) and isinstance(dm[0], torch.Tensor):
+            dm = torch.stack(list(dm))                        # per-box distance maps of the mask-free sampler
+        elif not isinstance(dm, torch.Tensor):
+            dm = np.asarray(dm)
         p2g, pw = self.assign_batch([results["gt_bboxes"]], [dm], (h, w))
         results["points_to_gt_index"] = p2g[0].cpu().numpy()
         results["points_weight"] = pw[0].cpu().numpy()

@@ -719,5 +719,38 @@ def mask_transform(src, out_hw=None, resized_hw=None, flip=None, pad_val=0, norm
 
 def assign_points(gt_boxes, gt_off, masks, H, W, uniforms, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
                   ws):
-    _lib.call("radet_assign_points", _ptr(gt_boxes), _ptr(gt_off), _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges,
+    """masks: u8 [sumG, H, W] visible masks, or f32 per-box distance maps (mask-free sampler)"""
+    _lib.call("radet_assign_points_f" if masks.dtype == torch.float32 else "radet_assign_points", _ptr(gt_boxes), _ptr(gt_off), _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges,
               nlvl, B, positive_num, neg_thr, _ptr(p2g), _ptr(pw), _ptr(used), _ptr(ws), _stream())
+
+
+# ---------------------------------------------------------------------- image processing around MBD / GDT (packed crops)
+def gauss9_kernel():
+    """cv::getGaussianKernel(9, sigma <= 0 -> 0.3 * ((9 - 1) * 0.5 - 1) + 0.8 = 1.7, CV_32F): float taps, normalised with a
+    double sum; returned as (centre, +-1, +-2, +-3, +-4)"""
+    import numpy as np
+    sigma = 0.3 * ((9 - 1) * 0.5 - 1) + 0.8
+    x = np.arange(9, dtype=np.float64) - 4.0
+    cf = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
+    s = 0.0
+    for v in cf:
+        s += float(v)
+    cf = (cf.astype(np.float64) * (1.0 / s)).astype(np.float32)
+    return (C.c_float * 5)(*[float(v) for v in cf[4:]])
+
+
+def resize_linear_u8(src, sdesc, dst, ddesc, n, max_dst_px, channels=3):
+    _lib.call("radet_resize_linear_u8", _ptr(src), _ptr(sdesc), _ptr(dst), _ptr(ddesc), n, max_dst_px, channels, _stream())
+
+
+def resize_linear_f(src, sdesc, dst, ddesc, n, max_dst_px):
+    _lib.call("radet_resize_linear_f", _ptr(src), _ptr(sdesc), _ptr(dst), _ptr(ddesc), n, max_dst_px,
+              1 if src.dtype == torch.float64 else 0, _stream())
+
+
+def gaussian_blur9_u8(src, desc, dst, tmp, n, max_px):
+    _lib.call("radet_gaussian_blur9_u8", _ptr(src), _ptr(desc), _ptr(dst), _ptr(tmp), gauss9_kernel(), n, max_px, _stream())
+
+
+def sobel_edge(src, desc, edge, gray_ws, max_ws, n, max_px):
+    _lib.call("radet_sobel_edge", _ptr(src), _ptr(desc), _ptr(edge), _ptr(gray_ws), _ptr(max_ws), n, max_px, _stream())

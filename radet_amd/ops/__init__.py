@@ -7,7 +7,7 @@ import torch
 from .. import kernels as K
 
 __all__ = ["vote_nms", "global_vote_nms", "cluster_nms", "batched_nms", "MBD_box2distance", "GDT_box2distance", "MBD", "GDT",
-           "mbd_batch", "gdt_batch", "border_seeds"]
+           "mbd_batch", "gdt_batch", "border_seeds", "resize_batch", "gaussian_blur9_batch", "sobel_edge_batch"]
 
 _MAX = 8192
 
@@ -185,14 +185,108 @@ def GDT(costmap, seeds_x, seeds_y):
     return gdt_batch([costmap], [(seeds_x, seeds_y)])[0]
 
 
-_NEEDS_CV2 = ("needs cv2.resize / cv2.GaussianBlur / Sobel, which this build does not restate (cv2 is absent from the "
-              "image, so they could not be pinned); pass pre-processed crops / cost maps to mbd_batch / gdt_batch")
+# ---------------------------------------------------------------------------------------------- image processing (packed crops)
+class _Packed:
+    """box crops of one call packed back to back on the device: data [sum h*w (* c)], desc i32 [n, 3] = (pixel offset, h, w)"""
+
+    def __init__(self, data, hw, channels):
+        self.data, self.hw, self.c = data, [(int(h), int(w)) for h, w in hw], channels
+        offs, o = [], 0
+        for h, w in self.hw:
+            offs.append(o)
+            o += h * w
+        self.offs, self.px = offs, o
+        self.desc = torch.tensor([[o_, h, w] for o_, (h, w) in zip(offs, self.hw)], dtype=torch.int32,
+                                 device=data.device).reshape(-1, 3).contiguous()
+        self.max_px = max([h * w for h, w in self.hw], default=0)
+
+    @staticmethod
+    def pack(items, dtype, channels):
+        dev = _dev()
+        ts = [torch.as_tensor(it).to(dev, dtype) for it in items]
+        for t in ts:
+            assert (t.dim() == 3 and t.shape[2] == channels) if channels > 1 else t.dim() == 2, tuple(t.shape)
+        flat = torch.cat([t.reshape(-1) for t in ts]) if ts else torch.empty(0, dtype=dtype, device=dev)
+        return _Packed(flat.contiguous(), [t.shape[:2] for t in ts], channels)
+
+    def empty_like(self, hw=None, dtype=None, channels=None):
+        hw = self.hw if hw is None else hw
+        c = self.c if channels is None else channels
+        n = sum(int(h) * int(w) for h, w in hw) * c
+        return _Packed(torch.empty(n, dtype=dtype or self.data.dtype, device=self.data.device), hw, c)
+
+    def unpack(self):
+        out = []
+        for o, (h, w) in zip(self.offs, self.hw):
+            t = self.data[o * self.c:(o + h * w) * self.c]
+            out.append(t.view(h, w, self.c) if self.c > 1 else t.view(h, w))
+        return out
+
+
+def _resize(p, dsizes):
+    """cv2.resize(crop, (w, h)) per crop (INTER_LINEAR): uint8 HWC, float32 or float64 HW"""
+    out = p.empty_like(hw=[(int(h), int(w)) for (w, h) in dsizes])
+    if len(p.hw):
+        if p.data.dtype == torch.uint8:
+            K.resize_linear_u8(p.data, p.desc, out.data, out.desc, len(p.hw), out.max_px, p.c)
+        else:
+            K.resize_linear_f(p.data, p.desc, out.data, out.desc, len(p.hw), out.max_px)
+    return out
+
+
+def _blur9(p):
+    out = p.empty_like()
+    if len(p.hw):
+        tmp = torch.empty(p.px * 3, dtype=torch.float32, device=p.data.device)
+        K.gaussian_blur9_u8(p.data, p.desc, out.data, tmp, len(p.hw), p.max_px)
+    return out
+
+
+def _sobel(p):
+    out = p.empty_like(dtype=torch.float32, channels=1)
+    if len(p.hw):
+        gray = torch.empty(p.px, dtype=torch.uint8, device=p.data.device)
+        mx = torch.empty(len(p.hw), dtype=torch.int32, device=p.data.device)
+        K.sobel_edge(p.data, p.desc, out.data, gray, mx, len(p.hw), p.max_px)
+    return out
+
+
+def resize_batch(images, dsizes):
+    """list of crops (uint8 [h, w, 3] or float [h, w]) resized to dsizes = [(w, h), ...] like cv2.resize(img, (w, h))"""
+    t0 = torch.as_tensor(images[0])
+    if t0.dtype == torch.uint8:
+        p = _Packed.pack(images, torch.uint8, 3 if t0.dim() == 3 else 1)
+    else:
+        p = _Packed.pack(images, torch.float64 if t0.dtype == torch.float64 else torch.float32, 1)
+    return _resize(p, dsizes).unpack()
+
+
+def gaussian_blur9_batch(images):
+    """cv2.GaussianBlur(img, (9, 9), sigmaX=0, borderType=BORDER_DEFAULT) per uint8 [h, w, 3] crop"""
+    return _blur9(_Packed.pack(images, torch.uint8, 3)).unpack()
+
+
+def sobel_edge_batch(images):
+    """GDT_box2distance.sobel_extract_edge per uint8 [h, w, 3] crop -> float32 [h, w]"""
+    return _sobel(_Packed.pack(images, torch.uint8, 3)).unpack()
+
+
+def _center_prepare(box_images, idx, size):
+    """mode='center': short edge -> `size` pixels (cv2.resize), then the 9x9 Gaussian (wrapper.py:80-88 / 170-177)"""
+    orig, dsz = [], []
+    for i in idx:
+        h, w = box_images[i].shape[:2]
+        ratio = size / min(w, h)
+        dsz.append((int(w * ratio), int(h * ratio)))
+        orig.append((w, h))
+    p = _Packed.pack([box_images[i] for i in idx], torch.uint8, 3)
+    return _blur9(_resize(p, dsz)), orig
 
 
 class MBD_box2distance:
-    """`radet.ops.MBD_box2distance` (bbox2distance_wrapper.py:9-95) on the GPU, all enabled crops of a call in one
-    launch.  mode='mean' with multi_scale=False is complete; mode='center' and multi_scale additionally resize / blur
-    with cv2 in the reference and raise here."""
+    """`radet.ops.MBD_box2distance` (bbox2distance_wrapper.py:9-95) on the GPU, all enabled crops of a call batched:
+    mode='center' (the reference default) = resize to a 150-pixel short edge -> 9x9 Gaussian -> MBD -> resize back;
+    mode='mean' = MBD on the crop itself.  `multi_scale` is stored and, like in the reference's __call__, not used."""
 
     def __init__(self, mode="center", multi_scale=False, alpha=0.1, niter=4, base_size=300, interval=3):
         assert mode in ["center", "mean"]
@@ -204,11 +298,17 @@ class MBD_box2distance:
         return MBD(image, *border_seeds(h, w, self.interval), self.alpha, self.niter, self.base_size)
 
     def __call__(self, box_images, mask_enable, bbox_images_xy):
-        if self.mode == "center" or isinstance(self.multi_scale, dict):
-            raise NotImplementedError("MBD_box2distance(mode='center' / multi_scale): " + _NEEDS_CV2)
         idx = [i for i, e in enumerate(mask_enable) if e]
-        maps = mbd_batch([box_images[i] for i in idx], [border_seeds(*box_images[i].shape[:2], self.interval) for i in idx],
-                         self.alpha, self.niter, self.base_size)
+        if self.mode == "center" and idx:
+            blurred, orig = _center_prepare(box_images, idx, self.size)
+            crops = blurred.unpack()
+            maps = mbd_batch(crops, [border_seeds(h, w, self.interval) for h, w in blurred.hw], self.alpha, self.niter,
+                             self.base_size)
+            maps = _resize(_Packed.pack(maps, torch.float64, 1), orig).unpack()
+        else:
+            maps = mbd_batch([box_images[i] for i in idx],
+                             [border_seeds(*box_images[i].shape[:2], self.interval) for i in idx], self.alpha, self.niter,
+                             self.base_size)
         maps = dict(zip(idx, maps))
         out = []
         for i, (img, xy) in enumerate(zip(box_images, bbox_images_xy)):
@@ -218,28 +318,39 @@ class MBD_box2distance:
 
 
 class GDT_box2distance:
-    """`radet.ops.GDT_box2distance` (bbox2distance_wrapper.py:98-185): the transform runs on the GPU; the edge map that
-    feeds it comes from `extract_edge_func(image) -> f32[h, w]` (the reference's Sobel / structured-edge extractors are
-    cv2 code and are not restated), mode='mean' only."""
+    """`radet.ops.GDT_box2distance` (bbox2distance_wrapper.py:98-185) on the GPU.  edge_mode='sobel' runs the Sobel edge
+    extractor as HIP passes; the reference's default edge_mode='sed' needs OpenCV's structured-edge model file
+    (cv2.ximgproc, 'model.yml'), which is data this repository does not have: pass `extract_edge_func(image) -> f32[h, w]`
+    for it."""
 
-    def __init__(self, edge_mode="sobel", interval=3, mode="center", extract_edge_func=None):
-        self.interval, self.mode, self.size = interval, mode, 150
+    def __init__(self, edge_mode="sed", interval=3, mode="center", extract_edge_func=None):
+        self.interval, self.mode, self.size, self.edge_mode = interval, mode, 150, edge_mode
         self.extract_edge_func = extract_edge_func
+        if extract_edge_func is None and edge_mode == "sed":
+            raise NotImplementedError("GDT_box2distance(edge_mode='sed') needs cv2.ximgproc's structured-edge model "
+                                      "(model.yml); use edge_mode='sobel' or pass extract_edge_func")
+
+    def sobel_extract_edge(self, image):
+        return sobel_edge_batch([image])[0]
+
+    def _edges(self, crops):
+        if self.extract_edge_func is not None:
+            return [torch.as_tensor(self.extract_edge_func(c.cpu().numpy() if isinstance(c, torch.Tensor) else c)) for c in crops]
+        return sobel_edge_batch(crops)
 
     def cal_dmap_single_scale(self, box_image):
-        if self.extract_edge_func is None:
-            raise NotImplementedError("GDT_box2distance edge extraction: " + _NEEDS_CV2)
         h, w = box_image.shape[:2]
-        return GDT(self.extract_edge_func(box_image), *border_seeds(h, w, self.interval))
+        return GDT(self._edges([box_image])[0], *border_seeds(h, w, self.interval))
 
     def __call__(self, box_images, mask_enable, bbox_images_xy):
-        if self.mode == "center":
-            raise NotImplementedError("GDT_box2distance(mode='center'): " + _NEEDS_CV2)
-        if self.extract_edge_func is None:
-            raise NotImplementedError("GDT_box2distance edge extraction: " + _NEEDS_CV2)
         idx = [i for i, e in enumerate(mask_enable) if e]
-        maps = gdt_batch([self.extract_edge_func(box_images[i]) for i in idx],
-                         [border_seeds(*box_images[i].shape[:2], self.interval) for i in idx])
+        if self.mode == "center" and idx:
+            blurred, orig = _center_prepare(box_images, idx, self.size)
+            maps = gdt_batch(self._edges(blurred.unpack()), [border_seeds(h, w, self.interval) for h, w in blurred.hw])
+            maps = _resize(_Packed.pack(maps, torch.float32, 1), orig).unpack()
+        else:
+            maps = gdt_batch(self._edges([box_images[i] for i in idx]),
+                             [border_seeds(*box_images[i].shape[:2], self.interval) for i in idx])
         maps = dict(zip(idx, maps))
         out = []
         for i, (img, xy) in enumerate(zip(box_images, bbox_images_xy)):

@@ -286,3 +286,38 @@ def test_distance_oracle_matches_reference_build():
         c = dist.gdt(cost, sx, sy)
         d = ref.GDT(torch.from_numpy(cost), torch.from_numpy(sx), torch.from_numpy(sy)).numpy()
         assert np.array_equal(c, d), (h, w)
+
+
+def test_imgproc_oracle_against_scipy():
+    """oracle/imgproc.py (the OpenCV operations around MBD / GDT, cv2 absent -> restated) against scipy.ndimage and
+    analytic cases: Gaussian / Sobel by correlation with mirror borders (= BORDER_REFLECT_101), bilinear resize on the
+    half-pixel grid, identity / constant images."""
+    import scipy.ndimage as ndi
+    from oracle import imgproc as ip
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    k = ip.gauss9_taps().astype(np.float64)
+    assert abs(k.sum() - 1) < 1e-7 and np.allclose(k, k[::-1]) and k.argmax() == 4
+    ref = ndi.correlate1d(ndi.correlate1d(img.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(ip.gaussian_blur9_u8(img).astype(float) - np.rint(ref)).max() <= 1           # float32 passes vs float64
+    blur = np.stack([ndi.correlate(img[..., c].astype(np.int64), np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]]), mode="mirror")
+                     for c in range(3)], -1)
+    b = (blur + 8) >> 4
+    gray = ((b[..., 0] * 4899 + b[..., 1] * 9617 + b[..., 2] * 1868 + 8192) >> 14).astype(np.float64)
+    gx = ndi.correlate(gray, np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], float), mode="mirror")
+    gy = ndi.correlate(gray, np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], float), mode="mirror")
+    e = np.abs(0.5 * gx + 0.5 * gy)
+    assert np.array_equal(ip.sobel_edge(img), (e / e.max()).astype(np.float32))                 # integer-valued: exact
+    assert np.array_equal(ip.resize_linear_u8(img, (53, 37)), img)                              # identity
+    assert (ip.resize_linear_u8(np.full((20, 30, 3), 77, np.uint8), (45, 31)) == 77).all()      # constants survive
+    up = ip.resize_linear_u8(img, (150, 105))
+    f = ip.resize_linear_float(img[..., 0].astype(np.float64), (150, 105))
+    assert np.abs(up[..., 0].astype(float) - f).max() < 1.0                                     # fixed point vs float: < 1 LSB
+    yy, xx = (np.arange(105) + 0.5) * (37 / 105) - 0.5, (np.arange(150) + 0.5) * (53 / 150) - 0.5
+    ref = ndi.map_coordinates(img[..., 0].astype(np.float64), np.meshgrid(yy, xx, indexing="ij"), order=1, mode="nearest")
+    assert np.abs(f - ref).max() < 2e-3                                                         # float32 coordinates in cv2's rule
+    dn = ip.resize_linear_float(img[..., 1].astype(np.float32), (20, 11))
+    assert dn.dtype == np.float32 and dn.shape == (11, 20) and img[..., 1].min() <= dn.min() and dn.max() <= img[..., 1].max()
+    ramp = np.tile(np.arange(0, 200, 4, dtype=np.uint8)[None, :, None], (9, 1, 3))              # linear ramp stays linear
+    r2 = ip.resize_linear_u8(ramp, (100, 9))[4, 2:-2, 0].astype(int)
+    assert set(np.diff(r2)) <= {1, 2, 3}

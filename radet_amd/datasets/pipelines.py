@@ -90,6 +90,7 @@ class GenerateDistanceMap:
 
 @PIPELINES.register_module()
 class LabelAssignment:
+    MAX_GTS = 256
     """Same constructor and result keys as the reference. `__call__(results)` handles one image like the
     reference; `assign_batch` is the MI355X-native entry point (one workgroup per image).
 
@@ -111,7 +112,7 @@ class LabelAssignment:
                                       "probability-weighted draw)")
         self.strides, self.regress_ranges = tuple(strides), tuple(tuple(r) for r in regress_ranges)
         self.positive_num, self.neg_threshold = positive_num, neg_threshold
-        self.uniform_budget = 4096
+        self.uniform_budget = 4096      # uniforms drawn per image: positive_num (+ rejection redraws) per gt, 256 gts x 10 fit
 
     def _levels(self, H, W):
         return K.Levels([(math.ceil(H / s), math.ceil(W / s)) for s in self.strides], 1)
@@ -132,6 +133,9 @@ class LabelAssignment:
         lv = self._levels(H, W)
         N = lv.rows
         counts = [int(np.asarray(b).reshape(-1, 4).shape[0]) for b in gt_bboxes]
+        if max(counts, default=0) > self.MAX_GTS:       # kernel limit (ASG_MAXG): refuse before anything is launched
+            raise ValueError(f"LabelAssignment: {max(counts)} gt boxes in one image exceed the kernel's limit of "
+                             f"{self.MAX_GTS} (BOP scenes hold at most a few dozen objects)")
         off = np.zeros(B + 1, np.int32)
         off[1:] = np.cumsum(counts)
         tot = int(off[-1])

@@ -1,0 +1,93 @@
+"""Data-parallel train step with the real engine and TWO ranks on one MI355X (both processes share cuda:0; the
+process group is gloo, because RCCL refuses two ranks on one device -- the collective calls, the bucket hooks on the
+side stream, finish() before AdamW and grad_div = world are exactly the code the 8-GPU RCCL run executes)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(seed):
+    import sys
+    sys.path.insert(0, REPO)
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    torch.manual_seed(seed)
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+    rt = det.runtime()
+    rt.init_optimizer()
+    rt.set_loss_from_head(det.bbox_head)
+    return det, rt
+
+
+def _batch(rank, rt):
+    import sys
+    sys.path.insert(0, REPO)
+    import bench
+    img, boxes, labels, p2g, pw = bench.make_batch(rank, 2, torch.device("cuda"))
+    tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+    return img, tg
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GPU_MAX_HW_QUEUES="8")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    det, rt = _setup(seed=100 + rank)              # different initial weights: the runtime's broadcast must equalise them
+    img, tg = _batch(rank, rt)
+    losses = [rt.train_step(img, tg, lr=1e-4).clone().cpu() for _ in range(2)]
+    torch.cuda.synchronize()
+    torch.save(dict(params=rt.flat.params.cpu(), losses=torch.stack(losses), m=rt.opt_state["m"].cpu()),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_one_gpu_train_step(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(800)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) for r in range(2))
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["m"], r1["m"])       # replicas stay identical
+    assert torch.isfinite(r0["losses"]).all() and not torch.equal(r0["losses"], r1["losses"])   # different shards
+    # single-process emulation of the same two steps: rank 0's initial weights, both shards' gradients summed,
+    # mean folded into AdamW (grad_div = 2).  Every reduction is deterministic, so the result is bit-identical.
+    det, rt = _setup(seed=100)
+    shards = [_batch(r, rt) for r in range(2)]
+    for _ in range(2):
+        total = torch.zeros_like(rt.flat.grads)
+        for img, tg in shards:
+            rt.forward(img)
+            rt.loss(tg)
+            rt.backward()
+            torch.cuda.synchronize()
+            total += rt.flat.grads
+        rt.flat.grads.copy_(total)
+        rt.optimizer_step(lr=1e-4, grad_div=2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(rt.flat.params.cpu(), r0["params"])

@@ -103,6 +103,45 @@ def test_assigner_random_batches(seed):
         assert rngs[i].random_sample() == orngs[i].random_sample()      # stream position preserved
 
 
+def test_assigner_shared_rng_consumes_one_stream_in_order():
+    """The reference's loader runs the sampler image after image on NumPy's GLOBAL RandomState: image i starts where
+    image i-1 stopped.  assign_batch with no rngs (or one RNG object for several images) must reproduce exactly that --
+    same assignments AND the same final stream position."""
+    from oracle import assigner as oa
+    from radet_amd.datasets import LabelAssignment
+    rs = np.random.RandomState(77)
+    H, W, B = 320, 320, 4
+    boxes, masks = [], []
+    for i in range(B):
+        G = int(rs.randint(1, 7))
+        bx = np.zeros((G, 4), np.float32)
+        mk = np.zeros((G, H, W), np.uint8)
+        for g in range(G):
+            w, h = rs.randint(20, W // 2), rs.randint(20, H // 2)
+            x, y = rs.randint(0, W - w), rs.randint(0, H - h)
+            bx[g] = (x, y, x + w, y + h)
+            mk[g, y:y + h, x + w // 3:x + w] = 1
+        boxes.append(bx); masks.append(mk)
+    la = LabelAssignment(neg_threshold=0.2, positive_num=10, balance_sample=True)
+    np.random.seed(4242)
+    p2g, pw = la.assign_batch(boxes, masks, (H, W, 3))                       # rngs=None: the global np.random, shared
+    after = np.random.random_sample()
+    ref = np.random.RandomState(4242)
+    for i in range(B):
+        rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), masks[i], (H, W, 3), rng=ref)
+        assert np.array_equal(p2g[i].cpu().numpy(), rp) and np.array_equal(pw[i].cpu().numpy(), rw), i
+    assert after == ref.random_sample()
+    shared = np.random.RandomState(9)                                       # one explicit RandomState for every image
+    ref = np.random.RandomState(9)
+    p2g, pw = la.assign_batch(boxes, masks, (H, W, 3), rngs=[shared] * B)
+    for i in range(B):
+        rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), masks[i], (H, W, 3), rng=ref)
+        assert np.array_equal(p2g[i].cpu().numpy(), rp), i
+    assert shared.random_sample() == ref.random_sample()
+    with pytest.raises(ValueError):
+        la.assign_batch([np.zeros((300, 4), np.float32)], [np.zeros((300, 8, 8), np.uint8)], (8, 8, 3))
+
+
 @pytest.mark.parametrize("n,n_labels,crowd", [(700, 1, 4), (1024, 1, 30), (1025, 1, 4), (4096, 1, 30), (4097, 1, 30),
                                               (8192, 1, 30), (6000, 2, 4), (5000, 3, 1)])
 def test_nms_long_label_segments(n, n_labels, crowd):

@@ -85,7 +85,8 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bits 4-5: tile override of the one-tap
- * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel;
+ * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel; bit 7: 32
+ * instead of 16 pixels per LDS stage in the one-tap fp32 kernel;
  * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32. */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,

@@ -456,6 +456,7 @@ struct WgradArgs {
     int chunks_per_split;  // 16-pixel chunks per split
     int dbg;          // experiments only (RADET_DBG_WGRAD): 1 = skip global loads after the first stage
     int math;         // 0: fp32 MFMA; 1: operands rounded to bf16, fp32 accumulate (LDS-DMA kernels only)
+    int bp32;         // one-tap fp32 kernel: 32 instead of 16 pixels per stage (flags bit 7; chosen by the autotuner)
 };
 
 // ------------------------------------------------------------------------------------------ wgrad, all 9 taps
@@ -643,9 +644,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
 // One (tap, 64x64 or 128x128 output x input channel tile, pixel split) per workgroup; the dy / x tiles are brought in
 // by global_load_lds (see conv_wgrad9g_kernel): the unpadded
 // [pixel][channel] tiles are lane-linear images of 1-KiB wave loads, so no staging registers and no ds_write pass.
-template <int BM, int BN, int WM, int WN, int MATH>
+template <int BM, int BN, int WM, int WN, int MATH, int BP = 16>
 __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
-    constexpr int BP = 16, NW = 4;
+    constexpr int NW = 4;                                   // BP = pixels per stage (16 or 32); splits count 16-pixel chunks
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_INSTR = BP * BM * 4 / 1024, B_INSTR = BP * BN * 4 / 1024;
     constexpr int N_INSTR = A_INSTR + B_INSTR;
@@ -673,8 +674,8 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     const int o0 = to * BM, c0 = tc * BN;
     const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
 
-    const int p_begin = split * a.chunks_per_split * BP;
-    int p_end = p_begin + a.chunks_per_split * BP;
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
     if (p_end > a.M) p_end = a.M;
     const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
 
@@ -795,9 +796,9 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
         }
 }
 
-template <int BM, int BN, int WM, int WN, int MATH>
+template <int BM, int BN, int WM, int WN, int MATH, int BP = 16>
 __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
-    wgradg_body<BM, BN, WM, WN, MATH>(a, blockIdx.x);
+    wgradg_body<BM, BN, WM, WN, MATH, BP>(a, blockIdx.x);
 }
 
 // Grouped launch: up to WG_MAX independent weight-gradient GEMMs (the convs of one backbone stage / of the neck, all
@@ -1369,7 +1370,9 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
+    const bool bp32 = a.bp32 != 0;                                        // 32 pixels per LDS stage (half the barriers)
     if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
+    else if (bp32 && BM >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
 }
 
@@ -1448,6 +1451,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     a.S = S;
     a.dbg = radet_switches().dbg_wgrad;
     a.math = flags & 1;
+    a.bp32 = (flags >> 7) & 1;
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
@@ -1505,7 +1509,7 @@ extern "C" int radet_conv2d_wgrad_group(const RadetWgradJob* jobs, int njobs, in
         WgradArgs& a = g.p[i];
         a.dy = j.dy; a.x = j.x; a.slabs = j.slabs; a.dbias_partials = j.dbias_partials; a.rowtab = j.gather_table;
         a.M = j.M; a.Mp = radet_gather_table_rows(j.M); a.Cin = j.Cin; a.Cout = j.Cout; a.KH = j.KH; a.KW = j.KW;
-        a.ld_dy = j.ld_dy; a.S = j.S; a.dbg = 0; a.math = flags & 1;
+        a.ld_dy = j.ld_dy; a.S = j.S; a.dbg = 0; a.math = flags & 1; a.bp32 = 0;
         const int chunks = (j.M + 15) / 16;
         a.chunks_per_split = (chunks + j.S - 1) / j.S;
         g.begin[i] = total;

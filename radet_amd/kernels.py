@@ -362,6 +362,8 @@ def autotune_wgrad(g, reps=None):
                 for blocks in (256, 512, 768, 1024):
                     S = max(1, min(64, round(blocks / tiles), (M + 127) // 128))
                     cands.append((tflag | 0x40, S))
+                    if not g.math and not g.h16:
+                        cands.append((tflag | 0x40 | 0x80, S))       # 32 pixels per stage
         cands = sorted(set(cands))
         dt = torch.bfloat16 if g.h16 else torch.float32
         dy = torch.randn(M, g.cout, device=dev).to(dt)

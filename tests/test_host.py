@@ -208,6 +208,15 @@ def test_reference_import_paths():
     from radet.datasets import PIPELINES
     import radet_amd.models
     assert DETECTORS is radet_amd.models.DETECTORS and "LabelAssignment" in PIPELINES
+    # sub-modules resolve to the SAME module objects (a second import under the alias name would re-register everything)
+    import radet.datasets.pipelines as p
+    import radet_amd.datasets.pipelines as q
+    from radet.core import bbox_overlaps, multiclass_nms  # noqa: F401
+    from radet.core.bbox import TBLRBBoxCoder  # noqa: F401
+    from radet.datasets import BOPDataset, build_dataset  # noqa: F401
+    from radet.models.losses import FocalLoss, GIoULoss  # noqa: F401
+    from radet.apis import train_detector  # noqa: F401
+    assert p is q
 
 
 def test_onecycle_matches_torch():

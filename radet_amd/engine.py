@@ -728,6 +728,9 @@ class Engine:
         K.gn_relu_bwd(self.plv, dy, b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"], p[gn + ".bias"], dz,
                       g[gn + ".weight"], g[gn + ".bias"], ws)
         x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
+        # the weight-gradient GEMM stays ON the tower's chain: moved to a stream of its own (overlapping the other
+        # tower's dgrad and GroupNorm) the all-taps kernel's large workgroups starve the dependent chain -- measured
+        # 20.4 instead of 16.0 ms per step
         K.conv_wgrad(c.geom, dz, x, c.slabs, None)
         if self.tower_mode == "hybrid":   # only the (un-overlapped) forward launches carry the profiling tag
             K.conv_dgrad(c.geom, dz, c.wft, dy if i > 0 else dP, addend=None if i > 0 else addend,

@@ -110,6 +110,90 @@ __device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr,
     return p.base + iy * p.Wi + ix;
 }
 
+// Fused epilogue of one block tile: y = relu?(acc + bias (+ addend)) masked by mask > 0.  All loads of an accumulator
+// tile (output-row indirection, residual, ReLU mask) are issued back to back BEFORE anything waits for them: written as
+// one loop with per-element branches the compiler emitted load -> s_waitcnt vmcnt(0) -> branch -> load -> ... for every
+// one of the 16 accumulator registers, i.e. up to 48 fully serialised L2 / HBM round trips per tile (44 % of the wave
+// cycles of the K = 256 residual layers were spent parked there).  Out-of-range rows / columns read a clamped address
+// and are dropped at the store; the storage type IO (0 fp32, 1 bf16, 2 bf16 in / fp32 out) is a compile-time branch.
+template <int IO>
+__device__ __forceinline__ float ld_act_t(const float* p, size_t o) {
+    if constexpr (IO != 0) return (float)reinterpret_cast<const __bf16*>(p)[o];
+    else return p[o];
+}
+template <int IO>
+__device__ __forceinline__ void st_out_t(float* p, size_t o, float v) {
+    if constexpr (IO == 1) reinterpret_cast<__bf16*>(p)[o] = (__bf16)v;   // v_cvt_pk_bf16_f32: round to nearest even
+    else p[o] = v;
+}
+
+template <int BM, int BN, int WM, int WN, int IO>
+__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ConvPtrs& P,
+                                               f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int wm, int wn,
+                                               int li, int lh) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    const bool has_add = P.addend != nullptr, has_mask = P.mask != nullptr, has_rows = a.out_rows != nullptr;   // uniform
+    const bool interior = m0 + BM <= a.M && n0 + BN <= a.Cout;                                                     // uniform
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        size_t obase[16];
+        bool rvalid[16];
+        if (has_rows) {
+            int orow[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rvalid[r] = row < a.M;
+                orow[r] = a.out_rows[rvalid[r] ? row : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) obase[r] = (size_t)orow[r] * a.Cout;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rvalid[r] = row < a.M;
+                obase[r] = (size_t)(rvalid[r] ? row : 0) * a.Cout;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + li;
+            const bool cvalid = col < a.Cout;
+            const int cc = cvalid ? col : 0;
+            const float bv = P.bias ? P.bias[cc] : 0.f;
+            float av[16], mv[16];
+            if (has_add) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) av[r] = ld_act_t<IO>(P.addend, obase[r] + cc);
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = ld_act_t<IO>(P.mask, obase[r] + cc);
+            }
+            float out[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                      // straight-line arithmetic: one wait for the loads above
+                float v = acc[i][j][r] + bv;
+                if (has_add) v += av[r];
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (has_mask) v = mv[r] > 0.f ? v : 0.f;
+                out[r] = v;
+            }
+            // stores last, with nothing left in flight that they would have to wait for (on gfx9-class hardware a
+            // store behind a conservative vmcnt(0) also waits for the store before it); interior tiles store unguarded
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (cvalid && rvalid[r]) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+            }
+        }
+    }
+}
+
 // Split episodes (split-K over the whole grid, or the K-split left-over tiles of a tail split) are reduced INSIDE the
 // launch: every workgroup of a tile writes its raw partial tile (tile-local layout), publishes it with one agent-scope
 // release and draws an arrival ticket; the workgroup that draws the last ticket acquires, re-reads all partial tiles in
@@ -174,25 +258,9 @@ __device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P
                 }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + li;
-            if (col >= a.Cout) continue;
-            const float bv = P.bias ? P.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= a.M) continue;
-                const size_t o = (size_t)(a.out_rows ? a.out_rows[row] : row) * a.Cout + col;
-                float v = acc[i][j][r] + bv;
-                if (P.addend) v += ld_act(P.addend, o, a.io);
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (P.mask) v = ld_act(P.mask, o, a.io) > 0.f ? v : 0.f;
-                st_out(P.y, o, v, a.io);
-            }
-        }
+    if (a.io == 0) igemm_epilogue<BM, BN, WM, WN, 0>(a, P, acc, m0, n0, wm, wn, li, lh);
+    else if (a.io == 1) igemm_epilogue<BM, BN, WM, WN, 1>(a, P, acc, m0, n0, wm, wn, li, lh);
+    else igemm_epilogue<BM, BN, WM, WN, 2>(a, P, acc, m0, n0, wm, wn, li, lh);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -721,6 +789,9 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     float bsum = 0.f;
     const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
 
+    // per-lane LDS byte addresses of the operand reads: pixel row lh of a k pair, channel (wave tile) * 32 + li
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + 4u * (unsigned)(lh * BM + wm * TM * 32 + li);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + 4u * (unsigned)(lh * BN + wn * TN * 32 + li);
     if (nIt > 0) issue_stage(0, 0);
     __syncthreads();
     for (int it = 0; it < nIt; ++it) {
@@ -747,19 +818,36 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ab[i], bb[j], acc[i][j], 0, 0, 0);
             }
         } else {
+            // The operand reads are inline asm with hand-placed lgkmcnt waits: behind plain LDS loads the compiler puts
+            // s_waitcnt vmcnt(0) (it cannot prove that the LDS-DMA just issued targets the OTHER buffer), which made every
+            // stage wait for its own prefetch before the first MFMA -- load and compute of a workgroup ran back to back.
+            const unsigned ab = a_thr + (unsigned)buf * (BP * BM * 4), bb = b_thr + (unsigned)buf * (BP * BN * 4);
+            float af[2][TM], bf[2][TN];
+            static_for<0, TM>([&](auto ic) { lds_read32<decltype(ic)::value * 128>(af[0][decltype(ic)::value], ab); });
+            static_for<0, TN>([&](auto jc) { lds_read32<decltype(jc)::value * 128>(bf[0][decltype(jc)::value], bb); });
+            static_for<0, BP / 2>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value, pp = kk & 1;
+                if constexpr (kk + 1 < BP / 2) {
+                    static_for<0, TM>([&](auto ic) {
+                        lds_read32<(2 * (kk + 1) * BM + decltype(ic)::value * 32) * 4>(af[pp ^ 1][decltype(ic)::value], ab);
+                    });
+                    static_for<0, TN>([&](auto jc) {
+                        lds_read32<(2 * (kk + 1) * BN + decltype(jc)::value * 32) * 4>(bf[pp ^ 1][decltype(jc)::value], bb);
+                    });
+                    lds_wait<TM + TN>();
+                } else {
+                    lds_wait<0>();
+                }
 #pragma unroll
-            for (int kk = 0; kk < BP / 2; ++kk) {
-                float af[TM], bf[TN];
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[pp][i]));
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[buf][(2 * kk + lh) * BM + (wm * TM + i) * 32 + li];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[buf][(2 * kk + lh) * BN + (wn * TN + j) * 32 + li];
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[pp][j]));
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pp][i], bf[pp][j], acc[i][j], 0, 0, 0);
+            });
         }
         if (want_bias) {
             constexpr int G = 256 / BM, RPT = BP / G;       // row groups, rows per thread

@@ -296,6 +296,11 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<I + 1, N>(f);
     }
 }
+typedef short s16x4v_ __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16(s16x4v_& d, unsigned addr) {   // gfx950 transposing LDS read (see conv_wgradh)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -748,17 +753,35 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
 
     int brow[PER_WAVE];                                     // gather rows of the NEXT stage (x-tile instructions)
+    bool bok[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
         const int bi = wave + k * NW - A_INSTR;
         brow[k] = -1;
+        bok[k] = false;
         if (bi >= 0 && bi < B_INSTR) {
             const int m = p_begin + bi * RB + (lane * 4) / BN;
-            brow[k] = m < p_end ? tab_tap[m] : -1;
+            brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];         // unconditional (clamped) load; rows >= p_end are masked at use
+            bok[k] = m < p_end;
         }
     }
+    // Issue order inside a stage: (1) the x-tile loads, which consume the gather rows fetched one stage earlier, (2) the
+    // dy-tile loads, (3) the gather rows of the next stage.  The compiler cannot see that the rows loaded in the previous
+    // iteration were already drained by the barrier's vmcnt(0) and waits (vmcnt(0)) before their first use: placed first,
+    // that wait is free; placed after a dy-tile load (the former order) it stalled every stage on its own prefetch.
     auto issue_stage = [&](int it, int buf) {
         const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int c = c0 + (lane * 4) % BN;
+                const float* src = (bok[k] && brow[k] >= 0 && c < a.Cin) ? a.x + (size_t)brow[k] * a.Cin + c
+                                                                         : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int ins = wave + k * NW;
@@ -767,14 +790,16 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
                 const int o = o0 + (lane * 4) % BM;
                 const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
-            } else if (ins < N_INSTR) {
-                const int bi = ins - A_INSTR;
-                const int c = c0 + (lane * 4) % BN;
-                const float* src = (brow[k] >= 0 && c < a.Cin) ? a.x + (size_t)brow[k] * a.Cin + c
-                                                               : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
-                const int m = p0 + BP + bi * RB + (lane * 4) / BN;
-                brow[k] = m < p_end ? tab_tap[m] : -1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                // unconditional (clamped) load; rows >= p_end are masked at use
+                const int m = p0 + BP + (ins - A_INSTR) * RB + (lane * 4) / BN;
+                brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];
+                bok[k] = m < p_end;
             }
         }
     };
@@ -961,18 +986,33 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
     // writer side: lane -> (sub-tile, pixel row, 8-channel half) of every wave load it issues
     const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
     int brow[PER_WAVE];                                     // gather rows of the NEXT stage (x-tile loads)
+    bool bok[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
         const int bi = wave + k * NW - A_INSTR;
         brow[k] = -1;
+        bok[k] = false;
         if (bi >= 0 && bi < B_INSTR) {
             const int blk = bi * 8 + l_blk;
             const int m = p_begin + 4 * (blk / CBB) + l_prow;
-            brow[k] = m < p_end ? tab_tap[m] : -1;
+            brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];         // unconditional (clamped) load, masked at use
+            bok[k] = m < p_end;
         }
     }
-    auto issue_stage = [&](int it, int buf) {
+    auto issue_stage = [&](int it, int buf) {                 // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
         const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int blk = bi * 8 + l_blk;
+                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
+                const void* src = (bok[k] && brow[k] >= 0 && c < a.Cin) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
+                                                                        : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int ins = wave + k * NW;
@@ -983,15 +1023,16 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
                 const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
                                                             : (const void*)(radet_zero_page + lane * 4);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
-            } else if (ins < N_INSTR) {
-                const int bi = ins - A_INSTR;
-                const int blk = bi * 8 + l_blk;
-                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
-                const void* src = (brow[k] >= 0 && c < a.Cin) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
-                                                              : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int blk = (ins - A_INSTR) * 8 + l_blk;
                 const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
-                brow[k] = m < p_end ? tab_tap[m] : -1;
+                brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];
+                bok[k] = m < p_end;
             }
         }
     };
@@ -1008,41 +1049,60 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
 
     // reader side (per lane): 16-lane group g16 -> channel sub-tile, m -> bytes 8m of the sub-tile, lh -> pixel half
     const int g16 = (lane >> 4) & 1, m16 = lane & 15;
-    typedef __attribute__((address_space(3))) s16x4v* tr_ptr;
 
     // the transposing read is not ordered against in-flight LDS-DMA by the compiler: every wave drains its own
     // loads (vmcnt(0)) before the barrier that publishes the stage
+    // per-lane LDS byte addresses of the transposing reads (sub-tile row 2 * lh of a 4-row group, channel sub-tile of the
+    // wave tile + g16, bytes 8 * m16 of the sub-tile)
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + wm * TM * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + wn * TN * 2 + g16) * 128 + m16 * 8);
     if (nIt > 0) issue_stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        // transposing reads as inline asm (+ hand-placed lgkmcnt waits): behind the builtin the compiler waits vmcnt(0)
+        // for the LDS-DMA prefetch just issued before the first read of the stage (see conv_wgradg)
+        {
+            const unsigned ab = a_thr + (unsigned)buf * (BP * BM * 2), bb = b_thr + (unsigned)buf * (BP * BN * 2);
+            s16x4v al[2][TM], ah[2][TM], bl[2][TN], bh[2][TN];
+            auto read_ks = [&](auto ksc, int pp) {
+                constexpr int ks = decltype(ksc)::value;
+                static_for<0, TM>([&](auto ic) {
+                    constexpr int off = ((4 * ks) * CBA + decltype(ic)::value * 2) * 128;
+                    lds_read_tr16<off>(al[pp][decltype(ic)::value], ab);
+                    lds_read_tr16<off + CBA * 128>(ah[pp][decltype(ic)::value], ab);
+                });
+                static_for<0, TN>([&](auto jc) {
+                    constexpr int off = ((4 * ks) * CBB + decltype(jc)::value * 2) * 128;
+                    lds_read_tr16<off>(bl[pp][decltype(jc)::value], bb);
+                    lds_read_tr16<off + CBB * 128>(bh[pp][decltype(jc)::value], bb);
+                });
+            };
+            read_ks(std::integral_constant<int, 0>{}, 0);
+            static_for<0, BP / 16>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, pp = ks & 1;
+                if constexpr (ks + 1 < BP / 16) {
+                    read_ks(std::integral_constant<int, ks + 1>{}, pp ^ 1);
+                    lds_wait<2 * (TM + TN)>();
+                } else {
+                    lds_wait<0>();
+                }
 #pragma unroll
-        for (int ks = 0; ks < BP / 16; ++ks) {
-            s16x8v af[TM], bf[TN];
+                for (int i = 0; i < TM; ++i) { asm volatile("" : "+v"(al[pp][i])); asm volatile("" : "+v"(ah[pp][i])); }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int cb = (wm * TM + i) * 2 + g16;
-                const unsigned short* q = &As[buf][((4 * ks + 2 * lh) * CBA + cb) * 64 + m16 * 4];
-                const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)q);
-                const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(q + CBA * 64));
-                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+                for (int j = 0; j < TN; ++j) { asm volatile("" : "+v"(bl[pp][j])); asm volatile("" : "+v"(bh[pp][j])); }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cb = (wn * TN + j) * 2 + g16;
-                const unsigned short* q = &Bs[buf][((4 * ks + 2 * lh) * CBB + cb) * 64 + m16 * 4];
-                const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)q);
-                const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(q + CBB * 64));
-                bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                                        __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        const s16x8v af = __builtin_shufflevector(al[pp][i], ah[pp][i], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const s16x8v bf = __builtin_shufflevector(bl[pp][j], bh[pp][j], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                                            __builtin_bit_cast(bf16x8, bf), acc[i][j], 0, 0, 0);
+                    }
+            });
         }
         if (want_bias && tid < BM) {                        // column sums of dy, pixel order
             const int cb = tid >> 4, cc = tid & 15;

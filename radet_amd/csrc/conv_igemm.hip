@@ -573,19 +573,33 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
     if (p_end > a.M) p_end = a.M;
     const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
 
-    // gather-table rows of the NEXT stage for this wave's x-tile instructions (loaded one stage ahead)
+    // gather-table rows of the NEXT stage for this wave's x-tile instructions (loaded one stage ahead; unconditional,
+    // clamped loads whose validity is applied at use -- see conv_wgradg for why)
     int brow[PER_WAVE];
+    bool bok[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
         const int ins = wave + k * NW - A_INSTR;             // x-tile instruction index (tap, half)
         brow[k] = -1;
+        bok[k] = false;
         if (ins >= 0 && ins < B_INSTR) {
             const int m = p_begin + (ins & 1) * 8 + (lane >> 3);
-            brow[k] = m < p_end ? a.rowtab[(size_t)(ins >> 1) * a.Mp + m] : -1;
+            brow[k] = a.rowtab[(size_t)(ins >> 1) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+            bok[k] = m < p_end;
         }
     }
-    auto issue_stage = [&](int it, int buf) {
+    auto issue_stage = [&](int it, int buf) {                // order: x tiles (consume brow), dy tiles, next gather rows
         const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const float* src = (bok[k] && brow[k] >= 0) ? a.x + (size_t)brow[k] * a.Cin + c0 + (lane & 7) * 4
+                                                            : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int ins = wave + k * NW;
@@ -595,13 +609,16 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
                 const int m = p0 + j;
                 const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
-            } else if (ins < N_INSTR) {
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
-                const float* src = brow[k] >= 0 ? a.x + (size_t)brow[k] * a.Cin + c0 + (lane & 7) * 4
-                                               : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
                 const int m = p0 + BP + (bi & 1) * 8 + (lane >> 3);
-                brow[k] = m < p_end ? a.rowtab[(size_t)(bi >> 1) * a.Mp + m] : -1;
+                brow[k] = a.rowtab[(size_t)(bi >> 1) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[k] = m < p_end;
             }
         }
     };
@@ -1168,18 +1185,33 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
     const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
     // x-tile load bi = tap * B_TAP + half: sub-tiles blk = half * 8 + l_blk of the tap's [8 pq][2 cb] grid
     int brow[PER_WAVE];
+    bool bok[PER_WAVE];
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k) {
         const int bi = wave + k * NW - A_INSTR;
         brow[k] = -1;
+        bok[k] = false;
         if (bi >= 0 && bi < B_INSTR) {
             const int blk = (bi % B_TAP) * 8 + l_blk;
             const int m = p_begin + 4 * (blk / CBB) + l_prow;
-            brow[k] = m < p_end ? a.rowtab[(size_t)(bi / B_TAP) * a.Mp + m] : -1;
+            brow[k] = a.rowtab[(size_t)(bi / B_TAP) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+            bok[k] = m < p_end;
         }
     }
-    auto issue_stage = [&](int it, int buf) {
+    auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
         const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int blk = (bi % B_TAP) * 8 + l_blk;
+                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
+                const void* src = (bok[k] && brow[k] >= 0) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
+                                                           : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int ins = wave + k * NW;
@@ -1190,15 +1222,17 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
                 const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
                                                             : (const void*)(radet_zero_page + lane * 4);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
-            } else if (ins < N_INSTR) {
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
                 const int blk = (bi % B_TAP) * 8 + l_blk;
-                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
-                const void* src = brow[k] >= 0 ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
-                                               : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
                 const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
-                brow[k] = m < p_end ? a.rowtab[(size_t)(bi / B_TAP) * a.Mp + m] : -1;
+                brow[k] = a.rowtab[(size_t)(bi / B_TAP) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[k] = m < p_end;
             }
         }
     };
@@ -1211,7 +1245,9 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
     float bsum = 0.f;
     const bool want_bias = a.dbias_partials != nullptr && tc == 0;
     const int g16 = (lane >> 4) & 1, m16 = lane & 15;
-    typedef __attribute__((address_space(3))) s16x4v* tr_ptr;
+    // per-lane LDS byte addresses of the (inline-asm) transposing reads, see conv_wgradh
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + wave * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + g16) * 128 + m16 * 8);
 
     if (nIt > 0) issue_stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1219,22 +1255,30 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < BP / 16; ++ks) {
-            const int pq = 4 * ks + 2 * lh;
-            const unsigned short* qa = &As[buf][(pq * CBA + wave * 2 + g16) * 64 + m16 * 4];
-            const s16x4v alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)qa);
-            const s16x4v ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(qa + CBA * 64));
-            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                const unsigned short* qb = &Bs[buf][t * BP * BC + (pq * CBB + g16) * 64 + m16 * 4];
-                const s16x4v blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)qb);
-                const s16x4v bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)(qb + CBB * 64));
+        const unsigned ab = a_thr + (unsigned)buf * (BP * BM * 2), bb = b_thr + (unsigned)buf * (KT * BP * BC * 2);
+        static_for<0, BP / 16>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            s16x4v alo, ahi, blo[2], bhi[2];
+            lds_read_tr16<(4 * ks) * CBA * 128>(alo, ab);
+            lds_read_tr16<(4 * ks) * CBA * 128 + CBA * 128>(ahi, ab);
+            lds_read_tr16<(4 * ks) * CBB * 128>(blo[0], bb);
+            lds_read_tr16<(4 * ks) * CBB * 128 + CBB * 128>(bhi[0], bb);
+            static_for<0, KT>([&](auto tc_) {
+                constexpr int t = decltype(tc_)::value, pp = t & 1;
+                if constexpr (t + 1 < KT) {
+                    lds_read_tr16<(t + 1) * BP * BC * 2 + (4 * ks) * CBB * 128>(blo[pp ^ 1], bb);
+                    lds_read_tr16<(t + 1) * BP * BC * 2 + (4 * ks) * CBB * 128 + CBB * 128>(bhi[pp ^ 1], bb);
+                    lds_wait<2>();
+                } else {
+                    lds_wait<0>();
+                }
+                asm volatile("" : "+v"(alo)); asm volatile("" : "+v"(ahi));
+                asm volatile("" : "+v"(blo[pp])); asm volatile("" : "+v"(bhi[pp]));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    af, __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[t], 0, 0, 0);
-            }
-        }
+                    af, __builtin_bit_cast(bf16x8, __builtin_shufflevector(blo[pp], bhi[pp], 0, 1, 2, 3, 4, 5, 6, 7)), acc[t], 0, 0, 0);
+            });
+        });
         if (want_bias && tid < BM) {
             const int cb = tid >> 4, cc = tid & 15;
 #pragma unroll

@@ -292,6 +292,7 @@ extern "C" int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int
 // Work unit = chunk of up to GN_CH pixels of one (level, image).  C = 256 channels, 32 groups of 8.
 // A block (256 threads) covers 4 pixel rows x 64 float4 columns per step.
 #define GN_CH 64
+#define GN_UNR 4      // pixel rows whose loads are in flight together per thread
 
 struct GnChunk { int seg, n, first_pix, npix, row0, chunk_in_img, nchunks_img, part_base; };
 
@@ -334,10 +335,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ z, 
     const int tid = threadIdx.x;
     const int col = tid & 63, prow = tid >> 6;
     float s = 0.f, ss = 0.f;
-    for (int p = prow; p < c.npix; p += 4) {
-        const float4 v = ld4(z, (size_t)(c.row0 + p) * 64 + col);
-        s += (v.x + v.y) + (v.z + v.w);
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    // 4 pixel rows per iteration, their loads issued together: left to the compiler the loop ran one 16-byte load
+    // at a time per lane (load -> vmcnt(0) -> add), far too little in flight for an HBM-bound kernel
+    for (int p0 = prow; p0 < c.npix; p0 += GN_UNR * 4) {
+        float4 v[GN_UNR];
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            v[u] = ld4(z, (size_t)(c.row0 + (p < c.npix ? p : prow)) * 64 + col);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            if (p0 + 4 * u < c.npix) {
+                s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                ss += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+            }
+        }
     }
     // the two float4 columns of a group are neighbouring lanes
     s += __shfl_xor(s, 1, 64);
@@ -401,16 +414,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ z, 
     const float mean = sm[g], rstd = sr[g];
     const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
     const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
-    for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 64 + col;
-        const float4 v = ld4(z, o);
-        float4 r;
-        r.x = (v.x - mean) * rstd * gm.x + bt.x;
-        r.y = (v.y - mean) * rstd * gm.y + bt.y;
-        r.z = (v.z - mean) * rstd * gm.z + bt.z;
-        r.w = (v.w - mean) * rstd * gm.w + bt.w;
-        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-        st4(y, o, r);
+    for (int p0 = prow; p0 < c.npix; p0 += GN_UNR * 4) {
+        float4 vv[GN_UNR];
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            vv[u] = ld4(z, (size_t)(c.row0 + (p < c.npix ? p : prow)) * 64 + col);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            if (p >= c.npix) continue;
+            const float4 v = vv[u];
+            float4 r;
+            r.x = (v.x - mean) * rstd * gm.x + bt.x;
+            r.y = (v.y - mean) * rstd * gm.y + bt.y;
+            r.z = (v.z - mean) * rstd * gm.z + bt.z;
+            r.w = (v.w - mean) * rstd * gm.w + bt.w;
+            if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            st4(y, (size_t)(c.row0 + p) * 64 + col, r);
+        }
     }
     if (c.chunk_in_img == 0 && tid < 32) {
         // stats layout: [(seg, n)][32][2]; (seg, n) linear id = sum_{l<seg} B + n
@@ -482,23 +505,34 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
     const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
     float s1 = 0.f, s2 = 0.f;
     float4 cg = make_float4(0.f, 0.f, 0.f, 0.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 64 + col;
-        const float4 v = ld4(z, o);
-        float4 d = ld4(dy, o);
-        float4 xh;
-        xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
-        if (relu) {
-            if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
-            if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
-            if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
-            if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+    for (int p0 = prow; p0 < c.npix; p0 += GN_UNR * 4) {
+        float4 vv[GN_UNR], dd[GN_UNR];
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            const size_t o = (size_t)(c.row0 + (p < c.npix ? p : prow)) * 64 + col;
+            vv[u] = ld4(z, o);
+            dd[u] = ld4(dy, o);
         }
-        cg.x += d.x * xh.x; cg.y += d.y * xh.y; cg.z += d.z * xh.z; cg.w += d.w * xh.w;
-        cb.x += d.x; cb.y += d.y; cb.z += d.z; cb.w += d.w;
-        const float a0 = d.x * gm.x, a1 = d.y * gm.y, a2 = d.z * gm.z, a3 = d.w * gm.w;
-        s1 += (a0 + a1) + (a2 + a3);
-        s2 += (a0 * xh.x + a1 * xh.y) + (a2 * xh.z + a3 * xh.w);
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            if (p0 + 4 * u >= c.npix) continue;
+            const float4 v = vv[u];
+            float4 d = dd[u];
+            float4 xh;
+            xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
+            if (relu) {
+                if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
+                if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
+                if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
+                if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+            }
+            cg.x += d.x * xh.x; cg.y += d.y * xh.y; cg.z += d.z * xh.z; cg.w += d.w * xh.w;
+            cb.x += d.x; cb.y += d.y; cb.z += d.z; cb.w += d.w;
+            const float a0 = d.x * gm.x, a1 = d.y * gm.y, a2 = d.z * gm.z, a3 = d.w * gm.w;
+            s1 += (a0 + a1) + (a2 + a3);
+            s2 += (a0 * xh.x + a1 * xh.y) + (a2 * xh.z + a3 * xh.w);
+        }
     }
     s1 += __shfl_xor(s1, 1, 64);
     s2 += __shfl_xor(s2, 1, 64);
@@ -551,24 +585,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const float m1 = m1s[g], m2 = m2s[g];
     const float4 gm = *reinterpret_cast<const float4*>(gamma + col * 4);
     const float4 bt = *reinterpret_cast<const float4*>(beta + col * 4);
-    for (int p = prow; p < c.npix; p += 4) {
-        const size_t o = (size_t)(c.row0 + p) * 64 + col;
-        const float4 v = ld4(z, o);
-        float4 d = ld4(dy, o);
-        float4 xh;
-        xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
-        if (relu) {
-            if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
-            if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
-            if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
-            if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+    for (int p0 = prow; p0 < c.npix; p0 += GN_UNR * 4) {
+        float4 vv[GN_UNR], dd[GN_UNR];
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            const size_t o = (size_t)(c.row0 + (p < c.npix ? p : prow)) * 64 + col;
+            vv[u] = ld4(z, o);
+            dd[u] = ld4(dy, o);
         }
-        float4 r;
-        r.x = rstd * (d.x * gm.x - m1 - xh.x * m2);
-        r.y = rstd * (d.y * gm.y - m1 - xh.y * m2);
-        r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
-        r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
-        st4(dz, o, r);
+#pragma unroll
+        for (int u = 0; u < GN_UNR; ++u) {
+            const int p = p0 + 4 * u;
+            if (p >= c.npix) continue;
+            const float4 v = vv[u];
+            float4 d = dd[u];
+            float4 xh;
+            xh.x = (v.x - mean) * rstd; xh.y = (v.y - mean) * rstd; xh.z = (v.z - mean) * rstd; xh.w = (v.w - mean) * rstd;
+            if (relu) {
+                if (xh.x * gm.x + bt.x <= 0.f) d.x = 0.f;
+                if (xh.y * gm.y + bt.y <= 0.f) d.y = 0.f;
+                if (xh.z * gm.z + bt.z <= 0.f) d.z = 0.f;
+                if (xh.w * gm.w + bt.w <= 0.f) d.w = 0.f;
+            }
+            float4 r;
+            r.x = rstd * (d.x * gm.x - m1 - xh.x * m2);
+            r.y = rstd * (d.y * gm.y - m1 - xh.y * m2);
+            r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
+            r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
+            st4(dz, (size_t)(c.row0 + p) * 64 + col, r);
+        }
     }
 }
 

@@ -271,6 +271,16 @@ def test_stem_maxpool(K):
     p = torch.empty(B * Hp * Wp, 64, device="cuda")
     K.maxpool(y, p, B, Ho, Wo, 64)
     assert rel_err(from_rows(p, B, Hp, Wp), F.max_pool2d(from_rows(y.cpu(), B, Ho, Wo).double(), 3, 2, 1)) == 0.0
+    # bf16 storage variant, and the headline image size (full 8 x 32 tiles) / a size below one tile
+    yh = torch.empty(B * Ho * Wo, 64, device="cuda", dtype=torch.bfloat16)
+    K.stem(img.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), bias.cuda(), yh, B, H, W)
+    assert rel_err(from_rows(yh.float(), B, Ho, Wo), ref) < 1e-2
+    for (b2, h2, w2) in ((1, 480, 640), (3, 9, 13)):
+        im = torch.randn(b2, 3, h2, w2, generator=g)
+        r2 = F.relu(F.conv2d(im.double(), w.double(), bias.double(), stride=2, padding=3))
+        y2 = torch.empty(b2 * r2.shape[2] * r2.shape[3], 64, device="cuda")
+        K.stem(im.cuda(), w.permute(0, 2, 3, 1).contiguous().cuda(), bias.cuda(), y2, b2, h2, w2)
+        assert rel_err(from_rows(y2, b2, r2.shape[2], r2.shape[3]), r2) < 1e-5, (b2, h2, w2)
 
 
 def test_groupnorm_fwd_bwd(K):

@@ -88,29 +88,43 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
     const float* a0 = &sx[(2 * (2 * wave)) * STEM_S + 2 * li];          // output row 2w, column li
     const float* a1 = a0 + 2 * STEM_S;                                   // output row 2w + 1
     const float* b0 = &sw[lh * STEM_LDW + li];
+    // operands of k pair kk + 1 are read before the MFMAs of pair kk (the LDS latency hides behind 4 MFMAs)
+    int off = lh ? stem_aoff(1) : stem_aoff(0);
+    float x0 = a0[off], x1 = a1[off], w0 = b0[0], w1 = b0[32];
 #pragma unroll
     for (int kk = 0; kk < KP / 2; ++kk) {
-        const int off = lh ? stem_aoff(2 * kk + 1) : stem_aoff(2 * kk);
-        const float x0 = a0[off], x1 = a1[off];
-        const float w0 = b0[2 * kk * STEM_LDW], w1 = b0[2 * kk * STEM_LDW + 32];
+        float nx0 = 0.f, nx1 = 0.f, nw0 = 0.f, nw1 = 0.f;
+        if (kk + 1 < KP / 2) {
+            off = lh ? stem_aoff(2 * kk + 3) : stem_aoff(2 * kk + 2);
+            nx0 = a0[off]; nx1 = a1[off];
+            nw0 = b0[(2 * kk + 2) * STEM_LDW]; nw1 = b0[(2 * kk + 2) * STEM_LDW + 32];
+        }
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, w0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, w1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, w0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, w1, acc[1][1], 0, 0, 0);
+        x0 = nx0; x1 = nx1; w0 = nw0; w1 = nw1;
     }
     // D layout: lane column li = channel within the 32-channel half, register r = pixel (r & 3) + 8 (r >> 2) + 4 lh
-#pragma unroll
+    const float bv0 = bias[li], bv1 = bias[32 + li];
+    const bool interior = ox0 + STEM_TC <= Wo && oy0 + STEM_TR <= Ho;       // uniform: unguarded stores (no exec juggling,
+#pragma unroll                                                                // no conservative waits between them)
     for (int i = 0; i < 2; ++i) {
         const int oy = oy0 + 2 * wave + i;
-        if (oy >= Ho) continue;
+        T* row = y + ((size_t)(n * Ho + (oy < Ho ? oy : 0)) * Wo + ox0 + 4 * lh) * 64 + li;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int ch = j * 32 + li;
-            const float bv = bias[ch];
+            const float bv = j ? bv1 : bv0;
+            if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (ox < Wo) y[((size_t)(n * Ho + oy) * Wo + ox) * 64 + ch] = (T)fmaxf(acc[i][j][r] + bv, 0.f);
+                for (int r = 0; r < 16; ++r)
+                    row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)fmaxf(acc[i][j][r] + bv, 0.f);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (oy < Ho && ox < Wo) row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)fmaxf(acc[i][j][r] + bv, 0.f);
+                }
             }
         }
     }

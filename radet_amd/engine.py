@@ -219,7 +219,10 @@ class Engine:
         if self.geo_key is not None:
             self._plans[self.geo_key] = self._snapshot()          # most recently used goes last
             while len(self._plans) >= max(self.max_plans, 1):
-                self._plans.popitem(last=False)                   # evict the least recently used plan (frees its buffers)
+                # evict the least recently used plan (frees its buffers): nothing on any stream may still be using them
+                # when the caching allocator hands the blocks to the new plan
+                torch.cuda.synchronize()
+                self._plans.popitem(last=False)
         self.geo_key = key
         if key in self._plans:
             self._restore(self._plans.pop(key))

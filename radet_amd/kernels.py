@@ -79,6 +79,11 @@ def _gather_table(key, B, k, so, sr, off, div, desc, nseg, rows):
         mp = _lib.load().radet_gather_table_rows(rows)
         t = torch.empty(k * k * mp, dtype=torch.int32, device=torch.device("cuda", dev))
         _lib.call("radet_build_gather_table", _ptr(t), B, k, k, so, sr, off, div, desc, nseg, _stream())
+        # Tables are shared by every conv of this geometry, whatever stream it launches on (the cls tower's dgrad builds
+        # the table on the main stream, the reg tower's dgrad picks it out of the cache and launches on the side
+        # stream a few microseconds later): finish the build before anyone can see the table.  Once per geometry.
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().synchronize()
         _TABLE_CACHE[key] = t
     return t
 
@@ -102,16 +107,24 @@ class ConvGeom:
         self.wgrad_flags = 0                  # tile override of the wgrad launcher (set by autotune_wgrad)
         self.h16 = False                      # bf16 tensors in HBM (tuning runs use the matching kernels)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
+        self._ft = self._bt = self._classes = None
 
+    # The geometry keeps its tables alive: _TABLE_CACHE only dedupes them across geometries and may drop its own
+    # reference at any time -- a table freed while a launch on a side stream still reads it would be recycled by the
+    # caching allocator and overwritten under that launch.
     @property
     def fwd_table(self):
-        return _gather_table(("f",) + self._key, self.B, self.k, self.stride, 1, -self.pad, 1, self.fwd_desc, self.nseg,
-                             self.lout.rows)
+        if self._ft is None:
+            self._ft = _gather_table(("f",) + self._key, self.B, self.k, self.stride, 1, -self.pad, 1, self.fwd_desc,
+                                     self.nseg, self.lout.rows)
+        return self._ft
 
     @property
     def bwd_table(self):
-        return _gather_table(("b",) + self._key, self.B, self.k, 1, -1, self.pad, self.stride, self.bwd_desc, self.nseg,
-                             self.lin.rows)
+        if self._bt is None:
+            self._bt = _gather_table(("b",) + self._key, self.B, self.k, 1, -1, self.pad, self.stride, self.bwd_desc,
+                                     self.nseg, self.lin.rows)
+        return self._bt
 
 
 _SPLITK_WS = {}
@@ -144,11 +157,14 @@ def _strided_dgrad_classes(g):
     One tap-subset launch per class does only the non-zero work (a dense launch wastes 75 % of the MFMAs
     of a 3x3/2 conv).  Returns a list of dicts(table, out_rows, tap_ids, ntaps, rows, zero)."""
     import numpy as np
+    if g._classes is not None:
+        return g._classes
     key = ("cls",) + g._key
     dev = torch.cuda.current_device()
     ck = (dev,) + key
     if ck in _TABLE_CACHE:
-        return _TABLE_CACHE[ck]
+        g._classes = _TABLE_CACHE[ck]
+        return g._classes
     KT = g.k * g.k
     M = g.lin.rows
     mp = _lib.load().radet_gather_table_rows(M)
@@ -178,7 +194,7 @@ def _strided_dgrad_classes(g):
         tab = np.full((1, mpc), -1, np.int32)
         out.append(dict(table=torch.from_numpy(tab).cuda(), out_rows=torch.from_numpy(rows.astype(np.int32)).cuda(),
                         tap_ids=(C.c_int * 1)(0), ntaps=1, rows=int(rows.size), zero=True))
-    _TABLE_CACHE[ck] = out
+    _TABLE_CACHE[ck] = g._classes = out
     return out
 
 

@@ -255,6 +255,29 @@ def test_conv_multilevel(K):
         assert rel_err(from_rows(y[r0:r1], B, *hw[i]), ref) < 1e-5
 
 
+def test_gather_tables_survive_cache_eviction(K, monkeypatch):
+    """The table cache is bounded; a geometry must keep its own tables (and dgrad parity classes) alive when the cache
+    drops them -- a table freed under a launch that is still running on a side stream gets recycled by the allocator
+    (found as a GPU memory fault late in a full test run, once > 1024 tables had been built)."""
+    monkeypatch.setattr(K._TABLE_CACHE, "cap", 2)
+    g0 = K.ConvGeom(K.Levels([(9, 7)], 2), 32, 32, 3, 2, 1)
+    t_f, t_b, cls = g0.fwd_table, g0.bwd_table, K._strided_dgrad_classes(g0)
+    snap = t_f.clone()
+    for i in range(6):                                   # push g0's entries out of the cache, recycle freed blocks
+        gi = K.ConvGeom(K.Levels([(9 + i, 8)], 2), 32, 32, 3, 1, 1)
+        assert gi.fwd_table.numel() and gi.bwd_table.numel()
+    assert len(K._TABLE_CACHE) <= 2 and not any(k[1:] == ("f",) + g0._key for k in K._TABLE_CACHE)
+    assert g0.fwd_table is t_f and g0.bwd_table is t_b and K._strided_dgrad_classes(g0) is cls
+    assert torch.equal(t_f, snap)
+    x = torch.randn(g0.lin.rows, 32, device="cuda")
+    w = torch.randn(32 * 9 * 32, device="cuda") * 0.05
+    y1, y2 = torch.empty(g0.lout.rows, 32, device="cuda"), torch.empty(g0.lout.rows, 32, device="cuda")
+    K.conv_fwd(g0, x, w, None, y1)
+    g1 = K.ConvGeom(K.Levels([(9, 7)], 2), 32, 32, 3, 2, 1)        # same geometry, rebuilt tables
+    K.conv_fwd(g1, x, w, None, y2)
+    assert torch.equal(y1, y2)
+
+
 def test_stem_maxpool(K):
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 70, 90

@@ -519,7 +519,9 @@ class Engine:
     def _side(self):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=self.dev)
-            self._events = [torch.cuda.Event() for _ in range(256)]
+            # ring of reusable events; an event handed out here is consumed (waited on) at most a few layers later, so
+            # the ring only has to be longer than the events of ONE step (R101: ~2 per conv + forks/joins, < 600)
+            self._events = [torch.cuda.Event() for _ in range(2048)]
             self._ev_i = 0
         return self._side_stream
 

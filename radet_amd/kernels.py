@@ -194,6 +194,8 @@ def _strided_dgrad_classes(g):
         tab = np.full((1, mpc), -1, np.int32)
         out.append(dict(table=torch.from_numpy(tab).cuda(), out_rows=torch.from_numpy(rows.astype(np.int32)).cuda(),
                         tap_ids=(C.c_int * 1)(0), ntaps=1, rows=int(rows.size), zero=True))
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()      # the uploads above have landed before another stream can use them
     _TABLE_CACHE[ck] = g._classes = out
     return out
 

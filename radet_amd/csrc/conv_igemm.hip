@@ -48,6 +48,9 @@ struct ConvArgs {
     // io = 0: fp32 tensors.  io = 1 / 2 (bf16 storage): x, w, addend, mask are bf16 and Cin counts PAIRS of channels
     // (a 4-byte unit, so the loaders and LDS layouts are those of the fp32 kernel); y is bf16 (1) or fp32 (2)
     int io;
+    // stream-K: sk_wgs persistent workgroups share the T * nK K-stages of the launch evenly (workgroup v owns stages
+    // [v * sk_base + min(v, sk_rem), ...) across tile boundaries); tiles cut by a boundary are reduced in the launch
+    int sk_wgs, sk_base, sk_rem;
 };
 
 __device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
@@ -127,8 +130,23 @@ __device__ __forceinline__ void st_out_t(float* p, size_t o, float v) {
     else p[o] = v;
 }
 
+// Everything the code after the K loop needs from the argument struct, loaded before the loop and pinned in SGPRs:
+// left to the compiler these become s_loads (each behind its own wait) between the last barrier and the first store.
+struct EpiArgs {
+    int M, Cout, relu, io;
+    const int* out_rows;
+    float* partial;       // split-K / stream-K workspace (ConvArgs::partial, ::counters)
+    int* counters;
+    int sk_base, sk_rem;  // stream-K partition
+};
+template <class T>
+__device__ __forceinline__ T pin_sgpr(T v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 template <int BM, int BN, int WM, int WN, int IO>
-__device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ConvPtrs& P,
+__device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs& P,
                                                f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int wm, int wn,
                                                int li, int lh) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -200,41 +218,111 @@ __device__ __forceinline__ void igemm_epilogue(const ConvArgs& a, const ConvPtrs
 // split order z = 0, 1, ... (so the sum does not depend on the arrival order: deterministic, and equal to what a
 // separate reduction pass would produce) and runs the fused epilogue.  This replaces 60-80 reduction launches per
 // train step that sat between dependent GEMMs on the critical chain.  `ws` is any LDS word all waves are done with.
+// partial tile = register image: [wave][i][j][lane][16 accumulator floats] -> every lane moves 64 contiguous bytes with
+// 16-byte accesses.  The stores are write-through (sc1), so publishing needs no L2 write-back.
 template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P,
+__device__ __forceinline__ void partial_write(float* dst, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)]) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int off = ((((wave * TM + i) * TN + j) * 64 + lane) * 16) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_ v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off + 16 * q, 0, 16);   // aux 16 = sc1
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void partial_add(const float* pz, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)]) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(pz + (((wave * TM + i) * TN + j) * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = src[q];
+                acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
+            }
+        }
+}
+
+template <class A>
+__device__ __forceinline__ int streamk_start(const A& a, int v) { return v * a.sk_base + (v < a.sk_rem ? v : a.sk_rem); }
+template <class A>
+__device__ __forceinline__ int streamk_owner(const A& a, int it) {       // workgroup that owns K-stage `it`
+    const int big = (a.sk_base + 1) * a.sk_rem;
+    return it < big ? it / (a.sk_base + 1) : a.sk_rem + (it - big) / a.sk_base;
+}
+
+// Stream-K: a workgroup's K-stage range [cur, cur + nseg) inside tile `tile` does not cover the tile.  Every contributor
+// writes its partial tile to its own slot (workgroup v has at most two cut tiles: the one its range starts in -> slot 0,
+// the one it ends in -> slot 1) and adds its stage count to the tile's counter; the contributor that completes the
+// count (nKs) re-reads ALL partials in K order (ascending workgroup), so the sum is independent of the arrival order.
+// Returns true in the workgroup that has to run the epilogue (acc = the reduced tile).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ bool streamk_publish(const EpiArgs& a, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)],
+                                                int tile, int nseg, int nKs, int v, int slot, volatile int* ws) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    partial_write<BM, BN, WM, WN>(a.partial + (size_t)(2 * v + slot) * BM * BN, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        ws[0] = __hip_atomic_fetch_add(&a.counters[tile], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = ws[0] + nseg == nKs;
+    __syncthreads();                                           // ws is LDS tile memory: the next segment's loads may reuse it
+    if (!last) return false;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&a.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int t0 = tile * nKs;
+    const int v0 = streamk_owner(a, t0), v1 = streamk_owner(a, t0 + nKs - 1);
+    for (int u = v0; u <= v1; ++u) {
+        const int sl = streamk_start(a, u) >= t0 ? 0 : 1;      // starts inside this tile -> its first cut tile
+        partial_add<BM, BN, WM, WN>(a.partial + (size_t)(2 * u + sl) * BM * BN, acc);
+    }
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_store(const EpiArgs& e, const ConvPtrs& P,
                                             f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int nsplit,
                                             int ctile, int z, int wm, int wn, int li, int lh, volatile int* ws) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (nsplit > 1) {
-        // partial tile = register image: [wave][i][j][lane][16 accumulator floats] -> every lane moves 64 contiguous
-        // bytes with 16-byte accesses.  The stores are write-through (sc1), so publishing needs no L2 write-back
-        // (a release fence here flushes every dirty line of the XCD's L2, i.e. the outputs of all concurrently running
-        // kernels: measured slower than the separate reduction launches it replaced).
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        float* base = a.partial + (size_t)ctile * nsplit * BM * BN;
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)z * BM * BN, 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int off = ((((wave * TM + i) * TN + j) * 64 + lane) * 16) * 4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off + 16 * q, 0, 16);   // aux 16 = sc1
-                }
-            }
+        // (a release fence here instead of write-through stores flushes every dirty line of the XCD's L2, i.e. the
+        // outputs of all concurrently running kernels: measured slower than the separate reduction launches it replaced)
+        float* base = e.partial + (size_t)ctile * nsplit * BM * BN;
+        partial_write<BM, BN, WM, WN>(base + (size_t)z * BM * BN, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            ws[0] = __hip_atomic_fetch_add(&a.counters[ctile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ws[0] = __hip_atomic_fetch_add(&e.counters[ctile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (ws[0] != nsplit - 1) return;                       // uniform: not the last arriver of this tile
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&a.counters[ctile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            __hip_atomic_store(&e.counters[ctile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         __syncthreads();
 #pragma unroll
@@ -243,24 +331,11 @@ __device__ __forceinline__ void igemm_store(const ConvArgs& a, const ConvPtrs& P
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int zz = 0; zz < nsplit; ++zz) {
-            const float* pz = base + (size_t)zz * BM * BN;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float4* src = reinterpret_cast<const float4*>(pz + (((wave * TM + i) * TN + j) * 64 + lane) * 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 v = src[q];
-                        acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
-                    }
-                }
-        }
+        for (int zz = 0; zz < nsplit; ++zz) partial_add<BM, BN, WM, WN>(base + (size_t)zz * BM * BN, acc);
     }
-    if (a.io == 0) igemm_epilogue<BM, BN, WM, WN, 0>(a, P, acc, m0, n0, wm, wn, li, lh);
-    else if (a.io == 1) igemm_epilogue<BM, BN, WM, WN, 1>(a, P, acc, m0, n0, wm, wn, li, lh);
-    else igemm_epilogue<BM, BN, WM, WN, 2>(a, P, acc, m0, n0, wm, wn, li, lh);
+    if (e.io == 0) igemm_epilogue<BM, BN, WM, WN, 0>(e, P, acc, m0, n0, wm, wn, li, lh);
+    else if (e.io == 1) igemm_epilogue<BM, BN, WM, WN, 1>(e, P, acc, m0, n0, wm, wn, li, lh);
+    else igemm_epilogue<BM, BN, WM, WN, 2>(e, P, acc, m0, n0, wm, wn, li, lh);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -315,7 +390,7 @@ __device__ __forceinline__ void lds_wait() {
 // pipelined one 8-wide k slice ahead) + MFMAs on the current buffer, then vmcnt(0) + barrier.
 // TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
 // K = 2304) so that rocprofv3 --stats reports it on its own line (bench.py's roofline kernel).
-template <int BM, int BN, int WM, int WN, int TAG, int BK, int NSTG = 2>
+template <int BM, int BN, int WM, int WN, int TAG, int BK, int NSTG = 2, bool SK = false>
 __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int F4 = BK / 4;            // 16-byte slots per tile row
     constexpr int RPI = 64 / F4;          // tile rows per wave load
@@ -339,22 +414,45 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
 
     const int tilesN = (a.Cout + BN - 1) / BN;
-    const bool tail = (int)blockIdx.x >= a.n_full;
-    const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;
-    int id = tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full);
     const int tilesG = ((a.M + BM - 1) / BM) * tilesN;
+    const int KT = a.KH * a.KW;
+    const int cpt = a.Cin / BK;
+    // stream-K: this workgroup walks its share [cur, end_it) of the launch's K stages, tile after tile (virtual index v:
+    // the workgroups of one XCD own consecutive tiles); otherwise exactly one (tile, K range) per workgroup
+    constexpr bool streamk = SK;                           // stream-K instantiations only: the loop costs registers
+    const int vwg = streamk ? ((int)blockIdx.x & 7) * (a.sk_wgs >> 3) + ((int)blockIdx.x >> 3) : 0;
+    int cur = streamk ? streamk_start(a, vwg) : 0;
+    const int end_it = streamk ? cur + a.sk_base + (vwg < a.sk_rem ? 1 : 0) : 1;
+    const int first_tile = cur / (KT * cpt);
+  do {
+    const bool tail = !streamk && (int)blockIdx.x >= a.n_full;
+    const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;
+    int id = streamk ? cur / (KT * cpt) : (tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full));
+    const int sk_tile = id;
     const int grp = id >= tilesG ? 1 : 0;
     id -= grp * tilesG;
-    const ConvPtrs P = a.p[grp];
+    ConvPtrs P = a.p[grp];
+    P.y = pin_sgpr(P.y); P.bias = pin_sgpr(P.bias); P.addend = pin_sgpr(P.addend); P.mask = pin_sgpr(P.mask);
+    EpiArgs epi;
+    epi.M = pin_sgpr(a.M); epi.Cout = pin_sgpr(a.Cout); epi.relu = pin_sgpr(a.relu); epi.io = pin_sgpr(a.io);
+    epi.out_rows = pin_sgpr(a.out_rows);
+    epi.partial = pin_sgpr(a.partial); epi.counters = pin_sgpr(a.counters);
+    epi.sk_base = pin_sgpr(a.sk_base); epi.sk_rem = pin_sgpr(a.sk_rem);
+    // split episode of this workgroup: (number of splits, split-tile index, my split)
+    const int nsplit = pin_sgpr(tail ? a.sk_tail : a.sk);
+    const int ctile = pin_sgpr(tail ? tail_slot / a.sk_tail : sk_tile);
+    const int zsplit = pin_sgpr(tail ? tail_slot % a.sk_tail : (int)blockIdx.y);
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
 
-    const int KT = a.KH * a.KW;
-    const int cpt = a.Cin / BK;
     const int per = tail ? a.it_per_tail : a.it_per_split;
-    const int it0 = (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
+    const int it0 = streamk ? cur - sk_tile * KT * cpt : (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
     int nK = KT * cpt - it0;
-    if (nK > per) nK = per;
+    if (streamk) {
+        if (nK > end_it - cur) nK = end_it - cur;
+    } else if (nK > per) {
+        nK = per;
+    }
 
     // writer side: this lane fills slot (lane % F4) of tile row ins * RPI + lane / F4 of every load it issues
     const int lrow = lane / F4;
@@ -419,11 +517,14 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     // vmcnt(LOADS) = "everything except the newest stage's loads has landed" (in-order return); only valid when every
     // wave owns exactly A_PW + B_PW loads per stage
     constexpr int LOADS = (A_FULL && B_FULL) ? A_PW + B_PW : 0;
+    // prologue: stages 0 .. NSTG-2 in flight, stage 0 landed
     if (nK > 0) issue_stage(0);
-    if (NSTG == 3 && nK > 1) {
+    if (NSTG >= 3 && nK >= NSTG - 1) {
         issue_stage(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        if constexpr (NSTG >= 4) issue_stage(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
     } else {
+        if (NSTG >= 3 && nK > 1) issue_stage(1);          // short K range: fewer stages, plain wait
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -498,22 +599,33 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the MFMAs of slice s ahead of the next waits
         }
-        if (NSTG == 3 && it + 2 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");   // stage it+1 has landed
+        // stage it+1 has landed once at most the NSTG-2 stages issued after it are outstanding (in-order return);
+        // on the last stages of the range fewer are in flight: plain wait
+        if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
     for (int it = 0; it < nK; it += NSTG) {
         stage(std::integral_constant<int, 0>{}, it);
         if (it + 1 < nK) stage(std::integral_constant<int, 1>{}, it + 1);
-        if constexpr (NSTG == 3)
+        if constexpr (NSTG >= 3)
             if (it + 2 < nK) stage(std::integral_constant<int, 2>{}, it + 2);
+        if constexpr (NSTG >= 4)
+            if (it + 3 < nK) stage(std::integral_constant<int, 3>{}, it + 3);
     }
-    // split episode of this workgroup: (number of splits, split-tile index, my split)
-    const int nsplit = tail ? a.sk_tail : a.sk;
-    const int ctile = tail ? tail_slot / a.sk_tail : id + grp * tilesG;
-    const int zsplit = tail ? tail_slot % a.sk_tail : (int)blockIdx.y;
-    igemm_store<BM, BN, WM, WN>(a, P, acc, m0, n0, nsplit, ctile, zsplit, wm, wn, li, lh,
-                                reinterpret_cast<volatile int*>(&As[0][0]));
+    if (streamk) {
+        cur += nK;
+        bool fin = nK == KT * cpt;                                // whole tile: plain epilogue
+        if (!fin)
+            fin = streamk_publish<BM, BN, WM, WN>(epi, acc, sk_tile, nK, KT * cpt, vwg, sk_tile == first_tile ? 0 : 1,
+                                                  reinterpret_cast<volatile int*>(&As[0][0]));
+        if (fin) igemm_store<BM, BN, WM, WN>(epi, P, acc, m0, n0, 1, 0, 0, wm, wn, li, lh, nullptr);
+    } else {
+        igemm_store<BM, BN, WM, WN>(epi, P, acc, m0, n0, nsplit, ctile, zsplit, wm, wn, li, lh,
+                                    reinterpret_cast<volatile int*>(&As[0][0]));
+        cur = end_it;
+    }
+  } while (SK && cur < end_it);
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
@@ -1355,9 +1467,23 @@ static const RadetSwitches& radet_switches() {
 }
 
 template <int BM, int BN, int WM, int WN>
-static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, bool stages3) {
+static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, int stages, int skw) {
     ConvArgs a = a_in;
     const int T = a.groups * ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    a.sk_wgs = a.sk_base = a.sk_rem = 0;
+    if (skw > 0 && a.partial != nullptr && tag == 0 && BM * BN <= 128 * 64) {
+        // stream-K with skw workgroups per CU: needs at least one K stage per workgroup, a ticket per tile and two
+        // partial-tile slots per workgroup; otherwise the plain launch below
+        const long I = (long)T * a.KH * a.KW * (a.Cin / bk);
+        const int G = 256 * skw;
+        if (I >= G && T <= RADET_SPLIT_COUNTERS && (size_t)G * 2 * BM * BN <= ws_floats && T % G != 0) {
+            a.sk = 1;
+            a.it_per_split = a.KH * a.KW * (a.Cin / bk);
+            a.sk_wgs = G;
+            a.sk_base = (int)(I / G);
+            a.sk_rem = (int)(I % G);
+        }
+    }
     // split-K partial tiles are tile-local [tile][z][BM][BN]: shrink the split until they (and the tickets) fit
     while (a.sk > 1 && ((size_t)T * a.sk * BM * BN > ws_floats || T > RADET_SPLIT_COUNTERS)) --a.sk;
     if (a.sk != a_in.sk) {
@@ -1368,7 +1494,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int nKs = a.KH * a.KW * (a.Cin / bk);
     const int rem = T % 256;
     // only for long K loops: on short kernels the extra epilogue launch costs more than the idle tail
-    if (a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 1152 &&
+    if (a.sk_wgs == 0 && a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 1152 &&
         !radet_switches().no_tail_split) {
         int skt = 256 / rem;
         if (skt > 8) skt = 8;
@@ -1380,10 +1506,13 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
             a.it_per_tail = (nKs + skt - 1) / skt;
         }
     }
-    const int tiles = a.n_full + (T - a.n_full) * a.sk_tail;
+    const int tiles = a.sk_wgs > 0 ? a.sk_wgs : a.n_full + (T - a.n_full) * a.sk_tail;
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
     {
-        if (stages3 && tag < 2) {
+        if (a.sk_wgs > 0) {                                            // stream-K: tag 0, 2 stages
+            if (bk == 32) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 32, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 16, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
+        } else if (stages >= 3 && tag < 2) {
 #define RADET_LAUNCH_IGEMM3(TAGV, BKV) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, 3>), dim3(tiles, a.sk), dim3(256), 0, st, a)
             if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
             else          { if (tag) RADET_LAUNCH_IGEMM3(1, 16); else RADET_LAUNCH_IGEMM3(0, 16); }
@@ -1524,8 +1653,9 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     // split-K for launches that cannot fill 256 CUs twice over (low-M stages): each split keeps >= 8 K stages
     const int nK = KH * KW * (Cin / bk);
     int sk = 1;
-    const bool stages3 = ((tile_override >> 17) & 1) != 0;   // 0x20000: 3 LDS stages (forward launches that run alone)
-    const int sk_force = (tile_override >> 12) & 0xF;
+    const int stages3 = ((tile_override >> 17) & 1) ? 3 : 2;   // 0x20000: 3 LDS stages (launches that run alone)
+    const int skw = (tile_override >> 20) & 7;               // 0x100000 * w: stream-K, w workgroups per CU
+    const int sk_force = skw ? 1 : (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;
     if (splitk_ws != nullptr && a.groups == 1 && !radet_switches().no_splitk) {
         if (sk_force) sk = sk_force;
@@ -1550,10 +1680,10 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         splitk_ws_floats = 0;
     }
     switch (choice) {
-        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
-        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
-        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3); break;
-        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats, stages3); break;
+        case 1: launch_igemm<128, 128, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
+        case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
+        case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
+        case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();

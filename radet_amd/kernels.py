@@ -305,6 +305,9 @@ def autotune(g, need_dgrad=True, reps=None):
             nk = taps * kdim // (32 if t & 0x200 else 16)
             if ntiles < 1024:
                 out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
+                # stream-K (fp32 tensors, fp32 / bf16-rounded math is decided by the launcher's tag: fp32 only)
+                if not g.math and not g.h16 and (t & 0xFF) in (3, 4) and ntiles % 256:
+                    out += [t | (w * STREAMK) for w in (2, 3) if ntiles * nk >= 256 * w]
         return out
 
     global _TUNE_DIRTY, TUNE_RUNS
@@ -334,6 +337,7 @@ MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
 
 
 STAGES3 = 0x20000                         # 3 LDS stages in the fp32 implicit-GEMM kernel (forward launches)
+STREAMK = 0x100000                        # * w (1..7): stream-K schedule with w persistent workgroups per CU (fp32 tags)
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
 
 

@@ -278,6 +278,37 @@ def test_gather_tables_survive_cache_eviction(K, monkeypatch):
     assert torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 3, 30, 40, 4), (1024, 256, 1, 30, 40, 4), (512, 2048, 1, 15, 20, 4),
+                                   (96, 80, 3, 13, 7, 2), (256, 256, 3, 5, 4, 4)])
+def test_streamk_schedule_matches_plain_launch(K, shape):
+    """Stream-K (persistent workgroups share the K stages of the launch evenly, cut tiles reduced in the launch in K
+    order): same result as the plain launch up to fp32 re-association, bit-identical from run to run, for every
+    workgroups-per-CU setting and tile; residual addend + ReLU epilogue and ragged M / N edges included."""
+    cin, cout, k, H, W, B = shape
+    lv = K.Levels([(H, W)], B)
+    g = K.ConvGeom(lv, cin, cout, k, 1, k // 2)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(lv.rows, cin, generator=gen).cuda()
+    w = (torch.randn(cout * k * k * cin, generator=gen) / (cin * k * k) ** 0.5).cuda()
+    add = torch.randn(lv.rows, cout, generator=gen).cuda()
+    ref = torch.empty(lv.rows, cout, device="cuda")
+    K.conv_fwd(g, x, w, None, ref, addend=add, relu=True, tile=3 | (1 << 12), splitk=False)
+    scale = float(ref.abs().max())
+    for tile in (3, 4, 2):
+        for bk in (0, 0x200):
+            if bk and cin % 32:
+                continue
+            for wgs in (1, 2, 3, 4):
+                t = tile | bk | (wgs * K.STREAMK)
+                y1, y2 = torch.full_like(ref, float("nan")), torch.full_like(ref, float("nan"))
+                K.conv_fwd(g, x, w, None, y1, addend=add, relu=True, tile=t)
+                K.conv_fwd(g, x, w, None, y2, addend=add, relu=True, tile=t)
+                assert torch.equal(y1, y2), (tile, bk, wgs)
+                assert float((y1 - ref).abs().max()) <= 2e-5 * scale, (tile, bk, wgs, float((y1 - ref).abs().max()), scale)
+    ws = K.splitk_ws()
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0          # every ticket handed back
+
+
 def test_stem_maxpool(K):
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 70, 90

@@ -6,7 +6,8 @@ from radet_amd import kernels as K
 H, W, cout = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 tile = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0x203
 lv = K.Levels([(H, W)], 4)
-for cin in (32, 64, 128, 256, 512, 1024, 2048):
+KS = [int(v) for v in os.environ.get('KS', '32,64,128,256,512,1024,2048').split(',')]
+for cin in KS:
     g = K.ConvGeom(lv, cin, cout, 1, 1, 0)
     x = torch.randn(lv.rows, cin, device="cuda")
     w = torch.randn(cout * cin, device="cuda") * 0.05

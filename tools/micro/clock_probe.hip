@@ -11,6 +11,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, float* out, long long* stamps, int iters, size_t span) {
     __shared__ __attribute__((aligned(16))) float tile[4][4096];      // MODE 2 / 3 / 4: 2 / 3 / 4 stages in flight
+    constexpr int STG = MODE < 2 ? 2 : (MODE == 5 ? 3 : MODE);
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -20,13 +21,13 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
     const size_t base = (size_t)blockIdx.x * 65536 + wave * 256 + lane * 4, lim = span - 8192;
     for (int it = 0; it < iters; ++it) {
         if (MODE >= 2) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (base + (size_t)it * 4096) % lim), (lptr_t)(&tile[it % MODE][wave * 256]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + (base + (size_t)it * 4096 + 2048) % lim), (lptr_t)(&tile[it % MODE][1024 + wave * 256]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (base + (size_t)it * 4096) % lim), (lptr_t)(&tile[it % STG][wave * 256]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (base + (size_t)it * 4096 + 2048) % lim), (lptr_t)(&tile[it % STG][1024 + wave * 256]), 16, 0, 0);
         }
         f32x4 a, b;
         if (MODE >= 1) {
-            a = *reinterpret_cast<const f32x4*>(&tile[(it + 1) % (MODE < 2 ? 2 : MODE)][(lane * 4 + wave * 256) & 4095]);
-            b = *reinterpret_cast<const f32x4*>(&tile[(it + 1) % (MODE < 2 ? 2 : MODE)][(2048 + lane * 4 + wave * 256) & 4095]);
+            a = *reinterpret_cast<const f32x4*>(&tile[(it + 1) % STG][(lane * 4 + wave * 256) & 4095]);
+            b = *reinterpret_cast<const f32x4*>(&tile[(it + 1) % STG][(2048 + lane * 4 + wave * 256) & 4095]);
         } else {
             a = f32x4{1.f, 2.f, 3.f, 4.f}; b = a;
         }
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
         if (MODE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
         if (MODE == 3) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); __syncthreads(); }
         if (MODE == 4) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __syncthreads(); }
+        if (MODE == 5) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }      // 3 stages, wave-private tiles: no barrier
     }
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
@@ -73,6 +75,7 @@ int main() {
         run<2>(w, "MFMA + LDS reads + global->LDS, 2 stages");
         run<3>(w, "MFMA + LDS reads + global->LDS, 3 stages");
         run<4>(w, "MFMA + LDS reads + global->LDS, 4 stages");
+        run<5>(w, "same, 3 stages, no barrier (wave-private)");
     }
     return 0;
 }

@@ -1494,7 +1494,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int nKs = a.KH * a.KW * (a.Cin / bk);
     const int rem = T % 256;
     // only for long K loops: on short kernels the extra epilogue launch costs more than the idle tail
-    if (a.sk_wgs == 0 && a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 1152 &&
+    if (a.sk_wgs == 0 && a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 512 &&
         !radet_switches().no_tail_split) {
         int skt = 256 / rem;
         if (skt > 8) skt = 8;

@@ -130,6 +130,15 @@ int radet_relu_bwd(const float* dy, const float* addend, const float* act, float
 int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_ohwi, const float* bias, void* y_nhwc, int B, int H,
                               int W, void* stream);
 int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream);
+/* Two tensors of one geometry (cls_convs[i].gn / reg_convs[i].gn, atss_head.py:60-76) in one pair of launches. */
+int radet_gn_relu_fwd_pair(const float* z0, const float* gamma0, const float* beta0, float* y0, float* stats0,
+                           float* partial_ws0, const float* z1, const float* gamma1, const float* beta1, float* y1,
+                           float* stats1, float* partial_ws1, int B, int C, int groups, float eps, int relu,
+                           const int* seg_desc, int nseg, void* stream);
+int radet_gn_relu_fwd_pair_h(const void* z0, const float* gamma0, const float* beta0, void* y0, float* stats0,
+                             float* partial_ws0, const void* z1, const float* gamma1, const float* beta1, void* y1,
+                             float* stats1, float* partial_ws1, int B, int C, int groups, float eps, int relu,
+                             const int* seg_desc, int nseg, void* stream);
 int radet_gn_relu_fwd_h(const void* z, const float* gamma, const float* beta, void* y, float* stats, float* partial_ws,
                         int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg, void* stream);
 int radet_gn_relu_bwd_h(const void* dy, const void* z, const float* stats, const float* gamma, const float* beta, void* dz,

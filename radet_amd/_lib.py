@@ -47,6 +47,8 @@ SIGNATURES = {
     "radet_maxpool3x3s2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "radet_gn_workspace_floats": (_i, [_i, _p, _i]),
     "radet_gn_relu_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_fwd_pair": (_i, [_p] * 12 + [_i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_fwd_pair_h": (_i, [_p] * 12 + [_i, _i, _i, _f, _i, _p, _i, _p]),
     "radet_gn_relu_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "radet_upsample_add": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "radet_upsample_add_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -388,9 +388,24 @@ static int gn_total_chunks(const RadetSegs& segs, int B) {
 }
 
 // partial[chunk][32 groups][2] = (sum, sumsq) over the chunk's pixels x 8 channels
+// one or two independent tensors of the same geometry per launch (blockIdx.y): cls / reg tower of one layer
 template <class T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ z, float* __restrict__ partial,
-                                                       const RadetSegs segs, int B) {
+struct GnFwdSet {
+    const T* z;
+    float* partial;
+    const float *gamma, *beta;
+    T* y;
+    float* stats;
+};
+template <class T>
+struct GnFwdArgs {
+    GnFwdSet<T> p[2];
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnFwdArgs<T> args, const RadetSegs segs, int B) {
+    const T* __restrict__ z = args.p[blockIdx.y].z;
+    float* __restrict__ partial = args.p[blockIdx.y].partial;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     const int col = tid & 63, prow = tid >> 6;
@@ -450,10 +465,14 @@ __device__ __forceinline__ void gn_reduce_partials(const float* __restrict__ par
 
 // y = relu?((z - mean) * rstd * gamma + beta); the chunk-0 block of each image also publishes (mean, rstd)
 template <class T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ z, const float* __restrict__ partial,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ y, float* __restrict__ stats,
-                                                       const RadetSegs segs, int B, float eps, int relu) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, const RadetSegs segs, int B, float eps,
+                                                       int relu) {
+    const T* __restrict__ z = args.p[blockIdx.y].z;
+    const float* __restrict__ partial = args.p[blockIdx.y].partial;
+    const float* __restrict__ gamma = args.p[blockIdx.y].gamma;
+    const float* __restrict__ beta = args.p[blockIdx.y].beta;
+    T* __restrict__ y = args.p[blockIdx.y].y;
+    float* __restrict__ stats = args.p[blockIdx.y].stats;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ float sm[32], sr[32];
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ z, 
 template <class T>
 static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T* y, float* stats,
                             float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
-                            int nseg, void* stream) {
+                            int nseg, void* stream, const GnFwdSet<T>* second = nullptr) {
     if (C != 256 || groups != 32) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
@@ -519,10 +538,33 @@ static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T
     }
     const int chunks = gn_total_chunks(segs, B);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, z, partial_ws, segs, B);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, z, partial_ws, gamma, beta, y, stats, segs, B,
-                       eps, relu);
+    GnFwdArgs<T> args;
+    args.p[0] = GnFwdSet<T>{z, partial_ws, gamma, beta, y, stats};
+    args.p[1] = second ? *second : args.p[0];
+    const int sets = second ? 2 : 1;
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, sets), dim3(256), 0, st, args, segs, B);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(chunks, sets), dim3(256), 0, st, args, segs, B, eps, relu);
     return radet_check_launch();
+}
+
+// GroupNorm + ReLU of two tensors of the same geometry in one pair of launches (cls_convs[i] / reg_convs[i]: two
+// separate launches on two streams cost a fork and a join, 10-17 us of idle device each, around 23 us of kernels)
+extern "C" int radet_gn_relu_fwd_pair(const float* z0, const float* gamma0, const float* beta0, float* y0, float* stats0,
+                                      float* partial_ws0, const float* z1, const float* gamma1, const float* beta1,
+                                      float* y1, float* stats1, float* partial_ws1, int B, int C, int groups, float eps,
+                                      int relu, const int* seg_desc, int nseg, void* stream) {
+    const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1};
+    return gn_relu_fwd_impl<float>(z0, gamma0, beta0, y0, stats0, partial_ws0, B, C, groups, eps, relu, seg_desc, nseg,
+                                   stream, &second);
+}
+
+extern "C" int radet_gn_relu_fwd_pair_h(const void* z0, const float* gamma0, const float* beta0, void* y0, float* stats0,
+                                        float* partial_ws0, const void* z1, const float* gamma1, const float* beta1,
+                                        void* y1, float* stats1, float* partial_ws1, int B, int C, int groups, float eps,
+                                        int relu, const int* seg_desc, int nseg, void* stream) {
+    const GnFwdSet<__bf16> second{(const __bf16*)z1, partial_ws1, gamma1, beta1, (__bf16*)y1, stats1};
+    return gn_relu_fwd_impl<__bf16>((const __bf16*)z0, gamma0, beta0, (__bf16*)y0, stats0, partial_ws0, B, C, groups, eps,
+                                    relu, seg_desc, nseg, stream, &second);
 }
 
 extern "C" int radet_gn_relu_fwd(const float* z, const float* gamma, const float* beta, float* y, float* stats,

@@ -609,16 +609,10 @@ class Engine:
         self._tower_launch(K.conv_fwd_pair, cc.geom, dict(x=xc, w=cc.wf, y=zc), dict(x=xr, w=cr.wf, y=zr),
                            tile=self._ttile(cc))
         gc, gr = f"bbox_head.cls_convs.{i}.gn", f"bbox_head.reg_convs.{i}.gn"
-        side = self._side() if self.use_streams else None
-        if side is not None:                        # the two (HBM-bound) GroupNorms overlap each other's tails
-            self._fork(side)
-            with torch.cuda.stream(side):
-                K.gn_relu_fwd(self.plv, zr, p[gr + ".weight"], p[gr + ".bias"], yr, b[f"reg.stats{i}"], self.gn_ws2)
-            K.gn_relu_fwd(self.plv, zc, p[gc + ".weight"], p[gc + ".bias"], yc, b[f"cls.stats{i}"], self.gn_ws)
-            self._join(side)
-        else:
-            K.gn_relu_fwd(self.plv, zc, p[gc + ".weight"], p[gc + ".bias"], yc, b[f"cls.stats{i}"], self.gn_ws)
-            K.gn_relu_fwd(self.plv, zr, p[gr + ".weight"], p[gr + ".bias"], yr, b[f"reg.stats{i}"], self.gn_ws)
+        # both GroupNorms in one pair of launches (on two streams the fork and the join idled the device for longer
+        # than the 23 us of kernels they overlapped)
+        K.gn_relu_fwd_pair(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], yc, b[f"cls.stats{i}"], self.gn_ws),
+                           (zr, p[gr + ".weight"], p[gr + ".bias"], yr, b[f"reg.stats{i}"], self.gn_ws2))
         return yc, yr
 
     def head_forward(self, P):

@@ -536,6 +536,13 @@ def gn_relu_fwd(levels, z, gamma, beta, y, stats, ws, eps=1e-5, relu=True):
               eps, int(relu), d, n, _stream())
 
 
+def gn_relu_fwd_pair(levels, a, b, eps=1e-5, relu=True):
+    """GroupNorm + ReLU of two tensors of one geometry in one pair of launches; a / b = (z, gamma, beta, y, stats, ws)."""
+    d, n = _gn_desc(levels)
+    _lib.call(_h("radet_gn_relu_fwd_pair", a[0]), *[_ptr(t) for t in a], *[_ptr(t) for t in b], levels.B, 256, 32, eps,
+              int(relu), d, n, _stream())
+
+
 def gn_relu_bwd(levels, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws, relu=True):
     d, n = _gn_desc(levels)
     _lib.call(_h("radet_gn_relu_bwd", dy), _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr(dgamma),

@@ -358,6 +358,19 @@ def test_groupnorm_fwd_bwd(K):
     for i in range(len(hw)):
         r0, r1 = lv.level_rows(i)
         assert rel_err(from_rows(y[r0:r1], B, *hw[i]), ys[i].detach()) < 1e-5
+    # the paired launch (cls / reg tower of one layer): bit-identical to two single launches, in fp32 and bf16 storage
+    z2, gm2, bt2 = z * 0.7 - 0.2, gm * 1.3, bt - 0.1
+    y2, stats2, ws2 = torch.empty_like(z), torch.empty_like(stats), torch.empty_like(ws)
+    K.gn_relu_fwd(lv, z2, gm2, bt2, y2, stats2, ws2)
+    ya, yb, sa, sb = torch.empty_like(z), torch.empty_like(z), torch.empty_like(stats), torch.empty_like(stats)
+    K.gn_relu_fwd_pair(lv, (z, gm, bt, ya, sa, ws), (z2, gm2, bt2, yb, sb, ws2))
+    assert torch.equal(ya, y) and torch.equal(yb, y2) and torch.equal(sa, stats) and torch.equal(sb, stats2)
+    zh, zh2 = z.bfloat16(), z2.bfloat16()
+    yh, yh2, yha, yhb = (torch.empty_like(zh) for _ in range(4))
+    K.gn_relu_fwd(lv, zh, gm, bt, yh, sa, ws)
+    K.gn_relu_fwd(lv, zh2, gm2, bt2, yh2, sb, ws2)
+    K.gn_relu_fwd_pair(lv, (zh, gm, bt, yha, sa, ws), (zh2, gm2, bt2, yhb, sb, ws2))
+    assert torch.equal(yha, yh) and torch.equal(yhb, yh2)
     dy = torch.cat([to_rows(d) for d in dys]).to(dev)
     dz = torch.empty_like(z)
     dg, db = torch.empty(Cch, device=dev), torch.empty(Cch, device=dev)

@@ -302,19 +302,39 @@ __global__ __launch_bounds__(256) void unfold_kernel(const RadetConvDesc* __rest
         // k0 is a multiple of KT*... only when K > 2304; handle generally by index math below
         __syncthreads();
         for (int i = threadIdx.x; i < kn; i += 256) {        // i + k0 = t*cin + c  (OHWI inner index)
+            // slabs summed in split order (as before: same bits), but four loads in flight per thread: with the split
+            // count a run-time value the plain loop is load -> wait -> add, one HBM round trip per slab
+            const float* p = d.dwf_slabs + (size_t)o * K + k0 + i;
             float g = 0.f;
-            for (int sp = 0; sp < d.nsplit; ++sp) g += d.dwf_slabs[sp * slab + (size_t)o * K + k0 + i];
+            int sp = 0;
+            for (; sp + 4 <= d.nsplit; sp += 4) {
+                const float v0 = p[(size_t)sp * slab], v1 = p[(size_t)(sp + 1) * slab];
+                const float v2 = p[(size_t)(sp + 2) * slab], v3 = p[(size_t)(sp + 3) * slab];
+                g = (((g + v0) + v1) + v2) + v3;
+            }
+            for (; sp < d.nsplit; ++sp) g += p[(size_t)sp * slab];
             row[i] = g;
         }
         __syncthreads();
         if (K <= 2304) {
             // whole row resident: emit OIHW order j = c*KT + t contiguously
-            for (int j = threadIdx.x; j < K; j += 256) {
-                const int c = j / KT, t = j - c * KT;
-                const float g = row[t * d.cin + c];
-                const size_t wi = (size_t)o * K + j;
-                dot += g * d.w[wi];
-                d.dw[wi] = g * s;
+            for (int j0 = threadIdx.x; j0 < K; j0 += 4 * 256) {       // 4 weight loads in flight per thread
+                float wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 256 * u;
+                    wv[u] = d.w[(size_t)o * K + (j < K ? j : threadIdx.x)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 256 * u;
+                    if (j < K) {
+                        const int c = j / KT, t = j - c * KT;
+                        const float g = row[t * d.cin + c];
+                        dot += g * wv[u];
+                        d.dw[(size_t)o * K + j] = g * s;
+                    }
+                }
             }
         } else {
             for (int i = threadIdx.x; i < kn; i += 256) {

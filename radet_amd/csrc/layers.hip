@@ -748,7 +748,19 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
     const int lc = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + lc;   // 0..511 = k*256 + c
     float a = 0.f;
-    for (int k = rg; k < nchunks; k += 16) a += cpart[(size_t)k * 512 + col];
+    // same order of additions as a plain loop, with 8 loads in flight (a plain loop is one round trip per chunk row: 26
+    // dependent loads per thread on the tower's backward chain)
+    for (int k0 = rg; k0 < nchunks; k0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 16 * u;
+            v[u] = cpart[(size_t)(k < nchunks ? k : rg) * 512 + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 16 * u < nchunks) a += v[u];
+    }
     __shared__ float red[16][16];
     red[rg][lc] = a;
     __syncthreads();

@@ -50,13 +50,15 @@ class Conv:
 
 class Engine:
     def __init__(self, params, grads, depth=50, num_classes=21, frozen_stages=1, strides=(8, 16, 32, 64, 128),
-                 stacked_convs=4, feat=256, math=None):
+                 stacked_convs=4, feat=256, math=None, watch=None):
         """params / grads: dict name -> device tensor (reference state-dict names; grads only for
         trainable parameters, same shapes).  math: "fp32" (default) or "bf16" = conv operands rounded to bf16 on
         their way into the matrix cores, fp32 accumulate, fp32 tensors / GroupNorm / loss / optimizer (the mixed
         precision of BASELINE config 3; env RADET_MATH)."""
         math = math or os.environ.get("RADET_MATH", "fp32")
         assert math in ("fp32", "bf16", "bf16-storage"), math
+        self.watch = watch or {}                  # name -> tensors whose version counters guard the folded weights
+        self._watched = {}
         self.math = 1 if math == "bf16" else 0
         # "bf16-storage": activations, folded weights and activation gradients are bf16 tensors in HBM
         # (v_mfma_f32_32x32x16_bf16, fp32 accumulate); head outputs, loss, statistics, weight gradients, master
@@ -444,17 +446,62 @@ class Engine:
         nf = 0
         while nf < n and not self.convs[nf].trainable:
             nf += 1
-        if self.use_streams and 0 < nf < n and os.environ.get("RADET_FOLD_SIDE", "1") != "0":
+        # Folded weights are kept while their sources are unchanged.  The frozen convs (stem + frozen stages, BN in eval
+        # mode) never change between steps: ~0.1 ms per step that sat in front of the stem on the main stream.  The
+        # trainable convs change with every optimizer step (`params_changed()`), but not between inference calls.
+        # A write through torch (load_state_dict, checkpoint load, replica sync, a torch optimizer) moves the tensors'
+        # version counters and is seen here; after a write torch does not track call `invalidate_fold()`.
+        vf, vt = self._part_version(0, nf), self._part_version(nf, n) + (self._param_epoch,)
+        do_f = nf > 0 and vf != self._folded[0]
+        do_t = nf < n and vt != self._folded[1]
+        tail = self.table[nf * C.sizeof(_lib.RadetConvDesc):]
+        if do_t and self.use_streams and nf > 0 and os.environ.get("RADET_FOLD_SIDE", "1") != "0":
             side = self._side()
             self._fork(side)
             with torch.cuda.stream(side):
-                K.fold_weights(self.table[nf * C.sizeof(_lib.RadetConvDesc):], n - nf)
+                K.fold_weights(tail, n - nf)
                 ev = self._event()
                 ev.record()
-            K.fold_weights(self.table, nf)
             self._fold_event = ev
-        else:
+            if do_f:
+                K.fold_weights(self.table, nf)
+        elif do_f and do_t:
             K.fold_weights(self.table, n)
+        elif do_f:
+            K.fold_weights(self.table, nf)
+        elif do_t:
+            K.fold_weights(tail, n - nf)
+        self._folded = (vf, vt)
+
+    _folded = (None, None)
+    _param_epoch = 0
+    _watched = None
+
+    def _part_version(self, lo, hi):
+        if os.environ.get("RADET_FOLD_EVERY_CALL"):
+            return (object(),)                    # never equal: fold on every call
+        key = (lo, hi)
+        watched = self._watched.get(key)
+        if watched is None:                       # the tensors (arena views + module Parameters) behind convs[lo:hi]
+            watched = []
+            for c in self.convs[lo:hi]:
+                names = [c.name + ".weight"] + ([c.name + ".bias"] if c.bias else [])
+                if c.bn:
+                    names += [c.bn + sfx for sfx in (".weight", ".bias", ".running_mean", ".running_var")]
+                for k in names:
+                    if k in self.p:
+                        watched += list(self.watch.get(k, (self.p[k],)))
+            self._watched[key] = watched
+        # (views of one arena share a version counter: a write to any of them re-folds the whole part -- conservative)
+        return (tuple(t._version for t in watched), tuple(t.data_ptr() for t in watched[:1]), self.h16, self.math)
+
+    def params_changed(self):
+        """The trainable parameters were written by a kernel torch does not see (the fused clip + AdamW step)."""
+        self._param_epoch += 1
+
+    def invalidate_fold(self):
+        """Fold everything again on the next call (after writing parameters through `.data` or a raw kernel)."""
+        self._folded = (None, None)
 
     def _await_fold(self):
         if self._fold_event is not None:

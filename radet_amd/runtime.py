@@ -44,12 +44,16 @@ class FlatParams:
         self.params = torch.zeros(self.n_train, device=device)
         self.grads = torch.zeros(self.n_train, device=device)
         self.p, self.g = {}, {}
+        # name -> the tensor objects through which torch code can write this parameter: the arena view and the module's
+        # Parameter (same storage, separate version counters); Engine.fold() watches both
+        self.watch = {}
         for n, p in train:
             o = self.offsets[n]
             v = self.params[o:o + p.numel()].view(p.shape)
             v.copy_(p.data)
             p.data = v
             self.p[n] = v
+            self.watch[n] = (v, p)
             self.g[n] = self.grads[o:o + p.numel()].view(p.shape)
         off = 0
         foffs = {}
@@ -63,6 +67,7 @@ class FlatParams:
             v.copy_(p.data)
             p.data = v
             self.p[n] = v
+            self.watch[n] = (v, p)
         for n, b in bufs:
             v = self.frozen[foffs[n]:foffs[n] + b.numel()].view(b.shape)
             v.copy_(b)
@@ -160,7 +165,8 @@ class DetectorRuntime:
         self.dev = dev
         self.flat = FlatParams(det, dev)
         self.engine = Engine(self.flat.p, self.flat.g, depth=depth, num_classes=num_classes,
-                             frozen_stages=frozen_stages, strides=strides, stacked_convs=stacked_convs, math=math)
+                             frozen_stages=frozen_stages, strides=strides, stacked_convs=stacked_convs, math=math,
+                             watch=self.flat.watch)
         self.num_classes, self.strides = num_classes, tuple(strides)
         self.opt_state = None
         self.step_count = 0
@@ -287,6 +293,7 @@ class DetectorRuntime:
         K.adamw_step(self.flat.params, self.flat.grads, st["m"], st["v"], self.flat.n_train, st["lr"] if lr is None else lr,
                      st["betas"], st["eps"], st["wd"], self.step_count, st["max_norm"], grad_div, st["partials"],
                      st["grad_norm"])
+        self.engine.params_changed()              # the kernel wrote the arena behind torch's back: fold again next step
 
     # ------------------------------------------------------------------ data-parallel train step
     def train_step(self, img, tg, lr=None):
@@ -500,7 +507,8 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
             graph = torch.cuda.CUDAGraph()
             cap_stream = torch.cuda.Stream(device=self.dev)
             K.splitk_ws_for(cap_stream)                         # allocate the stream's split-K workspace outside capture
-            with torch.cuda.graph(graph, stream=cap_stream):
+            self.engine.invalidate_fold()                       # the weight fold is part of the graph: replays see
+            with torch.cuda.graph(graph, stream=cap_stream):    # the parameters of the moment, like the eager path
                 self.forward(static_img)
                 outs = _post_launch(self, hw, sf, test_cfg)
             g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs, plan=self.engine.buf)

@@ -211,6 +211,47 @@ def test_detect_hipgraph_replay_matches_eager():
         assert sum(d.shape[0] for d, _ in a) > 0
 
 
+def test_folded_weights_are_cached_until_parameters_change(monkeypatch):
+    """Engine.fold() keeps the folded (BN-scaled, re-laid-out) weights while their sources are unchanged: inference calls
+    fold nothing after the first, a train step re-folds only the trainable convs, and any write through torch (here an
+    in-place scale of a frozen stem weight / of a trainable head weight) or `invalidate_fold()` is picked up; results
+    equal those of folding on every call."""
+    from radet_amd import kernels as K
+    det = make_det().eval()
+    rt = det.runtime()
+    e = rt.engine
+    calls = []
+    real = K.fold_weights
+    monkeypatch.setattr(K, "fold_weights", lambda table, n: (calls.append(n), real(table, n))[1])
+    img = torch.randn(2, 3, 160, 192, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        f0 = [t.clone() for t in det.extract_feat(img)]
+        n_all = sum(calls)
+        assert n_all == len(e.convs)
+        calls.clear()
+        f1 = det.extract_feat(img)
+        assert calls == [] and all(torch.equal(a, b) for a, b in zip(f0, f1))
+        e.p["backbone.conv1.weight"].mul_(1.25)                   # frozen stem, written through the arena view
+        f2 = [t.clone() for t in det.extract_feat(img)]
+        nf = sum(1 for c in e.convs if not c.trainable)           # leading frozen convs (stem + layer1)
+        assert 0 < nf < n_all and sum(calls) >= nf and not torch.equal(f2[0], f0[0])
+        calls.clear()
+        det.bbox_head.atss_cls.weight.mul_(0.5)                   # trainable, written through the module's Parameter
+        f2 = [t.clone() for t in det.extract_feat(img)]
+        assert sum(calls) >= n_all - nf
+        monkeypatch.setenv("RADET_FOLD_EVERY_CALL", "1")
+        calls.clear()
+        f3 = det.extract_feat(img)
+        assert sum(calls) == n_all and all(torch.equal(a, b) for a, b in zip(f2, f3))
+        monkeypatch.delenv("RADET_FOLD_EVERY_CALL")
+        e.invalidate_fold()
+        det.extract_feat(img)
+        calls.clear()
+        e.params_changed()                                        # what the fused AdamW step reports
+        det.extract_feat(img)
+        assert sum(calls) == n_all - nf and nf > 0                # trainable part only
+
+
 def test_multi_geometry_plans_no_retune_no_realloc():
     """Engine keeps a plan per (B, H, W): alternating training at B = 4 with detection at B = 1 (a harness that
     interleaves validation) builds each plan once -- no second autotune, no reallocation, identical results."""

@@ -61,7 +61,10 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * +0x800 = bf16 storage (x, w, addend, mask are bf16 tensors, Cin % 32 == 0; y bf16, or fp32 with +0x10000);
  * +0x400 = bf16 math mode (operands rounded RNE to bf16 between LDS and the matrix core, fp32 accumulate, fp32
  * tensors in HBM -- the arithmetic of mmcv's fp16 wrapper, `apis/train.py:113-117`, in bf16); bits 12-15 force
- * a split-K factor.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
+ * a split-K factor; +0x20000 = 3 LDS stages (fp32, launches that run alone on the device); + (w << 20), w = 1..7 =
+ * stream-K schedule with w persistent workgroups per CU (fp32, untagged symbol, tiles 2-4): the K stages of the whole
+ * launch are shared evenly, tiles cut by a share boundary are reduced inside the launch in K order (deterministic);
+ * plain launch when there is less than one K stage per workgroup.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
  * tickets that must be ZERO before the first launch (every launch leaves them zero); when given, launches with too few
  * tiles for 256 CUs split the K loop (<= 8 ways, or only the left-over tiles of the last round) and the workgroup that
  * arrives last at a tile sums the partial tiles in split order and applies the epilogue -- one launch, deterministic.

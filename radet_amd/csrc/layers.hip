@@ -170,18 +170,22 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
         p /= Wo;
         const int oy = (int)(p % Ho);
         const int n = (int)(p / Ho);
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        // nine unconditional loads in flight: an out-of-range tap is clamped onto the border pixel, which is inside the
+        // window already (max is idempotent), instead of skipped (a skipped load is a branch and a wait per tap)
+        float4 v[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int iy = oy * 2 - 1 + r;
-            if (iy < 0 || iy >= H) continue;
+            const int iy = min(max(oy * 2 - 1 + r, 0), H - 1);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const int ix = ox * 2 - 1 + q;
-                if (ix < 0 || ix >= W) continue;
-                const float4 v = ld4(x, ((size_t)(n * H + iy) * W + ix) * C4 + c);
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                const int ix = min(max(ox * 2 - 1 + q, 0), W - 1);
+                v[r * 3 + q] = ld4(x, ((size_t)(n * H + iy) * W + ix) * C4 + c);
             }
+        }
+        float4 m = v[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) {
+            m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
         }
         st4(y, i, m);
     }

@@ -236,7 +236,7 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "conv_igemmg_kernel<64,64,2,2,TAG=1,BK=32,NSTG=3>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
+                               "kernel": "conv_igemmg_kernel<128,64,2,2,TAG=1,BK=32,NSTG=3>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
                                          + ("; forward launches, cls_convs[i] + reg_convs[i] grouped per launch (2 GEMMs), alone on the device"
                                             if hybrid else "; fwd+dgrad launches, cls+reg layers grouped per launch, flop_per_launch = average"
                                             if pair else "; fwd+dgrad launches, cls and reg towers run concurrently on two streams"),

@@ -79,18 +79,23 @@ class Engine:
     # ------------------------------------------------------------------ profiling hook
     # own kernel symbol for the head-tower GEMM family (see conv_igemm.hip) + its measured-best tile:
     # 64x64 block tile with a 32-deep K step (bench_conv.py: 98.7 vs 88.8 TFLOP/s for the heuristic pick)
-    TOWER_TAG = 0x100 | 0x200 | 3
+    TOWER_TAG = 0x100 | 0x200 | 3        # backward: 64 x 64 tile, K step 32
+    TOWER_TAG_FWD = 0x100 | 0x200 | 2    # forward: 128 x 64 tile (2 accumulators per wave), K step 32
 
     def _ttile(self, c, bwd=False, tag=True):
-        """tile_override of a tower conv launch + profiling tag.  Forward: the measured-best 64x64 tile with a 32-deep K
-        step in every arithmetic mode (the forward launches are grouped cls + reg pairs, which the single-conv timing of
-        the autotuner does not represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch); fp32
-        forward launches run alone on the device -> 3 LDS stages (+8 %: 112 vs 104 TFLOP/s).  Backward: fixed tile in
-        fp32, autotuned in the bf16 modes (single launches, as tuned)."""
-        if bwd and (self.math or self.h16):
+        """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step
+        (the forward launches are grouped cls + reg pairs, which the single-conv timing of the autotuner does not
+        represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch).  fp32: 128 x 64 (two
+        accumulators per wave; with the accumulators in VGPRs it fits 3 waves per SIMD: 120.5 vs 116.5 TFLOP/s for
+        64 x 64) and, as these launches run alone on the device, 3 LDS stages; bf16 modes: 64 x 64.  Backward: 64 x 64
+        in fp32 (128 x 64 / 128 x 128 measured equal next to the wgrad streams), autotuned in the bf16 modes."""
+        fp32 = not self.math and not self.h16
+        if bwd and not fp32:
             t = c.geom.bwd_tile
+        elif bwd or not fp32:
+            t = self.TOWER_TAG & ~0x100
         else:
-            t = (self.TOWER_TAG & ~0x100) | (K.STAGES3 if (not bwd and not self.math and not self.h16) else 0)
+            t = (self.TOWER_TAG_FWD & ~0x100) | K.STAGES3
         return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 

@@ -85,17 +85,16 @@ class Engine:
     def _ttile(self, c, bwd=False, tag=True):
         """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step
         (the forward launches are grouped cls + reg pairs, which the single-conv timing of the autotuner does not
-        represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch).  fp32: 128 x 64 (two
-        accumulators per wave; with the accumulators in VGPRs it fits 3 waves per SIMD: 120.5 vs 116.5 TFLOP/s for
-        64 x 64) and, as these launches run alone on the device, 3 LDS stages; bf16 modes: 64 x 64.  Backward: 64 x 64
-        in fp32 (128 x 64 / 128 x 128 measured equal next to the wgrad streams), autotuned in the bf16 modes."""
+        represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch): 128 x 64, two accumulators
+        per wave -- with the accumulators in VGPRs it fits 3 waves per SIMD: 120.5 vs 116.5 TFLOP/s for 64 x 64 in fp32,
+        +0.6 % / +1.5 % of the step in the bf16-storage / bf16-math modes; the fp32 launches run alone on the device and
+        take 3 LDS stages.  Backward: 64 x 64 in fp32 (128 x 64 / 128 x 128 measured equal next to the wgrad streams),
+        autotuned in the bf16 modes."""
         fp32 = not self.math and not self.h16
-        if bwd and not fp32:
-            t = c.geom.bwd_tile
-        elif bwd or not fp32:
-            t = self.TOWER_TAG & ~0x100
+        if bwd:
+            t = (self.TOWER_TAG & ~0x100) if fp32 else c.geom.bwd_tile
         else:
-            t = (self.TOWER_TAG_FWD & ~0x100) | K.STAGES3
+            t = (self.TOWER_TAG_FWD & ~0x100) | (K.STAGES3 if fp32 else 0)
         return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
 

@@ -39,6 +39,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "conv_igemmg_kernel<128, 64, 2, 2, 1, 32, 3, false>" \
     $OUT/pmc_hbm_traffic_fp32.txt $OUT/roofline_traffic.json 103022592 > /dev/null 2>> $OUT/bench_default.err
-python3 $R/tools/pmc_traffic.py /tmp/pmc_bf16s_FETCH_SIZE /tmp/pmc_bf16s_WRITE_SIZE "conv_igemmg_kernel<64, 64, 2, 2, 5, 32, 2, false>" \
+python3 $R/tools/pmc_traffic.py /tmp/pmc_bf16s_FETCH_SIZE /tmp/pmc_bf16s_WRITE_SIZE "conv_igemmg_kernel<128, 64, 2, 2, 5, 32, 2, false>" \
     $OUT/pmc_hbm_traffic_bf16_storage.txt $OUT/roofline_traffic_bf16_storage.json 51511296 > /dev/null 2>> $OUT/bench_default.err
 ls -la $OUT

@@ -254,9 +254,22 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
                 if (d.bn_gamma && o < d.cout) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
                 ssc[tid] = s;
             }
-            for (int i = tid; i < no * run; i += 256) {
-                const int oo = i / run, k = i - oo * run;   // k = c_local*KT + t
-                tile[oo][k] = d.w[((size_t)(o0 + oo) * d.cin + c0) * KT + k];
+            for (int i0 = tid; i0 < no * run; i0 += 4 * 256) {           // 4 loads in flight per thread
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + 256 * u, no * run - 1);
+                    const int oo = i / run, k = i - oo * run;               // k = c_local*KT + t
+                    v[u] = d.w[((size_t)(o0 + oo) * d.cin + c0) * KT + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 256 * u;
+                    if (i < no * run) {
+                        const int oo = i / run, k = i - oo * run;
+                        tile[oo][k] = v[u];
+                    }
+                }
             }
             __syncthreads();
             // OHWI: wf[o][t][c0 + cl]  (runs of nc floats)

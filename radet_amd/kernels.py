@@ -265,7 +265,10 @@ def save_tune_cache(path=None):
         pass
 
 
-TUNE_REPS = int(os.environ.get("RADET_TUNE_REPS", "3"))      # timed launches per candidate (median)
+TUNE_REPS = int(os.environ.get("RADET_TUNE_REPS", "3"))      # timed samples per candidate (the fastest counts)
+# launches per sample, back to back between one pair of events: a single 30-60 us launch per sample carries 5-10 us of
+# event / launch-gap jitter, more than the differences between the candidates
+TUNE_BURST = max(1, int(os.environ.get("RADET_TUNE_BURST", "4")))
 
 
 def autotune(g, need_dgrad=True, reps=None):
@@ -285,10 +288,11 @@ def autotune(g, need_dgrad=True, reps=None):
             for i, t in enumerate(cands):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                fn(t)
+                for _b in range(TUNE_BURST):
+                    fn(t)
                 e.record()
                 e.synchronize()
-                best[i] = min(best[i], s.elapsed_time(e))
+                best[i] = min(best[i], s.elapsed_time(e) / TUNE_BURST)
         return cands[min(range(len(cands)), key=lambda i: (best[i], i))]
 
     def cands(kdim, n, m, taps):
@@ -401,10 +405,11 @@ def autotune_wgrad(g, reps=None):
                 g.wgrad_flags, g.nsplit = fl, S
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                conv_wgrad(g, dy, x, slabs)
+                for _b in range(TUNE_BURST):
+                    conv_wgrad(g, dy, x, slabs)
                 e.record()
                 e.synchronize()
-                tbest[i] = min(tbest[i], s.elapsed_time(e))
+                tbest[i] = min(tbest[i], s.elapsed_time(e) / TUNE_BURST)
         best = None
         for (fl, S), t in zip(cands, tbest):
             cost = t + S * g.cout * kk * g.cin * 8 / 3e12 * 1e3

@@ -308,10 +308,10 @@ def autotune(g, need_dgrad=True, reps=None):
             ntiles = -(-m // bm) * -(-n // bn)
             nk = taps * kdim // (32 if t & 0x200 else 16)
             if ntiles < 1024:
-                out += [t | (sk << 12) for sk in (1, 2, 3, 4, 6, 8) if nk // sk >= 4]
+                out += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
                 # stream-K (fp32 tensors, fp32 / bf16-rounded math is decided by the launcher's tag: fp32 only)
-                if not g.math and not g.h16 and (t & 0xFF) in (3, 4) and ntiles % 256:
-                    out += [t | (w * STREAMK) for w in (2, 3) if ntiles * nk >= 256 * w]
+                if not g.math and not g.h16 and (t & 0xFF) in (2, 3, 4) and ntiles % 256:
+                    out += [t | (w * STREAMK) for w in (1, 2, 3, 4) if ntiles * nk >= 256 * w]
         return out
 
     global _TUNE_DIRTY, TUNE_RUNS
@@ -330,6 +330,8 @@ def autotune(g, need_dgrad=True, reps=None):
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev, dtype=dt)
+            # (no 3-stage candidates for dgrad: timed alone they win, next to the wgrad streams they lose -- a tune file
+            # that allowed them made the step 1 % slower)
             bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
         _TUNE_CACHE[key] = (ft, bt)
         if os.environ.get("RADET_TUNE_LOG"):

@@ -381,6 +381,45 @@ __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// fp32 operand -> three bf16 planes, exact: x = hi + mid + lo where hi / mid / lo are the top 8 / next 8 / last 8 bits of
+// the significand (truncation; each residual x - hi is exact in fp32).  Two 4-float fragments (8 k values of one lane)
+// become three bf16x8 MFMA operands; v_perm_b32 packs the high halves of two dwords.
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_bf16(const float (&a)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    unsigned ua[8], ur[8], ul[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ua[e] = __float_as_uint(a[e]);
+        const float r = a[e] - __uint_as_float(ua[e] & 0xFFFF0000u);
+        ur[e] = __float_as_uint(r);
+        ul[e] = __float_as_uint(r - __uint_as_float(ur[e] & 0xFFFF0000u));
+    }
+    u32x4_ h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = __builtin_amdgcn_perm(ua[2 * q + 1], ua[2 * q], 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(ur[2 * q + 1], ur[2 * q], 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(ul[2 * q + 1], ul[2 * q], 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, h);
+    mid = __builtin_bit_cast(bf16x8, m);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ void split3_bf16(const f32x4& f0, const f32x4& f1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+    const float a[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    split3_bf16(a, hi, mid, lo);
+}
+// acc += A x B with fp32-accurate products from the planes of A and B (6 of the 9 plane products, small terms first)
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
+                                        const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 // Implicit-GEMM kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
 // global_load_lds_dwordx4, no staging registers and no ds_write pass.  A wave load writes 1 KiB lane-linearly, so
 // the LDS rows are unpadded [row][BK]; bank conflicts of the 16-byte fragment reads are avoided by an XOR swizzle
@@ -401,6 +440,10 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     constexpr int NS = BK / 8;
     constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
     constexpr bool H16 = (TAG & 4) != 0;                      // bit 2: bf16 storage (a 16-byte slot = 8 bf16 = one MFMA operand)
+    // bit 3: fp32 tensors, fp32-accurate products on the bf16 matrix cores: every operand is split into three bf16 planes
+    // in registers and 6 of the 9 plane products (everything above 2^-24 relative) are accumulated by
+    // v_mfma_f32_32x32x16_bf16, which retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32
+    constexpr bool X3 = (TAG & 8) != 0;
     static_assert(WM * WN == 4, "4 waves");
     // NSTG LDS stages: loads run NSTG - 1 K steps ahead of the MFMAs.  3 stages hide more L2 latency (+8 % on the
     // tower GEMM running alone) but cost LDS occupancy, which loses when dgrad and wgrad kernels share the CUs: used
@@ -547,13 +590,43 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int AO = BUF * BM * BK * 4, BO = BUF * BN * BK * 4, RO = 32 * BK * 4;
         if (it + NSTG - 1 < nK) issue_stage((BUF + NSTG - 1) % NSTG);
-        f32x4 af[2][TM], bf[2][TN];
+        f32x4 af[X3 ? NS : 2][TM], bf[X3 ? NS : 2][TN];
         auto read_s = [&](int s, int pp) {
             lds_read128<AO>(af[pp][0], aaddr[s]);
             if constexpr (TM > 1) lds_read128<AO + RO>(af[pp][TM - 1], aaddr[s]);
             lds_read128<BO>(bf[pp][0], baddr[s]);
             if constexpr (TN > 1) lds_read128<BO + RO>(bf[pp][TN - 1], baddr[s]);
         };
+        if constexpr (X3) {
+            // all fragment reads of the stage up front; slices 2g, 2g + 1 are the 8 k values per lane of one K = 16 MFMA
+            // (the lane -> k assignment only has to be the same for A and B)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) read_s(s, s);
+            static_for<0, NS / 2>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                lds_wait<(NS - 2 * g - 2) * (TM + TN)>();
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[2 * g][i]), "+v"(af[2 * g + 1][i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bf[2 * g][j]), "+v"(bf[2 * g + 1][j]));
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) split3_bf16(af[2 * g][i], af[2 * g + 1][i], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) split3_bf16(bf[2 * g][j], bf[2 * g + 1][j], bh[j], bm[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {      // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            });
+        } else {
         read_s(0, 0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -598,6 +671,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
                     }
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the MFMAs of slice s ahead of the next waits
+        }
         }
         // stage it+1 has landed once at most the NSTG-2 stages issued after it are outstanding (in-order return);
         // on the last stages of the range fewer are in flight: plain wait
@@ -751,6 +825,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
     const unsigned a_addr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((lh * BM + wave * 32 + li) * 4);
     const unsigned b_addr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((lh * BC + li) * 4);
     const unsigned a_addr4 = a_addr + (unsigned)(3 * lh * BM * 4), b_addr4 = b_addr + (unsigned)(3 * lh * BC * 4);  // row 4*lh
+    const unsigned a_addr8 = a_addr + (unsigned)(7 * lh * BM * 4), b_addr8 = b_addr + (unsigned)(7 * lh * BC * 4);  // row 8*lh
     auto stage = [&](auto bufc, int it) {
         constexpr int BUF = decltype(bufc)::value;
         constexpr int AO = BUF * BP * BM * 4, BO = BUF * KT * BP * BC * 4;
@@ -784,6 +859,38 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
                 for (int t = 0; t < KT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ab, cvt_bf16x4(b4[t][0], b4[t][1], b4[t][2], b4[t][3]),
                                                                       acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            return;
+        }
+        if constexpr (MATH == 2) {
+            // fp32-accurate products on the bf16 matrix cores: lane (i, h) holds pixels 8h .. 8h+7 of the stage's 16 for
+            // its channel; the dy fragment is split once, the x fragment of every tap as it arrives (one tap ahead)
+            float a8[8], b8[2][8];
+            static_for<0, 8>([&](auto ec) { lds_read32<AO + decltype(ec)::value * BM * 4>(a8[decltype(ec)::value], a_addr8); });
+            static_for<0, 8>([&](auto ec) { lds_read32<BO + decltype(ec)::value * BC * 4>(b8[0][decltype(ec)::value], b_addr8); });
+            lds_wait<8>();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a8[e]));
+            bf16x8 ah, am, al;
+            split3_bf16(a8, ah, am, al);
+            static_for<0, KT>([&](auto tc_) {
+                constexpr int t = decltype(tc_)::value, pp = t & 1;
+                if constexpr (t + 1 < KT) {
+                    static_for<0, 8>([&](auto ec) {
+                        lds_read32<BO + ((t + 1) * BP + decltype(ec)::value) * BC * 4>(b8[pp ^ 1][decltype(ec)::value], b_addr8);
+                    });
+                    lds_wait<8>();
+                } else {
+                    lds_wait<0>();
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(b8[pp][e]));
+                bf16x8 bh, bm, bl;
+                split3_bf16(b8[pp], bh, bm, bl);
+                mfma_x3(acc[t], ah, am, al, bh, bm, bl);
                 __builtin_amdgcn_sched_barrier(0);
             });
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -951,7 +1058,44 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
-        if constexpr (MATH == 1) {
+        if constexpr (MATH == 2) {
+            // fp32-accurate products on the bf16 matrix cores (see conv_igemmg_kernel, X3): lane (i, h) holds pixels
+            // 8h .. 8h+7 of every 16-pixel group for its channel
+            const unsigned ab = a_thr + (unsigned)buf * (BP * BM * 4) + 7u * lh * BM * 4;
+            const unsigned bb = b_thr + (unsigned)buf * (BP * BN * 4) + 7u * lh * BN * 4;
+            static_for<0, BP / 16>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                float a8[TM][8], b8[TN][8];
+                static_for<0, TM>([&](auto ic) {
+                    static_for<0, 8>([&](auto ec) {
+                        lds_read32<((16 * g + decltype(ec)::value) * BM + decltype(ic)::value * 32) * 4>(a8[decltype(ic)::value][decltype(ec)::value], ab);
+                    });
+                });
+                static_for<0, TN>([&](auto jc) {
+                    static_for<0, 8>([&](auto ec) {
+                        lds_read32<((16 * g + decltype(ec)::value) * BN + decltype(jc)::value * 32) * 4>(b8[decltype(jc)::value][decltype(ec)::value], bb);
+                    });
+                });
+                lds_wait<0>();
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a8[i][e]));
+                    split3_bf16(a8[i], ah[i], am[i], al[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(b8[j][e]));
+                    split3_bf16(b8[j], bh[j], bm[j], bl[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+            });
+        } else if constexpr (MATH == 1) {
 #pragma unroll
             for (int g = 0; g < BP / 8; ++g) {
                 s16x4 ab[TM], bb[TN];
@@ -1517,6 +1661,8 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
             if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
             else          { if (tag) RADET_LAUNCH_IGEMM3(1, 16); else RADET_LAUNCH_IGEMM3(0, 16); }
 #undef RADET_LAUNCH_IGEMM3
+        } else if (tag & 8) {                                          // bf16 x 3 planes (fp32 tensors), K step 32
+            if (tag & 1) RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 9, 32); else RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 8, 32);
         } else if (bk == 32) {
             switch (tag) {
                 case 0: RADET_LAUNCH_IGEMM(conv_igemmg_kernel, 0, 32); break;
@@ -1633,10 +1779,13 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.M = M;
     a.Mp = radet_gather_table_rows(M);
     hipStream_t st = (hipStream_t)stream;
-    const int tag = h16 ? (4 | ((tile_override >> 8) & 1))
-                        : (((tile_override >> 8) & 1) | (((tile_override >> 10) & 1) << 1));   // 0x100 symbol tag, 0x400 bf16 math
+    int tag = h16 ? (4 | ((tile_override >> 8) & 1))
+                  : (((tile_override >> 8) & 1) | (((tile_override >> 10) & 1) << 1));   // 0x100 symbol tag, 0x400 bf16 math
     int bk = ((tile_override >> 9) & 1) ? 32 : 16;
     if (Cin % 32 != 0) bk = 16;
+    // 0x1000000: fp32 tensors, products from three bf16 planes per operand (6 bf16 MFMAs per K = 16 step); K step 32
+    const bool x3 = ((tile_override >> 24) & 1) && !h16 && !((tile_override >> 10) & 1) && Cin % 32 == 0;
+    if (x3) { bk = 32; tag |= 8; }
     int choice = tile_override & 0xFF;
     if (choice <= 0) {
         if (Cout <= 32) choice = 4;
@@ -1693,7 +1842,8 @@ template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
     const bool bp32 = a.bp32 != 0;                                        // 32 pixels per LDS stage (half the barriers)
-    if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
+    if (a.math == 2) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 2>), dim3(tiles), dim3(256), 0, st, a);
+    else if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
     else if (bp32 && BM >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);
 }
@@ -1772,7 +1922,7 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     a.Mp = radet_gather_table_rows(M);
     a.S = S;
     a.dbg = radet_switches().dbg_wgrad;
-    a.math = flags & 1;
+    a.math = (flags & 1) ? 1 : (((flags >> 8) & 1) && !(flags & 2) ? 2 : 0);   // 0x100: fp32 products from 3 bf16 planes
     a.bp32 = (flags >> 7) & 1;
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
@@ -1797,7 +1947,8 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     if (use_wgrad9(M, Cin, Cout, KH, KW) && !(flags & 0x40) && (a.math == 0 || wgrad9_bm(Cout) == 256)) {
         if (wgrad9_bm(Cout) == 256) {
             const int tiles = ((Cout + 255) / 256) * (Cin / 32) * S;
-            if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
+            if (a.math == 2) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 2>), dim3(tiles), dim3(512), 0, st, a);
+            else if (a.math == 1) hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 1>), dim3(tiles), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad9g_kernel<8, 0>), dim3(tiles), dim3(512), 0, st, a);
         } else {
             const int tiles = ((Cout + 127) / 128) * (Cin / 32) * S;

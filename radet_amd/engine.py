@@ -64,6 +64,7 @@ class Engine:
         # (v_mfma_f32_32x32x16_bf16, fp32 accumulate); head outputs, loss, statistics, weight gradients, master
         # weights and optimizer stay fp32
         self.h16 = math == "bf16-storage"
+        self.x3 = math == "fp32" and os.environ.get("RADET_X3", "0") == "1"
         self.math_name = math
         self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
@@ -321,6 +322,7 @@ class Engine:
             if c.geom is not None:
                 c.geom.math = self.math
                 c.geom.h16 = self.h16
+                c.geom.x3 = self.x3
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         self._plan_wgrad_groups()
         if tune:

@@ -106,6 +106,7 @@ class ConvGeom:
         self.math = 0                         # 1: bf16 math mode (operands rounded to bf16, fp32 accumulate)
         self.wgrad_flags = 0                  # tile override of the wgrad launcher (set by autotune_wgrad)
         self.h16 = False                      # bf16 tensors in HBM (tuning runs use the matching kernels)
+        self.x3 = False                       # fp32 tensors, igemm products from three bf16 planes per operand (tile flag X3)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
         self._ft = self._bt = self._classes = None
 
@@ -315,7 +316,7 @@ def autotune(g, need_dgrad=True, reps=None):
         return out
 
     global _TUNE_DIRTY, TUNE_RUNS
-    key = (g._key, g.cin, g.cout, g.math, g.h16)
+    key = (g._key, g.cin, g.cout, g.math, g.h16) + (("x3",) if getattr(g, "x3", False) else ())
     if key not in _TUNE_CACHE:
         _TUNE_DIRTY = True
         TUNE_RUNS += 1
@@ -343,6 +344,7 @@ MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
 
 
 STAGES3 = 0x20000                         # 3 LDS stages in the fp32 implicit-GEMM kernel (forward launches)
+X3 = 0x1000000                            # fp32 tensors, products from three bf16 planes per operand on the bf16 matrix cores
 STREAMK = 0x100000                        # * w (1..7): stream-K schedule with w persistent workgroups per CU (fp32 tags)
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
 
@@ -354,6 +356,8 @@ def _is16(t):
 def _tile(g, tile, default, x=None, y=None):
     """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
     t = (tile or default) | (MATH_BF16 if g.math else 0)
+    if getattr(g, "x3", False) and not g.math and not _is16(x):
+        t |= X3
     if _is16(x):
         t = (t & ~MATH_BF16) | STORE_BF16 | (OUT_F32 if (y is not None and y.dtype == torch.float32) else 0)
     return t
@@ -377,7 +381,7 @@ def autotune_wgrad(g, reps=None):
     dev = torch.device("cuda", torch.cuda.current_device())
     reps = reps or TUNE_REPS
     global _TUNE_DIRTY, TUNE_RUNS
-    key = (g._key, g.cin, g.cout, g.math, g.h16, "w")
+    key = (g._key, g.cin, g.cout, g.math, g.h16, "w") + (("x3",) if getattr(g, "x3", False) else ())
     if key not in _WTUNE_CACHE:
         _TUNE_DIRTY = True
         TUNE_RUNS += 1
@@ -468,7 +472,7 @@ def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
               g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit,
-              (2 if _is16(dy) else (1 if g.math else 0)) | g.wgrad_flags, _stream())
+              (2 if _is16(dy) else (1 if g.math else (0x100 if getattr(g, "x3", False) else 0))) | g.wgrad_flags, _stream())
 
 
 def conv_wgrad_group(jobs, tile=128, math=0):

@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 IMG_H, IMG_W, PER_GPU_BATCH = 480, 640, 4
 TRAIN_FLOP_PER_IMG = 341.1e9      # conv MACs fwd + dgrad + wgrad (frozen stem/layer1), x2
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 
 
 def synth_objects(rng, G, H=IMG_H, W=IMG_W):
@@ -134,7 +135,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--math", choices=("fp32", "bf16", "bf16-storage"), default="fp32",
+    ap.add_argument("--no-mfma-line", action="store_true", help="skip the native-f32-MFMA comparison measurement")
+    ap.add_argument("--math", choices=("fp32", "fp32-mfma", "bf16", "bf16-storage"), default="fp32",
                     help="fp32 = the headline metric (BASELINE configs[1]); bf16 = configs[2] arithmetic: conv operands "
                          "rounded to bf16 into the matrix cores, fp32 accumulate / storage / optimizer (secondary line)")
     args = ap.parse_args()
@@ -203,7 +205,7 @@ def main():
             "metric": "images/sec train-step, r50_ycbv_pbr 640x480 bs=4/GPU",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)",
+            "dtype": {"fp32": "f32", "fp32-mfma": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)",
                       "bf16-storage": "bf16 tensors + operands, f32 accumulate / loss / optimizer"}[args.math], "data": "synthetic",
             "config": {"workload": "r50_ycbv_pbr bs=4 fp32 forward+loss+backward+allreduce+clip+AdamW (BASELINE configs[1])",
                        "global_batch": world * B, "per_gpu_batch": B, "image": f"{IMG_W}x{IMG_H}",
@@ -212,12 +214,19 @@ def main():
                        "step_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
                        "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
-        if args.math != "fp32":
+        x3 = bool(rt.engine.x3)
+        if args.math.startswith("fp32"):
+            out["config"]["arithmetic"] = (
+                "f32 tensors, f32-accurate conv GEMMs: every f32 operand is split exactly into three bf16 planes in "
+                "registers, 6 of the 9 plane products go through v_mfma_f32_32x32x16_bf16 with f32 accumulation "
+                "(measured error vs f64 <= that of v_mfma_f32_32x32x2_f32: tools/x3_probe.py, DESIGN.md 6); "
+                "`--math fp32-mfma` / RADET_X3=0 = native f32 MFMA") if x3 else "f32 tensors, v_mfma_f32_32x32x2_f32"
+        else:
             out["metric"] += " [bf16 math mode: NOT the headline fp32 metric]"
             out["config"]["workload"] = out["config"]["workload"].replace("fp32", "bf16-math").replace("configs[1]", "configs[2] arithmetic")
-        if events and args.math == "fp32":
+        if events and args.math.startswith("fp32"):
             traffic = None          # HBM bytes/launch of the roofline kernel from the committed PMC pass (offline)
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json" if x3 else "roofline_traffic_fp32_mfma.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -234,14 +243,45 @@ def main():
                 # per step: 4 fwd pairs + 3 dgrad pairs (2 GEMMs each) + 2 single dgrads into dL/dP
                 flops = flops * 16.0 / n_per_step
             ach = flops / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "conv_igemmg_kernel<128,64,2,2,TAG=1,BK=32,NSTG=3>: head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
+            # x3: the kernel runs on the bf16 matrix pipe and issues 6 bf16 MACs per algorithmic f32 MAC: priced against
+            # the dense bf16 MFMA peak with the flops it actually issues; the f32-equivalent rate is given next to it
+            issued, peak = (6.0 * ach, BF16_MFMA_PEAK_TFLOPS) if x3 else (ach, FP32_MFMA_PEAK_TFLOPS)
+            out["roofline"] = {"bound": "mfma", "achieved": round(issued, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(issued / peak, 4), "traffic": traffic,
+                               "algorithmic_tflops": round(ach, 2), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "kernel": ("conv_igemmg_kernel<128,128,2,2,TAG=9,BK=32,NSTG=2> (f32 operands split into 3 bf16 planes, "
+                                          "6 v_mfma_f32_32x32x16_bf16 per K=16 step; `achieved` = issued bf16 flop = 6 x algorithmic)"
+                                          if x3 else "conv_igemmg_kernel<128,64,2,2,TAG=1,BK=32,NSTG=3>")
+                                         + ": head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
                                          + ("; forward launches, cls_convs[i] + reg_convs[i] grouped per launch (2 GEMMs), alone on the device"
                                             if hybrid else "; fwd+dgrad launches, cls+reg layers grouped per launch, flop_per_launch = average"
                                             if pair else "; fwd+dgrad launches, cls and reg towers run concurrently on two streams"),
                                "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
                                "flop_per_launch": flops}
+        if world == 1 and x3 and not args.no_mfma_line:
+            # the same step with the native f32 matrix instruction, measured in this run on a fresh replica
+            del rt
+            torch.manual_seed(0)
+            det2 = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device).train()
+            rt2 = det2.runtime(math="fp32-mfma")
+            rt2.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
+                               max_norm=float(cfg.optimizer_config.grad_clip.max_norm))
+            rt2.set_loss_from_head(det2.bbox_head)
+            tg2 = rt2.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+            first2 = None
+            for _ in range(args.warmup):
+                o2 = rt2.train_step(img, tg2)
+                first2 = o2.clone() if first2 is None else first2
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                rt2.train_step(img, tg2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out["fp32_mfma_native"] = {"value": round(B * args.steps / dt2, 2), "unit": "images/sec",
+                                       "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                                       "losses_step1": [float(x) for x in first2.cpu()],
+                                       "note": "same step, `--math fp32-mfma` (v_mfma_f32_32x32x2_f32)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

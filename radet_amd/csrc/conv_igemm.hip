@@ -1656,9 +1656,10 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         if (a.sk_wgs > 0) {                                            // stream-K: tag 0, 2 stages
             if (bk == 32) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 32, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 16, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
-        } else if (stages >= 3 && tag < 2) {
+        } else if (stages >= 3 && (tag < 2 || (tag & 8))) {
 #define RADET_LAUNCH_IGEMM3(TAGV, BKV) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, 3>), dim3(tiles, a.sk), dim3(256), 0, st, a)
-            if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
+            if (tag & 8) { if (tag & 1) RADET_LAUNCH_IGEMM3(9, 32); else RADET_LAUNCH_IGEMM3(8, 32); }
+            else if (bk == 32) { if (tag) RADET_LAUNCH_IGEMM3(1, 32); else RADET_LAUNCH_IGEMM3(0, 32); }
             else          { if (tag) RADET_LAUNCH_IGEMM3(1, 16); else RADET_LAUNCH_IGEMM3(0, 16); }
 #undef RADET_LAUNCH_IGEMM3
         } else if (tag & 8) {                                          // bf16 x 3 planes (fp32 tensors), K step 32

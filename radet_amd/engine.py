@@ -52,11 +52,18 @@ class Engine:
     def __init__(self, params, grads, depth=50, num_classes=21, frozen_stages=1, strides=(8, 16, 32, 64, 128),
                  stacked_convs=4, feat=256, math=None, watch=None):
         """params / grads: dict name -> device tensor (reference state-dict names; grads only for
-        trainable parameters, same shapes).  math: "fp32" (default) or "bf16" = conv operands rounded to bf16 on
-        their way into the matrix cores, fp32 accumulate, fp32 tensors / GroupNorm / loss / optimizer (the mixed
-        precision of BASELINE config 3; env RADET_MATH)."""
+        trainable parameters, same shapes).  math (env RADET_MATH):
+          "fp32" (default)  fp32 tensors and fp32-accurate arithmetic.  The conv GEMMs form their products on the bf16
+                            matrix cores from an exact three-way bf16 split of every fp32 operand (6 of the 9 plane
+                            products, fp32 accumulate: error against fp64 at or below the native fp32 MFMA's, 16x the
+                            MAC rate per plane product); RADET_X3=0 or "fp32-mfma" selects v_mfma_f32_32x32x2_f32;
+          "fp32-mfma"       the same with the native fp32 matrix instruction;
+          "bf16"            conv operands rounded to bf16 on their way into the matrix cores, fp32 accumulate, fp32
+                            tensors / GroupNorm / loss / optimizer;
+          "bf16-storage"    bf16 activations / folded weights / activation gradients in HBM (the mixed precision of
+                            BASELINE config 3)."""
         math = math or os.environ.get("RADET_MATH", "fp32")
-        assert math in ("fp32", "bf16", "bf16-storage"), math
+        assert math in ("fp32", "fp32-mfma", "bf16", "bf16-storage"), math
         self.watch = watch or {}                  # name -> tensors whose version counters guard the folded weights
         self._watched = {}
         self.math = 1 if math == "bf16" else 0
@@ -64,7 +71,7 @@ class Engine:
         # (v_mfma_f32_32x32x16_bf16, fp32 accumulate); head outputs, loss, statistics, weight gradients, master
         # weights and optimizer stay fp32
         self.h16 = math == "bf16-storage"
-        self.x3 = math == "fp32" and os.environ.get("RADET_X3", "0") == "1"
+        self.x3 = math == "fp32" and os.environ.get("RADET_X3", "1") != "0"
         self.math_name = math
         self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
@@ -92,7 +99,12 @@ class Engine:
         take 3 LDS stages.  Backward: 64 x 64 in fp32 (128 x 64 / 128 x 128 measured equal next to the wgrad streams),
         autotuned in the bf16 modes."""
         fp32 = not self.math and not self.h16
-        if bwd:
+        if fp32 and self.x3:
+            # products from bf16 planes: the operand split is VALU work per fragment, so the tile with the most MFMAs per
+            # fragment wins -- 128 x 128 (4 accumulators per wave), 2 LDS stages, forward (178 vs 158 TFLOP/s fp32-equivalent
+            # for 128 x 64) and backward (-0.15 ms per step)
+            t = 0x200 | 1
+        elif bwd:
             t = (self.TOWER_TAG & ~0x100) if fp32 else c.geom.bwd_tile
         else:
             t = (self.TOWER_TAG_FWD & ~0x100) | (K.STAGES3 if fp32 else 0)

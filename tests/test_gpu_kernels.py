@@ -59,12 +59,15 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("math", [0, 1], ids=["fp32", "bf16math"])
+@pytest.mark.parametrize("math", [0, 1, 2], ids=["fp32mfma", "bf16math", "fp32x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(K, case, math):
     """math=1: operands rounded (RNE) to bf16 inside the kernel, fp32 accumulate -- the reference is the exact
-    convolution of the pre-rounded tensors, so the tolerance stays at fp32-accumulation level."""
+    convolution of the pre-rounded tensors, so the tolerance stays at fp32-accumulation level.
+    math=2 (the default fp32 arithmetic): fp32 operands split exactly into three bf16 planes, 6 of the 9 plane products
+    on the bf16 matrix cores -- held to the SAME fp64 reference and tolerance as the native fp32 MFMA path (math=0)."""
     B, Cin, Cout, H, W, k, s, tile = case
+    x3, math = math == 2, math & 1
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -83,6 +86,7 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     lv = K.Levels([(H, W)], B)
     geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
     geom.math = math
+    geom.x3 = x3
     xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
     y = torch.empty(B * Ho * Wo, Cout, device=dev)
     K.conv_fwd(geom, xr, wf, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)
@@ -106,6 +110,41 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     gw_mine = slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     assert rel_err(gw_mine, gw) < 2e-5
     assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
+
+
+def test_fp32_from_bf16_planes_is_as_accurate_as_the_fp32_mfma(K):
+    """The default fp32 arithmetic forms products from three bf16 planes per operand (exact split, 6 of 9 plane products,
+    fp32 accumulate).  On the tower shape its error against an fp64 convolution must not exceed that of the native
+    v_mfma_f32_32x32x2_f32 path (measured: 0.8x) -- forward, dgrad and wgrad; exact under power-of-two scalings like
+    the native path; bit-identical from run to run."""
+    B, C, H, W = 2, 256, 40, 40
+    gen = torch.Generator().manual_seed(9)
+    x4 = torch.randn(B, C, H, W, generator=gen)
+    w4 = torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5
+    dy4 = torch.randn(B, C, H, W, generator=gen)
+    ref_y = F.conv2d(x4.double(), w4.double(), padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(x4.double(), w4.shape, dy4.double(), padding=1)
+    lv = K.Levels([(H, W)], B)
+    xr, dyr, wf = to_rows(x4).cuda(), to_rows(dy4).cuda(), fold_w(w4).cuda()
+    errs = {}
+    for x3 in (False, True):
+        g = K.ConvGeom(lv, C, C, 3, 1, 1)
+        g.x3 = x3
+        y = torch.empty(lv.rows, C, device="cuda")
+        K.conv_fwd(g, xr, wf, None, y, tile=0x202)
+        y2 = torch.empty_like(y)
+        K.conv_fwd(g, xr * 4, wf * 0.5, None, y2, tile=0x202)
+        assert torch.equal(y2, y * 2)
+        slabs = torch.empty(g.nsplit, C, 9, C, device="cuda")
+        K.conv_wgrad(g, dyr, xr, slabs)
+        s2 = torch.empty_like(slabs)
+        K.conv_wgrad(g, dyr, xr, s2)
+        assert torch.equal(slabs, s2)
+        gw = slabs.double().sum(0).reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+        errs[x3] = (rel_err(from_rows(y, B, H, W), ref_y), rel_err(gw, ref_gw.cuda() if gw.is_cuda else ref_gw))
+    for native, planes in zip(errs[False], errs[True]):
+        assert planes <= 1.25 * native + 1e-9, errs
+        assert planes < 1e-5
 
 
 @pytest.mark.parametrize("tile", [64, 128])

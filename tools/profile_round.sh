@@ -23,8 +23,11 @@ pmc() {    # name, counter, program args...
 }
 # 1. headline bench: JSON line, kernel stats, timeline
 python3 $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-db=$(prof bench $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline)
+db=$(prof bench $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-mfma-line)
 python3 $R/tools/trace_timeline.py $db 5 $OUT/bench_timeline.txt > /dev/null
+# 1b. the same step with the native fp32 matrix instruction
+python3 $R/bench.py --math fp32-mfma --no-cpu-baseline > $OUT/bench_fp32_mfma.json 2>> $OUT/bench_default.err
+db=$(prof bench_fp32_mfma $R/bench.py --math fp32-mfma --steps 20 --warmup 3 --no-cpu-baseline)
 # 2. bf16-storage (BASELINE config 3 arithmetic)
 python3 $R/bench.py --math bf16-storage --no-cpu-baseline > $OUT/bench_bf16_storage.json 2>> $OUT/bench_default.err
 db=$(prof bench_bf16_storage $R/bench.py --math bf16-storage --steps 20 --warmup 3 --no-cpu-baseline)
@@ -34,11 +37,14 @@ db=$(prof infer $R/tools/bench_configs.py infer)
 python3 $R/tools/bench_configs.py r101 > $OUT/r101.log 2>&1
 # 4. PMC: HBM traffic of the fp32 and bf16-storage GEMM kernels (separate passes per counter)
 for c in FETCH_SIZE WRITE_SIZE; do
-  pmc fp32 $c $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  pmc fp32 $c $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfma-line
+  pmc fp32m $c $R/bench.py --math fp32-mfma --steps 2 --warmup 1 --no-cpu-baseline
   pmc bf16s $c $R/bench.py --math bf16-storage --steps 2 --warmup 1 --no-cpu-baseline
 done
-python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "conv_igemmg_kernel<128, 64, 2, 2, 1, 32, 3, false>" \
+python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "conv_igemmg_kernel<128, 128, 2, 2, 9, 32, 2, false>" \
     $OUT/pmc_hbm_traffic_fp32.txt $OUT/roofline_traffic.json 103022592 > /dev/null 2>> $OUT/bench_default.err
+python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32m_FETCH_SIZE /tmp/pmc_fp32m_WRITE_SIZE "conv_igemmg_kernel<128, 64, 2, 2, 1, 32, 3, false>" \
+    $OUT/pmc_hbm_traffic_fp32_mfma.txt $OUT/roofline_traffic_fp32_mfma.json 103022592 > /dev/null 2>> $OUT/bench_default.err
 python3 $R/tools/pmc_traffic.py /tmp/pmc_bf16s_FETCH_SIZE /tmp/pmc_bf16s_WRITE_SIZE "conv_igemmg_kernel<128, 64, 2, 2, 5, 32, 2, false>" \
     $OUT/pmc_hbm_traffic_bf16_storage.txt $OUT/roofline_traffic_bf16_storage.json 51511296 > /dev/null 2>> $OUT/bench_default.err
 ls -la $OUT

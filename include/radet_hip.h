@@ -64,7 +64,10 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * a split-K factor; +0x20000 = 3 LDS stages (fp32, launches that run alone on the device); + (w << 20), w = 1..7 =
  * stream-K schedule with w persistent workgroups per CU (fp32, untagged symbol, tiles 2-4): the K stages of the whole
  * launch are shared evenly, tiles cut by a share boundary are reduced inside the launch in K order (deterministic);
- * plain launch when there is less than one K stage per workgroup.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
+ * plain launch when there is less than one K stage per workgroup; +0x1000000 = fp32 tensors, products formed on the
+ * bf16 matrix cores from an exact three-way bf16 split of every fp32 operand (x = hi + mid + lo, 8 significand bits
+ * each; 6 of the 9 plane products -- everything above 2^-24 relative -- through v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate; Cin % 32 == 0, otherwise the native fp32 MFMA is used).  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
  * tickets that must be ZERO before the first launch (every launch leaves them zero); when given, launches with too few
  * tiles for 256 CUs split the K loop (<= 8 ways, or only the left-over tiles of the last round) and the workgroup that
  * arrives last at a tile sums the partial tiles in split order and applies the epilogue -- one launch, deterministic.
@@ -87,7 +90,8 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
                             void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
- * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bits 4-5: tile override of the one-tap
+ * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bit 8 (0x100): fp32 products from three bf16
+ * planes per operand (as tile_override 0x1000000); bits 4-5: tile override of the one-tap
  * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel; bit 7: 32
  * instead of 16 pixels per LDS stage in the one-tap fp32 kernel;
  * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32. */

@@ -409,15 +409,18 @@ __device__ __forceinline__ void split3_bf16(const f32x4& f0, const f32x4& f1, bf
     const float a[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
     split3_bf16(a, hi, mid, lo);
 }
-// acc += A x B with fp32-accurate products from the planes of A and B (6 of the 9 plane products, small terms first)
+// acc += A x B with fp32-accurate products from the planes of A and B (6 of the 9 plane products).  Order: the planes
+// that are ready first -- hi x hi needs one v_perm per pair, the mid / lo planes two / four more operations -- so that the
+// rest of the split runs in the shadow of the first MFMAs (the accumulator is fp32: the order of these six terms moves
+// the result by less than its last bit).
 __device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
                                         const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 }
 
 // Implicit-GEMM kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
@@ -617,14 +620,10 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {      // small terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < TN; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+                // nothing may move across this point: without it the compiler hoists the NEXT waits (incl. the stage's
+                // closing vmcnt(0)) above this group's split + MFMAs and the wave waits for its own prefetch first
+                __builtin_amdgcn_sched_barrier(0);
             });
         } else {
         read_s(0, 0);
@@ -1094,6 +1093,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+                __builtin_amdgcn_sched_barrier(0);
             });
         } else if constexpr (MATH == 1) {
 #pragma unroll

@@ -386,20 +386,20 @@ __device__ __forceinline__ void lds_wait() {
 // become three bf16x8 MFMA operands; v_perm_b32 packs the high halves of two dwords.
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3_bf16(const float (&a)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    unsigned ua[8], ur[8], ul[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        ua[e] = __float_as_uint(a[e]);
-        const float r = a[e] - __uint_as_float(ua[e] & 0xFFFF0000u);
-        ur[e] = __float_as_uint(r);
-        ul[e] = __float_as_uint(r - __uint_as_float(ur[e] & 0xFFFF0000u));
-    }
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
     u32x4_ h, m, l;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        h[q] = __builtin_amdgcn_perm(ua[2 * q + 1], ua[2 * q], 0x07060302u);
-        m[q] = __builtin_amdgcn_perm(ur[2 * q + 1], ur[2 * q], 0x07060302u);
-        l[q] = __builtin_amdgcn_perm(ul[2 * q + 1], ul[2 * q], 0x07060302u);
+    for (int q = 0; q < 4; ++q) {            // pairs: the two residual subtractions are one v_pk_add_f32 each
+        const f32x2_ a2 = {a[2 * q], a[2 * q + 1]};
+        const unsigned ua0 = __float_as_uint(a2.x), ua1 = __float_as_uint(a2.y);
+        const f32x2_ h2 = {__uint_as_float(ua0 & 0xFFFF0000u), __uint_as_float(ua1 & 0xFFFF0000u)};
+        const f32x2_ r2 = a2 - h2;
+        const unsigned ur0 = __float_as_uint(r2.x), ur1 = __float_as_uint(r2.y);
+        const f32x2_ m2 = {__uint_as_float(ur0 & 0xFFFF0000u), __uint_as_float(ur1 & 0xFFFF0000u)};
+        const f32x2_ l2 = r2 - m2;
+        h[q] = __builtin_amdgcn_perm(ua1, ua0, 0x07060302u);
+        m[q] = __builtin_amdgcn_perm(ur1, ur0, 0x07060302u);
+        l[q] = __builtin_amdgcn_perm(__float_as_uint(l2.y), __float_as_uint(l2.x), 0x07060302u);
     }
     hi = __builtin_bit_cast(bf16x8, h);
     mid = __builtin_bit_cast(bf16x8, m);

@@ -1843,7 +1843,8 @@ template <int BM, int BN, int WM, int WN>
 static void launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const int tiles = ((a.Cout + BM - 1) / BM) * ((a.Cin + BN - 1) / BN) * a.KH * a.KW * a.S;
     const bool bp32 = a.bp32 != 0;                                        // 32 pixels per LDS stage (half the barriers)
-    if (a.math == 2) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 2>), dim3(tiles), dim3(256), 0, st, a);
+    if (a.math == 2 && bp32 && BM >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 2, 32>), dim3(tiles), dim3(256), 0, st, a);
+    else if (a.math == 2) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 2>), dim3(tiles), dim3(256), 0, st, a);
     else if (a.math == 1) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 1>), dim3(tiles), dim3(256), 0, st, a);
     else if (bp32 && BM >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0, 32>), dim3(tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgradg_kernel<BM, BN, WM, WN, 0>), dim3(tiles), dim3(256), 0, st, a);

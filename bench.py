@@ -235,7 +235,7 @@ def main():
             # pair mode: most tower launches are grouped (cls + reg layer in one launch = 2x the flops)
             flops = rt.engine.tower_gemm_flops()
             pair = rt.engine.tower_mode == "pair"
-            hybrid = rt.engine.tower_mode == "hybrid"
+            hybrid = rt.engine.tower_mode in ("hybrid", "pairbwd")
             if hybrid:
                 flops = flops * 2.0     # every tagged launch = cls_convs[i] + reg_convs[i] grouped, forward only
             if pair:

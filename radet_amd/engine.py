@@ -72,6 +72,8 @@ class Engine:
         # weights and optimizer stay fp32
         self.h16 = math == "bf16-storage"
         self.x3 = math == "fp32" and os.environ.get("RADET_X3", "1") != "0"
+        if self.x3 and "RADET_TOWER_MODE" not in os.environ:
+            self.tower_mode = "pairbwd"
         self.math_name = math
         self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
@@ -664,6 +666,9 @@ class Engine:
     # "streams": cls / reg towers on two HIP streams; "pair": cls+reg layer = one grouped launch (forward and backward);
     # "hybrid" (default): grouped forward launches (they run alone on the device -> clean roofline measurement),
     # two-stream backward (dgrad / wgrad / GroupNorm of the two towers overlap).  bench: 229.5 / 227.7 / 232 img/s
+    # "pairbwd" (default with the bf16-plane fp32 arithmetic): grouped launches forward AND for the tower dgrads (their
+    # 128 x 128 tiles fill the chip better two GEMMs at a time: -1 % step), wgrads on the side streams, only the forward
+    # launches tagged; with the native fp32 MFMA the two-stream backward of "hybrid" is the faster one (14.27 vs 14.34 ms)
     tower_mode = os.environ.get("RADET_TOWER_MODE", "hybrid")
 
     def _tower_pair_fwd(self, i, xc, xr):
@@ -683,7 +688,7 @@ class Engine:
     def head_forward(self, P):
         b = self.buf
         n = self.stacked_convs
-        if self.tower_mode in ("pair", "hybrid"):
+        if self.tower_mode in ("pair", "hybrid", "pairbwd"):
             xc = xr = P
             for i in range(n):
                 xc, xr = self._tower_pair_fwd(i, xc, xr)
@@ -809,8 +814,10 @@ class Engine:
         b = self.buf
         n = self.stacked_convs
         dP = b["dP"]
-        if self.tower_mode == "pair":
+        if self.tower_mode in ("pair", "pairbwd"):
             p, g = self.p, self.g
+            tagged = self.tower_mode == "pair"        # "pairbwd": only the forward launches are tagged / timed (like hybrid)
+            launch = self._tower_launch if tagged else (lambda fn, *a, **k: fn(*a, **k))
             self._tower_bwd_head_async("cls")
             self._tower_bwd_head_async("reg")
             wg_done = {}
@@ -827,11 +834,11 @@ class Engine:
                 cc, cr = self.cls_tower[i], self.reg_tower[i]
                 dzc, dzr = b[f"cls.dz{i & 1}"], b[f"reg.dz{i & 1}"]
                 if i > 0:
-                    self._tower_launch(K.conv_dgrad_pair, cc.geom, dict(x=dzc, w=cc.wft, y=b["cls.dy"]),
-                                       dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self._ttile(cc, bwd=True))
+                    launch(K.conv_dgrad_pair, cc.geom, dict(x=dzc, w=cc.wft, y=b["cls.dy"]),
+                                       dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self._ttile(cc, bwd=True, tag=tagged))
                 else:   # both write dL/dP: the second accumulates onto the first
-                    self._tower_launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self._ttile(cc, bwd=True))
-                    self._tower_launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self._ttile(cr, bwd=True))
+                    launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self._ttile(cc, bwd=True, tag=tagged))
+                    launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self._ttile(cr, bwd=True, tag=tagged))
         elif self.use_streams:
             side = self._side()
             self._fork(side)

@@ -102,6 +102,42 @@ def test_train_step_is_deterministic():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
+    """The default fp32 arithmetic (products from three bf16 planes on the bf16 matrix cores) and the native fp32 MFMA
+    run the same forward + loss + backward on the headline batch.  Yardstick: the native arithmetic against ITSELF with
+    other tiles / split-K factors (launcher heuristics instead of the tune file), i.e. another fp32 summation order --
+    ReLU masks and GroupNorm amplify last-bit differences through ~60 layers.  The plane arithmetic must sit within 3x of
+    that distance (measured: about the same) and far below the bf16 math mode; the loss triple agrees to 1e-6."""
+    import os
+    import bench
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img, boxes, labels, p2g, pw = bench.make_batch(0, 4, torch.device("cuda"))
+    out = {}
+    for tag, math, tune in (("planes", "fp32", "1"), ("mfma", "fp32-mfma", "1"), ("mfma-heur", "fp32-mfma", "0"), ("bf16", "bf16", "1")):
+        monkeypatch.setenv("RADET_AUTOTUNE", tune)
+        cfg = Config.fromfile(os.path.join(root, "configs", "bop", "r50_ycbv_pbr.py"))
+        cfg.model["pretrained"] = None
+        torch.manual_seed(0)
+        det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        rt = det.runtime(math=math)
+        assert rt.engine.x3 == (math == "fp32")
+        tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+        rt.forward(img)
+        losses = rt.loss(tg).clone()
+        rt.backward()
+        torch.cuda.synchronize()
+        out[tag] = (losses.double().cpu(), rt.flat.grads.double().cpu().clone())
+        del det, rt
+    ref_l, ref_g = out["mfma"]
+    dist = {k: float((g - ref_g).norm() / ref_g.norm()) for k, (_, g) in out.items() if k != "mfma"}
+    print("gradient distance to the tuned native-fp32 run:", dist)
+    assert ((out["planes"][0] - ref_l).abs() / ref_l.abs()).max() < 1e-6, (out["planes"][0], ref_l)
+    assert dist["planes"] <= 3 * dist["mfma-heur"] + 1e-6, dist
+    assert dist["bf16"] > 20 * dist["planes"], dist
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE configs 3 / 5 at full size
 def _synth_batch(B, H, W, seed):
     """images + 1..8 boxes with elliptical visible masks per image + GPU-assigned points, like bench.make_batch"""

@@ -1962,9 +1962,16 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     wgrad_tile(M, Cout, Cin, KH * KW, &bm, &bn);
     if (bm != 32 && ((flags >> 4) & 3) == 1) bm = bn = 128;      // autotuned tile (radet_amd/kernels.py)
     if (bm != 32 && ((flags >> 4) & 3) == 2) bm = bn = 64;
+    // 128 (output channels) x 64 (input channels): two accumulators per wave -- three operand splits per two MFMA blocks
+    // instead of two per block; offered to the tuner with the bf16-plane arithmetic, where the 64 x 64 tile is VALU-bound
+    if (bm != 32 && ((flags >> 4) & 3) == 3 && a.math == 2) { bm = 128; bn = 64; }
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
     else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
-    else launch_wgrad<128, 128, 2, 2>(a, st);
+    else if (bn == 64) {
+        const int tiles = ((a.Cout + 127) / 128) * ((a.Cin + 63) / 64) * a.KH * a.KW * a.S;
+        if (a.bp32) hipLaunchKernelGGL((conv_wgradg_kernel<128, 64, 2, 2, 2, 32>), dim3(tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgradg_kernel<128, 64, 2, 2, 2>), dim3(tiles), dim3(256), 0, st, a);
+    } else launch_wgrad<128, 128, 2, 2>(a, st);
     return radet_check_launch();
 }
 

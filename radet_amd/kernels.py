@@ -389,8 +389,11 @@ def autotune_wgrad(g, reps=None):
         s0 = g.nsplit
         cands = [(0, s0)]
         if g.cout > 64 and g.cin > 64:
-            for tflag, t in ((1 << 4, 128), (2 << 4, 64)):
-                tiles = -(-g.cout // t) * -(-g.cin // t) * kk
+            shapes = [(1 << 4, 128, 128), (2 << 4, 64, 64)]
+            if getattr(g, "x3", False):
+                shapes.append((3 << 4, 128, 64))          # plane arithmetic only: fewer operand splits per MFMA block
+            for tflag, t, tn in shapes:
+                tiles = -(-g.cout // t) * -(-g.cin // tn) * kk
                 for blocks in (256, 512, 768, 1024):
                     S = max(1, min(64, round(blocks / tiles), (M + 127) // 128))
                     cands.append((tflag | 0x40, S))

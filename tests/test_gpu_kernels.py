@@ -142,6 +142,12 @@ def test_fp32_from_bf16_planes_is_as_accurate_as_the_fp32_mfma(K):
         assert torch.equal(slabs, s2)
         gw = slabs.double().sum(0).reshape(C, 3, 3, C).permute(0, 3, 1, 2)
         errs[x3] = (rel_err(from_rows(y, B, H, W), ref_y), rel_err(gw, ref_gw.cuda() if gw.is_cuda else ref_gw))
+        if x3:      # every one-tap tile of the plane arithmetic, 16- and 32-pixel stages (0x40: not the all-taps kernel)
+            for fl in (0x40 | (1 << 4), 0x40 | (2 << 4), 0x40 | (3 << 4), 0xC0 | (2 << 4), 0xC0 | (3 << 4)):
+                g.wgrad_flags, g.nsplit = fl, 6
+                s3 = torch.empty(6, C, 9, C, device="cuda")
+                K.conv_wgrad(g, dyr, xr, s3)
+                assert rel_err(s3.double().sum(0).reshape(C, 3, 3, C).permute(0, 3, 1, 2), ref_gw) < 1e-5, hex(fl)
     for native, planes in zip(errs[False], errs[True]):
         assert planes <= 1.25 * native + 1e-9, errs
         assert planes < 1e-5

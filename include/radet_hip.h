@@ -88,6 +88,16 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
                             const int* gather_table, const int* out_rows, const int* tap_ids_host, int ntaps, int kt_w,
                             int M, int Cin, int Cout, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
                             void* stream);
+/* Class variant: ALL stride-parity classes of a strided dgrad in ONE launch (replaces one radet_conv2d_igemm_taps
+ * launch per class; reference: the dgrad torch autograd runs for the stride-2 convs of mmdet ResNet / FPN extra levels).
+ * GEMM rows = output rows sorted by class, each class padded to a multiple of 128 rows (out_rows = -1 and table = -1 on
+ * the pad rows); class c owns rows [cls_start[c], cls_start[c+1]) (cls_start[0] = 0, the last class ends at M, M % 128
+ * == 0), runs cls_ntaps[c] <= 4 taps, its tap t reads weight tap tap_ids_host[4c + t]; gather_table is
+ * [max ntaps][M].  Order the classes by taps, most first (the grid keeps that order). */
+int radet_conv2d_igemm_classes(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                               const int* gather_table, const int* out_rows, const int* tap_ids_host, const int* cls_ntaps,
+                               const int* cls_start, int ncls, int kt_w, int M, int Cin, int Cout, int tile_override,
+                               float* splitk_ws, size_t splitk_ws_floats, void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bit 8 (0x100): fp32 products from three bf16

@@ -51,6 +51,10 @@ struct ConvArgs {
     // stream-K: sk_wgs persistent workgroups share the T * nK K-stages of the launch evenly (workgroup v owns stages
     // [v * sk_base + min(v, sk_rem), ...) across tile boundaries); tiles cut by a boundary are reduced in the launch
     int sk_wgs, sk_base, sk_rem;
+    // class launch (all parity classes of a strided dgrad in one grid): GEMM rows [cls_b[c-1], cls_b[c]) belong to class
+    // c (boundaries are multiples of 128, pad rows have out_rows = -1), class c runs (cls_nt >> 4c) & 15 taps and its
+    // tap t reads weight tap tap_ids[4c + t]; rowtab is [max taps][Mp].  cls_nt = 0: one tap list for all rows.
+    int cls_nt, cls_b[3];
 };
 
 __device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
@@ -151,7 +155,7 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
                                                int li, int lh) {
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     const bool has_add = P.addend != nullptr, has_mask = P.mask != nullptr, has_rows = a.out_rows != nullptr;   // uniform
-    const bool interior = m0 + BM <= a.M && n0 + BN <= a.Cout;                                                     // uniform
+    const bool interior = !has_rows && m0 + BM <= a.M && n0 + BN <= a.Cout;                                        // uniform
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         size_t obase[16];
@@ -161,8 +165,9 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                rvalid[r] = row < a.M;
-                orow[r] = a.out_rows[rvalid[r] ? row : 0];
+                orow[r] = a.out_rows[row < a.M ? row : 0];
+                rvalid[r] = row < a.M && orow[r] >= 0;             // (-1: pad row between the classes of a class launch)
+                if (orow[r] < 0) orow[r] = 0;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) obase[r] = (size_t)orow[r] * a.Cout;
@@ -473,7 +478,9 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
   do {
     const bool tail = !streamk && (int)blockIdx.x >= a.n_full;
     const int tail_slot = tail ? (int)blockIdx.x - a.n_full : 0;
-    int id = streamk ? cur / (KT * cpt) : (tail ? a.n_full + tail_slot / a.sk_tail : xcd_remap(blockIdx.x, a.n_full));
+    // (class launches keep the grid order: classes are sorted by taps, heaviest first, and spread over the XCDs)
+    int id = streamk ? cur / (KT * cpt)
+                     : (tail ? a.n_full + tail_slot / a.sk_tail : (a.cls_nt ? (int)blockIdx.x : xcd_remap(blockIdx.x, a.n_full)));
     const int sk_tile = id;
     const int grp = id >= tilesG ? 1 : 0;
     id -= grp * tilesG;
@@ -490,10 +497,16 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     const int zsplit = pin_sgpr(tail ? tail_slot % a.sk_tail : (int)blockIdx.y);
     const int m0 = (id / tilesN) * BM;
     const int n0 = (id % tilesN) * BN;
+    int KTt = KT, tbase = 0;                                 // taps of this tile, its slice of tap_ids
+    if (!streamk && a.cls_nt) {
+        const int cls = (m0 >= a.cls_b[0] ? 1 : 0) + (m0 >= a.cls_b[1] ? 1 : 0) + (m0 >= a.cls_b[2] ? 1 : 0);
+        KTt = (a.cls_nt >> (4 * cls)) & 15;
+        tbase = 4 * cls;
+    }
 
     const int per = tail ? a.it_per_tail : a.it_per_split;
     const int it0 = streamk ? cur - sk_tile * KT * cpt : (tail ? tail_slot % a.sk_tail : (int)blockIdx.y) * per;
-    int nK = KT * cpt - it0;
+    int nK = KTt * cpt - it0;
     if (streamk) {
         if (nK > end_it - cur) nK = end_it - cur;
     } else if (nK > per) {
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
                     ? P.w + (size_t)n * a.KTw * a.Cin + 4 * ((lane % F4) ^ ((r / RPB) % F4)) : nullptr;
     }
     constexpr bool A_FULL = A_INSTR % 4 == 0, B_FULL = B_INSTR % 4 == 0;   // every wave owns A_PW / B_PW loads
-    int wtap = nK > 0 ? a.tap_ids[ld_tap] : 0;
+    int wtap = nK > 0 ? a.tap_ids[tbase + ld_tap] : 0;
     auto issue_stage = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < A_PW; ++k) {
@@ -542,8 +555,8 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
         if (ld_c0 == a.Cin) {
             ld_c0 = 0;
             ++ld_tap;
-            if (ld_tap < KT) {
-                wtap = a.tap_ids[ld_tap];
+            if (ld_tap < KTt) {
+                wtap = a.tap_ids[tbase + ld_tap];
 #pragma unroll
                 for (int k = 0; k < A_PW; ++k)
                     if (A_FULL || wave + 4 * k < A_INSTR)
@@ -1638,7 +1651,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
     const int nKs = a.KH * a.KW * (a.Cin / bk);
     const int rem = T % 256;
     // only for long K loops: on short kernels the extra epilogue launch costs more than the idle tail
-    if (a.sk_wgs == 0 && a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 512 &&
+    if (a.sk_wgs == 0 && a.cls_nt == 0 && a.sk == 1 && a.partial != nullptr && T > 256 && rem > 0 && rem <= 160 && nKs * bk >= 512 &&
         !radet_switches().no_tail_split) {
         int skt = 256 / rem;
         if (skt > 8) skt = 8;
@@ -1720,7 +1733,8 @@ extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int s
 static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
-                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second = nullptr);
+                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second = nullptr,
+                      const int* cls = nullptr);
 
 // Two independent convolutions of identical geometry (the cls- and reg-tower layers of the shared head) as ONE
 // launch: twice the tiles per launch halves the wave-quantisation loss on 256 CUs and the launch count.
@@ -1755,10 +1769,38 @@ extern "C" int radet_conv2d_igemm_taps(const float* x, const float* w, const flo
                       splitk_ws_floats, out_rows, tap_ids_host, kt_w, stream);
 }
 
+// Class variant: ALL parity classes of a strided dgrad in one grid.  GEMM rows are the output rows sorted by class, each
+// class padded to a multiple of 128 rows (out_rows = -1 on the pad rows, table entries -1); class c owns rows
+// [cls_start[c], cls_start[c + 1]) (cls_start[0] = 0, the last class ends at M), runs cls_ntaps[c] <= 4 taps and its tap
+// t reads weight tap tap_ids_host[4 c + t]; table is [max ntaps][M].  Order the classes by taps, most first.
+extern "C" int radet_conv2d_igemm_classes(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                                          const int* gather_table, const int* out_rows, const int* tap_ids_host,
+                                          const int* cls_ntaps, const int* cls_start, int ncls, int kt_w, int M, int Cin,
+                                          int Cout, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
+                                          void* stream) {
+    if (ncls < 1 || ncls > 4 || M % 128 != 0 || out_rows == nullptr || tap_ids_host == nullptr || cls_ntaps == nullptr ||
+        cls_start == nullptr || cls_start[0] != 0)
+        return RADET_ERR_ARG;
+    int cls[9] = {ncls, 0, 0, 0, 0, 0, 0, 0, 0}, tids[16] = {0}, kmax = 0;
+    for (int c = 0; c < ncls; ++c) {
+        if (cls_ntaps[c] < 1 || cls_ntaps[c] > 4 || cls_start[c] % 128 != 0 || cls_start[c] >= M ||
+            (c > 0 && cls_start[c] <= cls_start[c - 1]))
+            return RADET_ERR_ARG;
+        cls[1 + c] = cls_ntaps[c]; cls[5 + c] = cls_start[c];
+        if (cls_ntaps[c] > kmax) kmax = cls_ntaps[c];
+        for (int t = 0; t < cls_ntaps[c]; ++t) {
+            if (tap_ids_host[4 * c + t] < 0 || tap_ids_host[4 * c + t] >= kt_w) return RADET_ERR_ARG;
+            tids[4 * c + t] = tap_ids_host[4 * c + t];
+        }
+    }
+    return igemm_impl(x, w, nullptr, addend, mask, y, gather_table, M, Cin, Cout, kmax, 1, 0, tile_override, splitk_ws,
+                      splitk_ws_floats, out_rows, tids, kt_w, stream, nullptr, cls);
+}
+
 static int igemm_impl(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
                       float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
-                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second) {
+                      const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second, const int* cls) {
     const int h16 = (tile_override >> 11) & 1;                 // 0x800: bf16 storage, 0x10000: fp32 output from bf16 inputs
     if (h16) {
         if (Cin % 32 != 0) return RADET_ERR_ARG;               // 16 channel pairs per K step at least
@@ -1769,6 +1811,14 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.io = h16 ? (((tile_override >> 16) & 1) ? 2 : 1) : 0;
     a.out_rows = out_rows;
     for (int t = 0; t < 16; ++t) a.tap_ids[t] = tap_ids ? (t < KH * KW ? tap_ids[t] : 0) : t;
+    a.cls_nt = 0; a.cls_b[0] = a.cls_b[1] = a.cls_b[2] = 0x7fffffff;
+    if (cls != nullptr) {                                      // cls = {ncls, ntaps[4], start[4]}: class launch
+        for (int t = 0; t < 16; ++t) a.tap_ids[t] = tap_ids[t];
+        for (int c = 0; c < cls[0]; ++c) {
+            a.cls_nt |= cls[1 + c] << (4 * c);
+            if (c > 0) a.cls_b[c - 1] = cls[5 + c];
+        }
+    }
     a.KTw = kt_w > 0 ? kt_w : KH * KW;
     a.p[0].x = x; a.p[0].w = w; a.p[0].bias = bias; a.p[0].addend = addend; a.p[0].mask = mask; a.p[0].y = y;
     a.p[1] = a.p[0];
@@ -1804,7 +1854,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     const int nK = KH * KW * (Cin / bk);
     int sk = 1;
     const int stages3 = ((tile_override >> 17) & 1) ? 3 : 2;   // 0x20000: 3 LDS stages (launches that run alone)
-    const int skw = (tile_override >> 20) & 7;               // 0x100000 * w: stream-K, w workgroups per CU
+    const int skw = cls ? 0 : (tile_override >> 20) & 7;     // 0x100000 * w: stream-K, w workgroups per CU
     const int sk_force = skw ? 1 : (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;
     if (splitk_ws != nullptr && a.groups == 1 && !radet_switches().no_splitk) {

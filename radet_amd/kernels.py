@@ -109,6 +109,7 @@ class ConvGeom:
         self.x3 = False                       # fp32 tensors, igemm products from three bf16 planes per operand (tile flag X3)
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
         self._ft = self._bt = self._classes = None
+        self._cgroup = 0                                   # 0 = not looked at yet, None = no class launch for this geometry
 
     # The geometry keeps its tables alive: _TABLE_CACHE only dedupes them across geometries and may drop its own
     # reference at any time -- a table freed while a launch on a side stream still reads it would be recycled by the
@@ -199,6 +200,46 @@ def _strided_dgrad_classes(g):
         torch.cuda.current_stream().synchronize()      # the uploads above have landed before another stream can use them
     _TABLE_CACHE[ck] = g._classes = out
     return out
+
+
+STRIDED_DGRAD_GROUP = os.environ.get("RADET_DGRAD_CLASS_GROUP", "1") != "0"
+
+
+def _strided_dgrad_group(g):
+    """All tap-carrying parity classes of a strided dgrad as ONE launch (radet_conv2d_igemm_classes): rows sorted by
+    class (most taps first), each class padded to 128 rows.  None when the geometry has a single class (1x1 / 2) or a
+    class with more than 4 taps.  Returns dict(table [kmax][M], out_rows [M], tap_ids[16], ntaps[4], start[4], ncls, M)."""
+    import numpy as np
+    if g._cgroup is None or g._cgroup != 0:
+        return g._cgroup
+    cls = sorted((c for c in _strided_dgrad_classes(g) if not c["zero"]), key=lambda c: -c["ntaps"])
+    grp = None
+    if STRIDED_DGRAD_GROUP and 2 <= len(cls) <= 4 and all(c["ntaps"] <= 4 for c in cls):
+        ck = (torch.cuda.current_device(), "clsgrp") + g._key
+        grp = _TABLE_CACHE.get(ck)
+        if grp is None:
+            kmax = max(c["ntaps"] for c in cls)
+            starts, m = [], 0
+            for c in cls:
+                starts.append(m)
+                m += -(-c["rows"] // 128) * 128
+            tab = np.full((kmax, m), -1, np.int32)
+            orow = np.full(m, -1, np.int32)
+            tids = [0] * 16
+            for i, (c, s0) in enumerate(zip(cls, starts)):
+                t = c["table"].cpu().numpy()
+                tab[:c["ntaps"], s0:s0 + c["rows"]] = t[:, :c["rows"]]
+                orow[s0:s0 + c["rows"]] = c["out_rows"].cpu().numpy()
+                tids[4 * i:4 * i + c["ntaps"]] = list(c["tap_ids"])
+            pad4 = lambda v: list(v) + [0] * (4 - len(v))  # noqa: E731
+            grp = dict(table=torch.from_numpy(tab).cuda(), out_rows=torch.from_numpy(orow).cuda(),
+                       tap_ids=(C.c_int * 16)(*tids), ntaps=(C.c_int * 4)(*pad4([c["ntaps"] for c in cls])),
+                       start=(C.c_int * 4)(*pad4(starts)), ncls=len(cls), M=m)
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().synchronize()
+            _TABLE_CACHE[ck] = grp
+    g._cgroup = grp
+    return grp
 
 
 _TUNE_CACHE = _LRU(8192)
@@ -457,7 +498,14 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
     tile = _tile(g, tile, g.bwd_tile, dy, dx)
     ws = splitk_ws() if splitk else None
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
+        grp = _strided_dgrad_group(g)
+        if grp is not None:
+            _lib.call("radet_conv2d_igemm_classes", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx),
+                      _ptr(grp["table"]), _ptr(grp["out_rows"]), grp["tap_ids"], grp["ntaps"], grp["start"], grp["ncls"],
+                      g.k * g.k, grp["M"], kc, g.cin, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
         for c in _strided_dgrad_classes(g):
+            if grp is not None and not c["zero"]:
+                continue
             if c["zero"] and skip_zero_rows:
                 assert addend is not None and addend.data_ptr() == dx.data_ptr()
                 continue

@@ -112,6 +112,51 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
 
 
+@pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "fp32x3"])
+@pytest.mark.parametrize("shape", [
+    # B, Cin, Cout, H, W, tile
+    (2, 128, 128, 18, 22, 0),
+    (1, 256, 256, 13, 7, 0x5203),       # odd sizes (classes of unequal size, ragged last tiles), forced split-K 5
+    (4, 256, 256, 15, 20, 0x3203),      # the FPN P6 shape
+    (2, 64, 128, 31, 33, 2),
+    (3, 512, 512, 9, 11, 0x201),        # 128 x 128 tiles over classes shorter than one tile
+])
+def test_strided_dgrad_class_launch(K, shape, x3, monkeypatch):
+    """All four parity classes of a 3x3 / 2 dgrad in one launch (radet_conv2d_igemm_classes) against the fp64 dgrad, with
+    addend + mask, and against the one-launch-per-class path it replaces."""
+    B, Cin, Cout, H, W, tile = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    add = torch.randn(B, Cin, H, W, generator=g)
+    msk = torch.randn(B, Cin, H, W, generator=g)
+    gx = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double(), stride=2, padding=1)
+    ref = (gx + add.double()) * (msk > 0)
+    geom = K.ConvGeom(K.Levels([(H, W)], B), Cin, Cout, 3, 2, 1)
+    geom.x3 = x3
+    assert K._strided_dgrad_group(geom) is not None and K._strided_dgrad_group(geom)["ncls"] == 4
+    dev = "cuda"
+    dyr = to_rows(dy).to(dev)
+    wft = w.permute(1, 2, 3, 0).reshape(Cin, 9, Cout).contiguous().to(dev)
+    addr, mr = to_rows(add).to(dev), to_rows(msk).to(dev)
+    dx = torch.full((B * H * W, Cin), float("nan"), device=dev)
+    K.conv_dgrad(geom, dyr, wft, dx, addend=addr, mask=mr, tile=tile)
+    assert rel_err(from_rows(dx, B, H, W), ref) < 1e-5
+    geom2 = K.ConvGeom(K.Levels([(H, W)], B), Cin, Cout, 3, 2, 1)
+    geom2.x3 = x3
+    monkeypatch.setattr(K, "STRIDED_DGRAD_GROUP", False)
+    assert K._strided_dgrad_group(geom2) is None
+    dx2 = torch.full((B * H * W, Cin), float("nan"), device=dev)
+    K.conv_dgrad(geom2, dyr, wft, dx2, addend=addr, mask=mr, tile=tile)
+    assert rel_err(dx2, dx.double()) < 2e-6              # (split-K factors may differ between the two paths)
+    # in place on a pre-masked dx (the engine's residual accumulation)
+    monkeypatch.setattr(K, "STRIDED_DGRAD_GROUP", True)
+    dx3 = (addr * (mr > 0)).contiguous()
+    K.conv_dgrad(geom, dyr, wft, dx3, addend=dx3, mask=mr, tile=tile, skip_zero_rows=True)
+    assert rel_err(from_rows(dx3, B, H, W), ref) < 1e-5
+
+
 def test_fp32_from_bf16_planes_is_as_accurate_as_the_fp32_mfma(K):
     """The default fp32 arithmetic forms products from three bf16 planes per operand (exact split, 6 of 9 plane products,
     fp32 accumulate).  On the tower shape its error against an fp64 convolution must not exceed that of the native

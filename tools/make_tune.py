@@ -16,7 +16,12 @@ from radet_amd.models import build_detector
 from radet_amd.utils import Config
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if os.path.exists(K._PACKAGED_TUNE) and "--keep" not in sys.argv:
+if "--retune-strided" in sys.argv:
+    # keep the shipped choices except those of the 3x3 / 2 convs (their dgrad changed to one class launch): timed again
+    K.load_tune_cache()
+    for key in [k for k in K._TUNE_CACHE if k[0][3] == 3 and k[0][4] > 1]:
+        del K._TUNE_CACHE[key]
+elif os.path.exists(K._PACKAGED_TUNE) and "--keep" not in sys.argv:
     K._TUNE_LOADED = True                                       # ignore the shipped file too
 out = [a for a in sys.argv[1:] if not a.startswith("--")][0]
 JOBS = [  # depth, math, (B, H, W) list

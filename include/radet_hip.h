@@ -98,6 +98,14 @@ int radet_conv2d_igemm_classes(const float* x, const float* w, const float* adde
                                const int* gather_table, const int* out_rows, const int* tap_ids_host, const int* cls_ntaps,
                                const int* cls_start, int ncls, int kt_w, int M, int Cin, int Cout, int tile_override,
                                float* splitk_ws, size_t splitk_ws_floats, void* stream);
+/* Predictor head convs (3x3, stride 1, pad 1, <= 32 output channels; reference: atss_cls / atss_reg / atss_iou of
+ * radet/models/dense_heads/radet_head.py:_init_layers, applied per level in forward_single) as a direct convolution from an
+ * LDS patch: x [rows][Cin] fp32 over all pyramid levels (rows of (level, image) contiguous, row-major H x W), w OHWI
+ * [c][9][Cin], y [rows][c].  tiles_dev: ntiles x {base_row, H, W, (tile_y << 16) | tile_x} (int32), one 8 x 16 block of
+ * output pixels each.  A second conv on the same input may share the launch (w1 / bias1 / y1 / c1; c0 + c1 <= 32).
+ * Arithmetic: fp32 products from three bf16 planes per operand (as tile_override 0x1000000).  Cin % 16 == 0. */
+int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntiles, const float* w0, const float* bias0,
+                        float* y0, int c0, const float* w1, const float* bias1, float* y1, int c1, void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bit 8 (0x100): fp32 products from three bf16

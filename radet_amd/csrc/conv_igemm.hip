@@ -714,6 +714,170 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
   } while (SK && cur < end_it);
 }
 
+// ------------------------------------------------------------------------------------------ predictor 3x3 from an LDS patch
+// The predictor convs of the head (3x3, 256 -> 21 / 4 / 1 channels over all B * 6400 pyramid positions) are bound by the
+// delivery of their A operand in the implicit-GEMM kernel: every pixel row is fetched 9 times (once per tap) into LDS for
+// a 32-column tile.  Here a workgroup owns an 8 x 16 block of output pixels of one (level, image) and walks the channels
+// in chunks of 16: the 10 x 18 input patch of the chunk (zero outside the image) and the [9][32][16] weight slice go
+// global -> LDS once (LDS-DMA, XOR-swizzled 16-byte slots as in the implicit-GEMM kernel), and the nine taps are nine
+// fragment reads at shifted patch positions: 1.4 fetches per pixel row instead of 9.  Arithmetic: fp32 operands split
+// into three bf16 planes in registers, 6 plane products per K = 16 on the bf16 matrix cores (as TAG bit 3 above).
+// Up to two convs of the same input share a launch (reg + iou: output columns [0, c0) -> y0, [c0, c0 + c1) -> y1).
+struct PredTile { int base_row, H, W, yx; };      // rows of this (level, image) start at base_row; yx = (tile y << 16) | tile x
+struct PredArgs {
+    const float* x;
+    const float* w[2];        // OHWI [c][9][Cin]
+    const float* bias[2];
+    float* y[2];              // [rows][c]
+    int c[2];
+    const PredTile* tiles;
+    int Cin;
+};
+
+__global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
+    constexpr int TH = 8, TW = 16, PW = TW + 2, PP = (TH + 2) * PW;          // 180 patch pixels
+    constexpr int PROWS = 192, WROWS = 9 * 32;                                // 64-byte rows: patch (padded), weights
+    constexpr int A_BYTES = PROWS * 64, BUF_BYTES = (PROWS + WROWS) * 64;     // 12 + 18 KiB per chunk buffer
+    constexpr int N_INSTR = (PROWS + WROWS) / 16;                             // 30 wave loads of 1 KiB per chunk
+    constexpr int PWL = (N_INSTR + 3) / 4;                                    // <= 8 per wave
+    // two chunk buffers (a third, loads two chunks ahead, measured the same at B = 4 and costs the second workgroup per CU)
+    __shared__ __attribute__((aligned(64))) float S[2][BUF_BYTES / 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const PredTile T = a.tiles[blockIdx.x];
+    const int y0 = (T.yx >> 16) * TH, x0 = (T.yx & 0xFFFF) * TW;
+    const int c0 = a.c[0], ctot = a.c[0] + a.c[1];
+
+    // writer side: load k of this wave is wave load i = wave + 4k; it fills rows 16 i + lane / 4, slot lane % 4
+    const float* src[PWL];
+    int inc[PWL];
+    const int kq = (lane & 3) ^ ((lane >> 4) & 3);                            // the k-quad this lane's slot holds
+#pragma unroll
+    for (int k = 0; k < PWL; ++k) {
+        const int i = wave + 4 * k;
+        const int r = i * 16 + (lane >> 2);
+        src[k] = radet_zero_page + lane * 4;
+        inc[k] = 0;
+        if (i < PROWS / 16) {
+            const int py = r / PW, px = r - py * PW;
+            const int iy = y0 + py - 1, ix = x0 + px - 1;
+            if (r < PP && iy >= 0 && iy < T.H && ix >= 0 && ix < T.W) {
+                src[k] = a.x + (size_t)(T.base_row + iy * T.W + ix) * a.Cin + 4 * kq;
+                inc[k] = 16;
+            }
+        } else if (i < N_INSTR) {
+            const int rb = r - PROWS, tap = rb >> 5, n = rb & 31;
+            if (n < ctot) {
+                const int sel = n < c0 ? 0 : 1;
+                src[k] = a.w[sel] + (size_t)((n - (sel ? c0 : 0)) * 9 + tap) * a.Cin + 4 * kq;
+                inc[k] = 16;
+            }
+        }
+    }
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < PWL; ++k) {
+            const int i = wave + 4 * k;
+            if (i < N_INSTR) {
+                __builtin_amdgcn_global_load_lds((gptr_t)src[k], (lptr_t)(&S[buf][i * 256]), 16, 0, 0);
+                src[k] += inc[k];
+            }
+        }
+    };
+
+    // reader side: this lane's output pixel is (2 wave + li / 16, li % 16); tap (dy, dx) reads patch pixel + dy * 18 + dx
+    const unsigned s_base = (unsigned)(size_t)(lptr_t)(&S[0][0]);
+    unsigned aa0[9], aa1[9];
+    {
+        const int p0 = (2 * wave + (li >> 4)) * PW + (li & 15);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pp = p0 + (t / 3) * PW + (t % 3);
+            const unsigned off = (unsigned)(pp * 64 + (((2 * lh) ^ ((pp >> 2) & 3)) << 4));
+            aa0[t] = s_base + off;
+            aa1[t] = s_base + (off ^ 16u);
+        }
+    }
+    const unsigned boff = (unsigned)(li * 64 + (((2 * lh) ^ ((li >> 2) & 3)) << 4));
+    const unsigned bb0 = s_base + A_BYTES + boff, bb1 = s_base + A_BYTES + (boff ^ 16u);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int nch = a.Cin / 16;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    auto chunk = [&](auto bufc, int c) {
+        constexpr int BUF = decltype(bufc)::value;
+        constexpr int BO = BUF * BUF_BYTES;
+        if (c + 1 < nch) issue(BUF ^ 1);
+        f32x4 fa[2][2], fb[2][2];
+        lds_read128<BO>(fa[0][0], aa0[0]);
+        lds_read128<BO>(fa[0][1], aa1[0]);
+        const unsigned cb0 = bb0 + BO, cb1 = bb1 + BO;         // (the 16-bit offset field cannot hold buffer + tap)
+        lds_read128<0>(fb[0][0], cb0);
+        lds_read128<0>(fb[0][1], cb1);
+        static_for<0, 9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int pp = t & 1;
+            if constexpr (t + 1 < 9) {
+                lds_read128<BO>(fa[pp ^ 1][0], aa0[t + 1]);
+                lds_read128<BO>(fa[pp ^ 1][1], aa1[t + 1]);
+                lds_read128<(t + 1) * 2048>(fb[pp ^ 1][0], cb0);
+                lds_read128<(t + 1) * 2048>(fb[pp ^ 1][1], cb1);
+                lds_wait<4>();
+            } else {
+                lds_wait<0>();
+            }
+            asm volatile("" : "+v"(fa[pp][0]), "+v"(fa[pp][1]), "+v"(fb[pp][0]), "+v"(fb[pp][1]));
+            bf16x8 ah, am, al, bh, bm, bl;
+            split3_bf16(fa[pp][0], fa[pp][1], ah, am, al);
+            split3_bf16(fb[pp][0], fb[pp][1], bh, bm, bl);
+            mfma_x3(acc, ah, am, al, bh, bm, bl);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < nch) chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+
+    // epilogue: accumulator r of this lane = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32, output column li
+    if (li < ctot) {
+        const int sel = li < c0 ? 0 : 1;
+        const int col = li - (sel ? c0 : 0), cn = a.c[sel];
+        const float bv = a.bias[sel] ? a.bias[sel][col] : 0.f;
+        float* yo = a.y[sel];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int oy = y0 + 2 * wave + (m >> 4), ox = x0 + (m & 15);
+            if (oy < T.H && ox < T.W) yo[(size_t)(T.base_row + oy * T.W + ox) * cn + col] = acc[r] + bv;
+        }
+    }
+}
+
+// tiles_dev: [ntiles] PredTile; second conv optional (w1 = null / c1 = 0)
+extern "C" int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntiles, const float* w0,
+                                   const float* bias0, float* y0, int c0, const float* w1, const float* bias1, float* y1,
+                                   int c1, void* stream) {
+    if (x == nullptr || tiles_dev == nullptr || w0 == nullptr || y0 == nullptr || Cin <= 0 || Cin % 16 != 0 || c0 < 1 ||
+        c1 < 0 || c0 + c1 > 32 || (c1 > 0 && (w1 == nullptr || y1 == nullptr)))
+        return RADET_ERR_ARG;
+    if (ntiles <= 0) return RADET_OK;
+    PredArgs a;
+    a.x = x; a.Cin = Cin; a.tiles = reinterpret_cast<const PredTile*>(tiles_dev);
+    a.w[0] = w0; a.bias[0] = bias0; a.y[0] = y0; a.c[0] = c0;
+    a.w[1] = c1 > 0 ? w1 : w0; a.bias[1] = c1 > 0 ? bias1 : nullptr; a.y[1] = c1 > 0 ? y1 : y0; a.c[1] = c1;
+    hipLaunchKernelGGL(pred3x3_patch_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, a);
+    return radet_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const float* dy;  // [M][Cout]

@@ -412,6 +412,33 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
               _stream())
 
 
+def _pred_tiles(lv):
+    """8 x 16 output blocks of every (level, image) of the pyramid `lv` for radet_pred3x3_patch (built once per Levels)."""
+    import numpy as np
+    t = getattr(lv, "_pred_tiles", None)
+    if t is None:
+        rows = []
+        for (h, w), off in zip(lv.hw, lv.offsets):
+            for n in range(lv.B):
+                for ty in range(-(-h // 8)):
+                    for tx in range(-(-w // 16)):
+                        rows.append((off + n * h * w, h, w, (ty << 16) | tx))
+        t = torch.from_numpy(np.asarray(rows, np.int32)).cuda()
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().synchronize()
+        lv._pred_tiles = t
+    return t
+
+
+def pred_conv_patch(lv, x, a, b=None):
+    """Predictor 3x3 convs from an LDS patch: a, b = (wf [c][9][Cin], bias, y [rows][c], c); b shares a's input."""
+    t = _pred_tiles(lv)
+    cin = x.shape[1]
+    w1, b1, y1, c1 = b if b is not None else (None, None, None, 0)
+    _lib.call("radet_pred3x3_patch", _ptr(x), cin, _ptr(t), t.shape[0], _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), a[3],
+              _ptr(w1), _ptr(b1), _ptr(y1), c1, _stream())
+
+
 _WTUNE_CACHE = _LRU(8192)
 
 

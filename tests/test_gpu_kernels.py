@@ -157,6 +157,34 @@ def test_strided_dgrad_class_launch(K, shape, x3, monkeypatch):
     assert rel_err(from_rows(dx3, B, H, W), ref) < 1e-5
 
 
+@pytest.mark.parametrize("hw,B", [([(60, 80), (30, 40), (15, 20), (8, 10), (4, 5)], 2), ([(13, 7), (9, 33)], 3),
+                                  ([(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)], 1)])
+def test_predictor_convs_from_lds_patch(K, hw, B):
+    """radet_pred3x3_patch (cls alone; reg + iou sharing one launch) against the fp64 convolution per level and against
+    the implicit-GEMM path it replaces, on ragged multi-level pyramids."""
+    Cin = 256
+    g = torch.Generator().manual_seed(len(hw) * 100 + B)
+    lv = K.Levels(hw, B)
+    xs = [torch.randn(B, Cin, h, w, generator=g) for h, w in hw]
+    x = torch.cat([to_rows(t) for t in xs]).cuda()
+    heads = {}
+    for name, c in (("cls", 21), ("reg", 4), ("iou", 1)):
+        w = torch.randn(c, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+        heads[name] = (w, torch.randn(c, generator=g), torch.full((lv.rows, c), float("nan"), device="cuda"), c)
+    q = lambda n: (fold_w(heads[n][0]).cuda(), heads[n][1].cuda(), heads[n][2], heads[n][3])  # noqa: E731
+    K.pred_conv_patch(lv, x, q("cls"))
+    K.pred_conv_patch(lv, x, q("reg"), q("iou"))
+    geom = K.ConvGeom(lv, Cin, 21, 3, 1, 1)
+    geom.x3 = True
+    y_ig = torch.empty(lv.rows, 21, device="cuda")
+    K.conv_fwd(geom, x, fold_w(heads["cls"][0]).cuda(), heads["cls"][1].cuda(), y_ig)
+    for name, (w, b, y, c) in heads.items():
+        ref = torch.cat([to_rows(F.conv2d(t.double(), w.double(), b.double(), padding=1)) for t in xs])
+        assert torch.isfinite(y).all()
+        assert rel_err(y.cpu(), ref) < 1e-5, name
+    assert rel_err(heads["cls"][2], y_ig.double()) < 2e-6
+
+
 def test_fp32_from_bf16_planes_is_as_accurate_as_the_fp32_mfma(K):
     """The default fp32 arithmetic forms products from three bf16 planes per operand (exact split, 6 of 9 plane products,
     fp32 accumulate).  On the tower shape its error against an fp64 convolution must not exceed that of the native

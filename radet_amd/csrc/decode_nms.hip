@@ -436,7 +436,7 @@ __device__ __forceinline__ float iou_ref(float x1i, float y1i, float x2i, float 
     return inter / (area_j + area_i - inter);
 }
 
-#define NMS_KREG 4   // label segments of up to 64 * NMS_KREG boxes are clustered out of registers
+#define NMS_KREG 1   // label segments of up to 64 * NMS_KREG boxes are clustered out of registers
 
 struct NmsWs {   // per-image global workspace (cap entries each unless noted)
     float* bx;   // [4][cap] sorted coordinates (mode 3: offset coordinates)
@@ -449,6 +449,7 @@ struct NmsWs {   // per-image global workspace (cap entries each unless noted)
     int* seg;    // [cap + 1] label-segment starts (sorted positions), seg[nseg] = n
     int* big;    // [cap / (64 * NMS_KREG) + 1] indices of the segments longer than 64 * NMS_KREG
     int* misc;   // [8]: 0 nseg, 1 nbig, 2 nheads, 3 K
+    unsigned long long* mask;   // [cap][(cap + 63) / 64] suppression bits of the crowded segments (row = sorted position)
 };
 
 __device__ __forceinline__ NmsWs nms_ws(char* ws_all, size_t ws_per_image, int b, int cap) {
@@ -463,7 +464,8 @@ __device__ __forceinline__ NmsWs nms_ws(char* ws_all, size_t ws_per_image, int b
     ws.hpos = (int*)w; w += (size_t)cap * 4;
     ws.seg = (int*)w; w += (size_t)(cap + 8) * 4;
     ws.big = (int*)w; w += (size_t)(cap / (64 * NMS_KREG) + 8) * 4;
-    ws.misc = (int*)w;
+    ws.misc = (int*)w; w += 64;
+    ws.mask = (unsigned long long*)(ws_all + (size_t)b * ws_per_image + (((size_t)(w - (ws_all + (size_t)b * ws_per_image)) + 15) & ~(size_t)15));
     return ws;
 }
 
@@ -744,6 +746,116 @@ __global__ __launch_bounds__(1024) void nms_big_kernel(int cap, int mode, float 
     }
 }
 
+// ---- 3'. crowded label segments, two passes (default; RADET_NMS_BLOCKED=1 selects nms_big_kernel above):
+//   nms_mask_kernel     every CU: bit (i, j) = IoU(box i, box j) > thr for j > i inside a crowded segment, 64 x 64 bits
+//                       per wavefront -- the same iou_ref(i = earlier box, j) the sequential loop evaluates;
+//   nms_resolve_kernel  1 WG / crowded segment: the greedy pass over the rows needs bit operations only (a position is
+//                       a head iff no earlier head's row has its bit; head[j] = the first head whose row has bit j),
+//                       then the vote-score decay of every suppressed box from its recomputed IoU with its head.
+// Same heads, head assignment and decay factors as the sequential reference loop; the IoU work (n^2 / 2 per segment,
+// one CU-bound workgroup in nms_big_kernel) spreads over the whole device.
+__global__ __launch_bounds__(256) void nms_mask_kernel(int cap, float thr, char* __restrict__ ws_all, size_t ws_per_image) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    const int nbig = ws.misc[1];
+    const int capw = (cap + 63) >> 6;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), step = gridDim.x * 4;
+    int base = 0;                                             // tiles of the segments before this one (rotates the start)
+    for (int k = 0; k < nbig; ++k) {
+        const int s = ws.big[k];
+        const int p0 = ws.seg[s], cnt = ws.seg[s + 1] - p0;
+        const int nb = (cnt + 63) >> 6, T = nb * (nb + 1) / 2;
+        for (int t = (w + step - base % step) % step; t < T; t += step) {
+            int rb = 0, rem = t;
+            while (rem >= nb - rb) { rem -= nb - rb; ++rb; }
+            const int cb = rb + rem;
+            const int r = rb * 64 + lane, c = cb * 64 + lane;
+            const int rr = p0 + (r < cnt ? r : 0), cc = p0 + (c < cnt ? c : 0);
+            const float x1 = ws.bx[rr], y1 = ws.bx[cap + rr], x2 = ws.bx[2 * cap + rr], y2 = ws.bx[3 * cap + rr];
+            const float cx1 = ws.bx[cc], cy1 = ws.bx[cap + cc], cx2 = ws.bx[2 * cap + cc], cy2 = ws.bx[3 * cap + cc];
+            const float area_i = (x2 - x1) * (y2 - y1);
+            unsigned long long bits = 0ull;
+            const int qn = min(64, cnt - cb * 64);
+            for (int q = 0; q < qn; ++q) {
+                const float jx1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cx1), q));     // q is uniform
+                const float jy1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cy1), q));
+                const float jx2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cx2), q));
+                const float jy2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cy2), q));
+                const float iou = iou_ref(x1, y1, x2, y2, area_i, jx1, jy1, jx2, jy2);
+                if (iou > thr && cb * 64 + q > r) bits |= 1ull << q;
+            }
+            if (r < cnt) ws.mask[(size_t)(p0 + r) * capw + cb] = bits;
+        }
+        base += T;
+    }
+}
+
+#define NMS_RROWS 32     // mask rows per chunk of the resolve pass
+__global__ __launch_bounds__(256) void nms_resolve_kernel(int cap, int mode, int iou_enable, float sigma,
+                                                          char* __restrict__ ws_all, size_t ws_per_image) {
+    __shared__ unsigned long long rows[NMS_RROWS][128];     // one chunk of mask rows (<= 8192 / 64 words each)
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    if ((int)blockIdx.x >= ws.misc[1]) return;
+    const int s = ws.big[blockIdx.x];
+    const int p0 = ws.seg[s], cnt = ws.seg[s + 1] - p0;
+    const int capw = (cap + 63) >> 6, nbw = (cnt + 63) >> 6;
+    // thread t stages words (t & 127) of rows (t >> 7) + 2 k of the chunk: 16 loads in flight per thread
+    unsigned long long st[NMS_RROWS / 2];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NMS_RROWS / 2; ++k) {
+            const int r = chunk + (tid >> 7) + 2 * k, wd = tid & 127;
+            // words left of the diagonal are never written by the mask pass (and never needed): zero
+            st[k] = (r < cnt && wd < nbw && wd >= (r >> 6)) ? ws.mask[(size_t)(p0 + r) * capw + wd] : 0ull;
+        }
+    };
+    unsigned long long sup0 = 0ull, sup1 = 0ull;            // wave 0: lane l holds the suppressed bits of words l, l + 64
+    bool stop = false;
+    fetch(0);
+    for (int chunk = 0; chunk < cnt; chunk += NMS_RROWS) {
+#pragma unroll
+        for (int k = 0; k < NMS_RROWS / 2; ++k) rows[(tid >> 7) + 2 * k][tid & 127] = st[k];
+        __syncthreads();
+        if (chunk + NMS_RROWS < cnt) fetch(chunk + NMS_RROWS);      // in flight while wave 0 resolves this chunk
+        if (wave == 0 && !stop) {
+            const int nr = min(NMS_RROWS, cnt - chunk);
+            for (int r = 0; r < nr; ++r) {
+                const int i = chunk + r, wd = i >> 6;
+                const unsigned long long sw = wd < 64 ? sup0 : sup1;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)sw, wd & 63);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sw >> 32), wd & 63);
+                const unsigned long long cur = ((unsigned long long)hi << 32) | lo;
+                if ((cur >> (i & 63)) & 1ull) continue;             // suppressed by an earlier head
+                // head i: everything its row marks and nobody claimed before belongs to it
+                const unsigned long long r0 = rows[r][lane], r1 = rows[r][lane + 64];
+                unsigned long long n0 = r0 & ~sup0, n1 = r1 & ~sup1;
+                sup0 |= r0; sup1 |= r1;
+                if (lane == 0) ws.head[p0 + i] = p0 + i;
+                while (n0) { const int j = lane * 64 + __ffsll((long long)n0) - 1; ws.head[p0 + j] = p0 + i; n0 &= n0 - 1ull; }
+                while (n1) { const int j = (lane + 64) * 64 + __ffsll((long long)n1) - 1; ws.head[p0 + j] = p0 + i; n1 &= n1 - 1ull; }
+                if (mode == 1) { stop = true; break; }               // global vote: one head per label, the rest is dropped
+            }
+        }
+        __syncthreads();
+    }
+    // vote-score decay of the suppressed boxes (the factor the sequential loop applies when it assigns the head)
+    if (iou_enable && mode <= 1) {
+        __threadfence();
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 256) {
+            const int h = ws.head[p0 + j];
+            if (h < 0 || h == p0 + j) continue;
+            const float x1 = ws.bx[h], y1 = ws.bx[cap + h], x2 = ws.bx[2 * cap + h], y2 = ws.bx[3 * cap + h];
+            const int jj = p0 + j;
+            const float iou = iou_ref(x1, y1, x2, y2, (x2 - x1) * (y2 - y1), ws.bx[jj], ws.bx[cap + jj], ws.bx[2 * cap + jj],
+                                      ws.bx[3 * cap + jj]);
+            const float f = -(1 - iou) * (1 - iou) / sigma;
+            ws.vs[jj] = ws.vs[jj] * expf(f);
+        }
+    }
+}
+
 // ---- 4. order the cluster heads (score desc, original index asc); mode 2 / 3 outputs
 __global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                          int cap, int mode, int max_out, float* __restrict__ out_boxes,
@@ -896,7 +1008,8 @@ __global__ __launch_bounds__(64) void nms_vote_kernel(const int* __restrict__ co
 }
 
 static size_t nms_ws_per_image(int cap) {
-    return ((size_t)cap * (16 + 4 * 6) + (size_t)(cap + 8) * 4 + (size_t)(cap / (64 * NMS_KREG) + 8) * 4 + 64 + 255) / 256 * 256;
+    return ((size_t)cap * (16 + 4 * 6) + (size_t)(cap + 8) * 4 + (size_t)(cap / (64 * NMS_KREG) + 8) * 4 + 64 +
+            (size_t)cap * ((cap + 63) / 64) * 8 + 16 + 255) / 256 * 256;
 }
 
 extern "C" size_t radet_nms_ws_bytes(int B, int cap) { return (size_t)B * nms_ws_per_image(cap); }
@@ -925,8 +1038,15 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(1024), smem_sort, st, boxes, cluster_scores, vote_scores, labels,
                        counts, cap, mode, (char*)ws, wpi);
     hipLaunchKernelGGL(nms_small_kernel, dim3(32, B), dim3(256), 0, st, cap, mode, iou_thr, iou_enable, sigma, (char*)ws, wpi);
-    hipLaunchKernelGGL(nms_big_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(1024), smem_big, st, cap, mode, iou_thr,
-                       iou_enable, sigma, (char*)ws, wpi);
+    static const bool blocked = [] { const char* e = getenv("RADET_NMS_BLOCKED"); return e && e[0] == '1'; }();
+    if (blocked) {
+        hipLaunchKernelGGL(nms_big_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(1024), smem_big, st, cap, mode, iou_thr,
+                           iou_enable, sigma, (char*)ws, wpi);
+    } else {
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(B >= 8 ? 64 : (B >= 2 ? 128 : 256), B), dim3(256), 0, st, cap, iou_thr, (char*)ws, wpi);
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(256), 0, st, cap, mode, iou_enable,
+                           sigma, (char*)ws, wpi);
+    }
     hipLaunchKernelGGL(nms_heads_kernel, dim3(B), dim3(1024), smem_sort, st, boxes, counts, cap, mode, max_out, out_boxes,
                        out_scores, out_labels, out_count, aux0, aux1, (char*)ws, wpi);
     if (mode <= 1)

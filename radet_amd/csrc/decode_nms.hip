@@ -820,21 +820,30 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(int cap, int mode, int
         if (chunk + NMS_RROWS < cnt) fetch(chunk + NMS_RROWS);      // in flight while wave 0 resolves this chunk
         if (wave == 0 && !stop) {
             const int nr = min(NMS_RROWS, cnt - chunk);
-            for (int r = 0; r < nr; ++r) {
-                const int i = chunk + r, wd = i >> 6;
-                const unsigned long long sw = wd < 64 ? sup0 : sup1;
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)sw, wd & 63);
-                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sw >> 32), wd & 63);
-                const unsigned long long cur = ((unsigned long long)hi << 32) | lo;
-                if ((cur >> (i & 63)) & 1ull) continue;             // suppressed by an earlier head
-                // head i: everything its row marks and nobody claimed before belongs to it
-                const unsigned long long r0 = rows[r][lane], r1 = rows[r][lane + 64];
-                unsigned long long n0 = r0 & ~sup0, n1 = r1 & ~sup1;
-                sup0 |= r0; sup1 |= r1;
-                if (lane == 0) ws.head[p0 + i] = p0 + i;
-                while (n0) { const int j = lane * 64 + __ffsll((long long)n0) - 1; ws.head[p0 + j] = p0 + i; n0 &= n0 - 1ull; }
-                while (n1) { const int j = (lane + 64) * 64 + __ffsll((long long)n1) - 1; ws.head[p0 + j] = p0 + i; n1 &= n1 - 1ull; }
-                if (mode == 1) { stop = true; break; }               // global vote: one head per label, the rest is dropped
+            // the chunk's rows into registers first (all LDS reads in flight together): the greedy chain below is serial,
+            // an LDS round trip per head would be most of its time
+            unsigned long long q0[NMS_RROWS], q1[NMS_RROWS];
+#pragma unroll
+            for (int r = 0; r < NMS_RROWS; ++r) { q0[r] = rows[r][lane]; q1[r] = rows[r][lane + 64]; }
+#pragma unroll
+            for (int r = 0; r < NMS_RROWS; ++r) {
+                if (r < nr && !stop) {                             // (no break / continue: the loop must unroll, q0 / q1 are registers)
+                    const int i = chunk + r, wd = i >> 6;
+                    const unsigned long long sw = wd < 64 ? sup0 : sup1;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)sw, wd & 63);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(sw >> 32), wd & 63);
+                    const unsigned long long cur = ((unsigned long long)hi << 32) | lo;
+                    if (!((cur >> (i & 63)) & 1ull)) {              // not suppressed by an earlier head: head i --
+                        // everything its row marks and nobody claimed before belongs to it
+                        const unsigned long long r0 = q0[r], r1 = q1[r];
+                        unsigned long long n0 = r0 & ~sup0, n1 = r1 & ~sup1;
+                        sup0 |= r0; sup1 |= r1;
+                        if (lane == 0) ws.head[p0 + i] = p0 + i;
+                        while (n0) { const int j = lane * 64 + __ffsll((long long)n0) - 1; ws.head[p0 + j] = p0 + i; n0 &= n0 - 1ull; }
+                        while (n1) { const int j = (lane + 64) * 64 + __ffsll((long long)n1) - 1; ws.head[p0 + j] = p0 + i; n1 &= n1 - 1ull; }
+                        if (mode == 1) stop = true;                 // global vote: one head per label, the rest is dropped
+                    }
+                }
             }
         }
         __syncthreads();

@@ -734,28 +734,32 @@ struct PredArgs {
     int Cin;
 };
 
-__global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
+__global__ __launch_bounds__(512) void pred3x3_patch_kernel(const PredArgs a) {
     constexpr int TH = 8, TW = 16, PW = TW + 2, PP = (TH + 2) * PW;          // 180 patch pixels
     constexpr int PROWS = 192, WROWS = 9 * 32;                                // 64-byte rows: patch (padded), weights
     constexpr int A_BYTES = PROWS * 64, BUF_BYTES = (PROWS + WROWS) * 64;     // 12 + 18 KiB per chunk buffer
     constexpr int N_INSTR = (PROWS + WROWS) / 16;                             // 30 wave loads of 1 KiB per chunk
-    constexpr int PWL = (N_INSTR + 3) / 4;                                    // <= 8 per wave
+    constexpr int PWL = (N_INSTR + 7) / 8;                                    // <= 4 per wave
     // two chunk buffers (a third, loads two chunks ahead, measured the same at B = 4 and costs the second workgroup per CU)
     __shared__ __attribute__((aligned(64))) float S[2][BUF_BYTES / 4];
 
+    // 8 waves = two per SIMD: wave quad 0 runs taps 0-4, quad 1 taps 5-8 of the same 4 x 32 pixels, so that one wave's
+    // operand split (VALU) runs next to the other's MFMA chain (a lone wave runs them one after the other: 670 cycles per
+    // tap against 190 of MFMA work); the two partial accumulators are added through LDS at the end
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, grp = wave >> 2;
     const int li = lane & 31, lh = lane >> 5;
     const PredTile T = a.tiles[blockIdx.x];
     const int y0 = (T.yx >> 16) * TH, x0 = (T.yx & 0xFFFF) * TW;
     const int c0 = a.c[0], ctot = a.c[0] + a.c[1];
 
-    // writer side: load k of this wave is wave load i = wave + 4k; it fills rows 16 i + lane / 4, slot lane % 4
+    // writer side: load k of this wave is wave load i = wave + 8k; it fills rows 16 i + lane / 4, slot lane % 4
     const float* src[PWL];
     int inc[PWL];
     const int kq = (lane & 3) ^ ((lane >> 4) & 3);                            // the k-quad this lane's slot holds
 #pragma unroll
     for (int k = 0; k < PWL; ++k) {
-        const int i = wave + 4 * k;
+        const int i = wave + 8 * k;
         const int r = i * 16 + (lane >> 2);
         src[k] = radet_zero_page + lane * 4;
         inc[k] = 0;
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
     auto issue = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < PWL; ++k) {
-            const int i = wave + 4 * k;
+            const int i = wave + 8 * k;
             if (i < N_INSTR) {
                 __builtin_amdgcn_global_load_lds((gptr_t)src[k], (lptr_t)(&S[buf][i * 256]), 16, 0, 0);
                 src[k] += inc[k];
@@ -786,20 +790,22 @@ __global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
         }
     };
 
-    // reader side: this lane's output pixel is (2 wave + li / 16, li % 16); tap (dy, dx) reads patch pixel + dy * 18 + dx
+    // reader side: this lane's output pixel is (2 wq + li / 16, li % 16); tap (dy, dx) reads patch pixel + dy * 18 + dx
     const unsigned s_base = (unsigned)(size_t)(lptr_t)(&S[0][0]);
-    unsigned aa0[9], aa1[9];
+    const int tap0 = grp * 5, ntap = grp ? 4 : 5;
+    unsigned aa0[5], aa1[5];
     {
-        const int p0 = (2 * wave + (li >> 4)) * PW + (li & 15);
+        const int p0 = (2 * wq + (li >> 4)) * PW + (li & 15);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int u = 0; u < 5; ++u) {
+            const int t = tap0 + (u < ntap ? u : 0);
             const int pp = p0 + (t / 3) * PW + (t % 3);
             const unsigned off = (unsigned)(pp * 64 + (((2 * lh) ^ ((pp >> 2) & 3)) << 4));
-            aa0[t] = s_base + off;
-            aa1[t] = s_base + (off ^ 16u);
+            aa0[u] = s_base + off;
+            aa1[u] = s_base + (off ^ 16u);
         }
     }
-    const unsigned boff = (unsigned)(li * 64 + (((2 * lh) ^ ((li >> 2) & 3)) << 4));
+    const unsigned boff = (unsigned)(li * 64 + (((2 * lh) ^ ((li >> 2) & 3)) << 4)) + (unsigned)(tap0 * 2048);
     const unsigned bb0 = s_base + A_BYTES + boff, bb1 = s_base + A_BYTES + (boff ^ 16u);
 
     f32x16 acc;
@@ -817,26 +823,29 @@ __global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
         f32x4 fa[2][2], fb[2][2];
         lds_read128<BO>(fa[0][0], aa0[0]);
         lds_read128<BO>(fa[0][1], aa1[0]);
-        const unsigned cb0 = bb0 + BO, cb1 = bb1 + BO;         // (the 16-bit offset field cannot hold buffer + tap)
-        lds_read128<0>(fb[0][0], cb0);
-        lds_read128<0>(fb[0][1], cb1);
-        static_for<0, 9>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int pp = t & 1;
-            if constexpr (t + 1 < 9) {
-                lds_read128<BO>(fa[pp ^ 1][0], aa0[t + 1]);
-                lds_read128<BO>(fa[pp ^ 1][1], aa1[t + 1]);
-                lds_read128<(t + 1) * 2048>(fb[pp ^ 1][0], cb0);
-                lds_read128<(t + 1) * 2048>(fb[pp ^ 1][1], cb1);
-                lds_wait<4>();
-            } else {
-                lds_wait<0>();
+        lds_read128<BO>(fb[0][0], bb0);
+        lds_read128<BO>(fb[0][1], bb1);
+        static_for<0, 5>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int pp = u & 1;
+            if (u < ntap) {                                        // uniform per wave
+                if (u + 1 < ntap) {
+                    if constexpr (u + 1 < 5) {
+                        lds_read128<BO>(fa[pp ^ 1][0], aa0[u + 1]);
+                        lds_read128<BO>(fa[pp ^ 1][1], aa1[u + 1]);
+                        lds_read128<BO + (u + 1) * 2048>(fb[pp ^ 1][0], bb0);
+                        lds_read128<BO + (u + 1) * 2048>(fb[pp ^ 1][1], bb1);
+                    }
+                    lds_wait<4>();
+                } else {
+                    lds_wait<0>();
+                }
+                asm volatile("" : "+v"(fa[pp][0]), "+v"(fa[pp][1]), "+v"(fb[pp][0]), "+v"(fb[pp][1]));
+                bf16x8 ah, am, al, bh, bm, bl;
+                split3_bf16(fa[pp][0], fa[pp][1], ah, am, al);
+                split3_bf16(fb[pp][0], fb[pp][1], bh, bm, bl);
+                mfma_x3(acc, ah, am, al, bh, bm, bl);
             }
-            asm volatile("" : "+v"(fa[pp][0]), "+v"(fa[pp][1]), "+v"(fb[pp][0]), "+v"(fb[pp][1]));
-            bf16x8 ah, am, al, bh, bm, bl;
-            split3_bf16(fa[pp][0], fa[pp][1], ah, am, al);
-            split3_bf16(fb[pp][0], fb[pp][1], bh, bm, bl);
-            mfma_x3(acc, ah, am, al, bh, bm, bl);
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -847,6 +856,17 @@ __global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
         if (c + 1 < nch) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
 
+    // the tap groups' partial sums: quad 1 -> LDS -> quad 0 (all loads have landed and been consumed: S is free)
+    float* red = &S[0][0];
+    if (grp == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wq * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[(wq * 16 + r) * 64 + lane];
+
     // epilogue: accumulator r of this lane = pixel (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32, output column li
     if (li < ctot) {
         const int sel = li < c0 ? 0 : 1;
@@ -856,7 +876,7 @@ __global__ __launch_bounds__(256) void pred3x3_patch_kernel(const PredArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int oy = y0 + 2 * wave + (m >> 4), ox = x0 + (m & 15);
+            const int oy = y0 + 2 * wq + (m >> 4), ox = x0 + (m & 15);
             if (oy < T.H && ox < T.W) yo[(size_t)(T.base_row + oy * T.W + ox) * cn + col] = acc[r] + bv;
         }
     }
@@ -874,7 +894,7 @@ extern "C" int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev
     a.x = x; a.Cin = Cin; a.tiles = reinterpret_cast<const PredTile*>(tiles_dev);
     a.w[0] = w0; a.bias[0] = bias0; a.y[0] = y0; a.c[0] = c0;
     a.w[1] = c1 > 0 ? w1 : w0; a.bias[1] = c1 > 0 ? bias1 : nullptr; a.y[1] = c1 > 0 ? y1 : y0; a.c[1] = c1;
-    hipLaunchKernelGGL(pred3x3_patch_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pred3x3_patch_kernel, dim3(ntiles), dim3(512), 0, (hipStream_t)stream, a);
     return radet_check_launch();
 }
 

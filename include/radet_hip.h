@@ -44,7 +44,8 @@ typedef struct RadetConvDesc {
     float eps;
     int wft_ld;            /* row stride of wft's last dim (>= Cout; zero-padded K for small heads), 0 = Cout */
     int wft_off;           /* column offset inside that padded row */
-    int w16;               /* 1: wf / wft are bf16 buffers (bf16-storage mode); bias_f stays fp32 */
+    int w16;               /* 1: wf / wft are bf16 buffers (bf16-storage mode); 2: bf16 plane triples (rows [3][Cin] resp.
+                              [3][wft_ld], see "planes" below); bias_f stays fp32 */
 } RadetConvDesc;
 
 /* Gather table of one conv geometry: table[tap][Mp] = input row feeding (output row m, tap) or -1 (padding /
@@ -67,7 +68,10 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * plain launch when there is less than one K stage per workgroup; +0x1000000 = fp32 tensors, products formed on the
  * bf16 matrix cores from an exact three-way bf16 split of every fp32 operand (x = hi + mid + lo, 8 significand bits
  * each; 6 of the 9 plane products -- everything above 2^-24 relative -- through v_mfma_f32_32x32x16_bf16, fp32
- * accumulate; Cin % 32 == 0, otherwise the native fp32 MFMA is used).  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
+ * accumulate; Cin % 32 == 0, otherwise the native fp32 MFMA is used); +0x2000000 = the same arithmetic with operands
+ * that ARRIVE as bf16 plane triples (x rows [3][Cin] bf16, w [Cout][taps][3][Cin] bf16 -- "planes" below; y, addend, mask,
+ * bias fp32; Cin % 32 == 0): no operand split in the K loop; tiles 1..4 as above plus 5 = 128 x 128 and 6 = 256 x 128 with
+ * 8 waves; K step 32 channels, or 16 with +0x4000000; +0x20000 = one more LDS stage.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
  * tickets that must be ZERO before the first launch (every launch leaves them zero); when given, launches with too few
  * tiles for 256 CUs split the K loop (<= 8 ways, or only the left-over tiles of the last round) and the workgroup that
  * arrives last at a tile sums the partial tiles in split order and applies the epilogue -- one launch, deterministic.
@@ -93,7 +97,7 @@ int radet_conv2d_igemm_taps(const float* x, const float* w, const float* addend,
  * GEMM rows = output rows sorted by class, each class padded to a multiple of 128 rows (out_rows = -1 and table = -1 on
  * the pad rows); class c owns rows [cls_start[c], cls_start[c+1]) (cls_start[0] = 0, the last class ends at M, M % 128
  * == 0), runs cls_ntaps[c] <= 4 taps, its tap t reads weight tap tap_ids_host[4c + t]; gather_table is
- * [max ntaps][M].  Order the classes by taps, most first (the grid keeps that order). */
+ * [max ntaps][radet_gather_table_rows(M)].  Order the classes by taps, most first (the grid keeps that order). */
 int radet_conv2d_igemm_classes(const float* x, const float* w, const float* addend, const float* mask, float* y,
                                const int* gather_table, const int* out_rows, const int* tap_ids_host, const int* cls_ntaps,
                                const int* cls_start, int ncls, int kt_w, int M, int Cin, int Cout, int tile_override,
@@ -112,7 +116,8 @@ int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntile
  * planes per operand (as tile_override 0x1000000); bits 4-5: tile override of the one-tap
  * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel; bit 7: 32
  * instead of 16 pixels per LDS stage in the one-tap fp32 kernel;
- * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32. */
+ * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32;
+ * bit 9 (0x200): dy and x are bf16 plane triples (dy rows [3][ld_dy], x rows [3][Cin]; 3x3 convs with Cin % 32 == 0). */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                        int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);
@@ -174,6 +179,27 @@ int radet_upsample_add_bwd_h(void* dsrc, const void* ddst, int B, int Ho, int Wo
 int radet_relu_bwd_h(const void* dy, const void* addend, const void* act, void* dx, size_t n, void* stream);
 int radet_convert_rows(const void* src, void* dst, size_t rows, int ncols, int src_ld, int src_off, int dst_ld,
                        int dst_off, int to_bf16, void* stream);
+/* ---- bf16 plane triples ("planes"): the operand format of the default fp32 arithmetic's conv GEMMs.  An fp32 value x is
+ * stored as three bf16 numbers hi + mid + lo == x exactly (8 significand bits each, truncation); a row of C channels is
+ * [3][C] bf16 = hi | mid | lo, rows back to back (6 bytes per element).  The producers of a tensor that only conv GEMMs read
+ * (GroupNorm+ReLU outputs of the head towers, their gradients, folded weights with RadetConvDesc.w16 = 2) write planes once;
+ * radet_conv2d_igemm (+0x2000000) and radet_conv2d_wgrad (flags 0x200) multiply them on the bf16 matrix cores with fp32
+ * accumulation (6 of the 9 plane products, as +0x1000000) -- same results as splitting the fp32 operands inside the GEMM,
+ * without the per-use VALU work.  Replaces nothing in the reference by itself: it is the storage format behind the convs of
+ * resnet.py:260-299 / fpn.py:170-221 / atss_head.py:118-145.  C % 8 == 0, row strides in floats, % 4 == 0. */
+int radet_split_planes(const float* src, void* dst_planes, size_t rows, int C, int src_ld, void* stream);
+int radet_merge_planes(const void* src_planes, float* dst, size_t rows, int C, int dst_ld, void* stream);
+/* GroupNorm + ReLU with plane outputs: y / dz as fp32 (may be NULL) and / or as planes (yp / dzp, may be NULL) */
+int radet_gn_relu_fwd_p(const float* z, const float* gamma, const float* beta, float* y, void* yp, float* stats,
+                        float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,
+                        void* stream);
+int radet_gn_relu_fwd_pair_p(const float* z0, const float* gamma0, const float* beta0, float* y0, void* yp0, float* stats0,
+                             float* partial_ws0, const float* z1, const float* gamma1, const float* beta1, float* y1,
+                             void* yp1, float* stats1, float* partial_ws1, int B, int C, int groups, float eps, int relu,
+                             const int* seg_desc, int nseg, void* stream);
+int radet_gn_relu_bwd_p(const float* dy, const float* z, const float* stats, const float* gamma, const float* beta,
+                        float* dz, void* dzp, float* dgamma, float* dbeta, float* partial_ws, int B, int C, int groups,
+                        int relu, const int* seg_desc, int nseg, void* stream);
 int radet_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int radet_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream);
 

@@ -80,6 +80,11 @@ SIGNATURES = {
     "radet_upsample_add_bwd_h": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "radet_relu_bwd_h": (_i, [_p, _p, _p, _p, _sz, _p]),
     "radet_convert_rows": (_i, [_p, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "radet_split_planes": (_i, [_p, _p, _sz, _i, _i, _p]),
+    "radet_merge_planes": (_i, [_p, _p, _sz, _i, _i, _p]),
+    "radet_gn_relu_fwd_p": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_fwd_pair_p": (_i, [_p] * 14 + [_i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_bwd_p": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "radet_mbd_ws_bytes": (_sz, [_sz]),
     "radet_mbd": (_i, [_p, _p, _i, _p, _p, _f, _i, _i, _p, _sz, _p, _p]),
     "radet_gdt": (_i, [_p, _p, _i, _p, _p, _p, _p, _p]),

@@ -20,6 +20,9 @@
 #include <type_traits>
 
 #define RADET_SPLIT_COUNTERS 16384     // arrival tickets at the head of the split workspace
+#ifndef RADET_P3_DBG
+#define RADET_P3_DBG 0                 // 1: ConvArgs::dbg ablation switches of the plane-operand loop are live (experiments)
+#endif
 
 struct ConvPtrs {
     const float* x;       // input rows [*, Cin]
@@ -55,6 +58,8 @@ struct ConvArgs {
     // c (boundaries are multiples of 128, pad rows have out_rows = -1), class c runs (cls_nt >> 4c) & 15 taps and its
     // tap t reads weight tap tap_ids[4c + t]; rowtab is [max taps][Mp].  cls_nt = 0: one tap list for all rows.
     int cls_nt, cls_b[3];
+    int dbg;              // experiments (RADET_DBG_IGEMM, plane-operand kernels): 1 no tile loads after the prologue, 2 no MFMAs,
+                          // 4 no fragment reads after the first
 };
 
 __device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
@@ -438,13 +443,14 @@ __device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf1
 // TAG only changes the kernel's symbol name: TAG=1 marks the head-tower GEMM family (M = B*6400, N = 256,
 // K = 2304) so that rocprofv3 --stats reports it on its own line (bench.py's roofline kernel).
 template <int BM, int BN, int WM, int WN, int TAG, int BK, int NSTG = 2, bool SK = false>
-__global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN;           // waves per workgroup: 4, or 8 (plane-operand tiles that own a whole CU's LDS)
     constexpr int F4 = BK / 4;            // 16-byte slots per tile row
     constexpr int RPI = 64 / F4;          // tile rows per wave load
     constexpr int RPB = 64 / BK;          // tile rows per 256 bytes of LDS
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
-    constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
+    constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
     constexpr int NS = BK / 8;
     constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
     constexpr bool H16 = (TAG & 4) != 0;                      // bit 2: bf16 storage (a 16-byte slot = 8 bf16 = one MFMA operand)
@@ -452,17 +458,25 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
     // in registers and 6 of the 9 plane products (everything above 2^-24 relative) are accumulated by
     // v_mfma_f32_32x32x16_bf16, which retires 16x the MACs per cycle of v_mfma_f32_32x32x2_f32
     constexpr bool X3 = (TAG & 8) != 0;
-    static_assert(WM * WN == 4, "4 waves");
+    // bit 4: the operands ARRIVE as bf16 plane triples (x rows [3][Cin] bf16 = hi | mid | lo with hi + mid + lo == the fp32
+    // value exactly, written once by the producer of the tensor; weights [Cout][taps][3][Cin]): the same 6 plane products as
+    // X3, but no operand split anywhere in the K loop -- it is ds_read_b128 + v_mfma only.  Byte geometry per plane = the
+    // bf16-storage path (K counted in channel pairs, a 16-byte LDS slot = 8 bf16 = one MFMA operand); outputs stay fp32
+    constexpr bool P3 = (TAG & 16) != 0;
+    constexpr int NPL = P3 ? 3 : 1;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(!P3 || BK == 16, "plane rows are laid out in 32-channel groups: one group per K stage");
     // NSTG LDS stages: loads run NSTG - 1 K steps ahead of the MFMAs.  3 stages hide more L2 latency (+8 % on the
     // tower GEMM running alone) but cost LDS occupancy, which loses when dgrad and wgrad kernels share the CUs: used
     // for forward launches only (tile_override 0x20000), chosen per shape by the autotuner
-    __shared__ __attribute__((aligned(16))) float As[NSTG][BM * BK];
-    __shared__ __attribute__((aligned(16))) float Bs[NSTG][BN * BK];
+    __shared__ __attribute__((aligned(16))) float As[NSTG][NPL * BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[NSTG][NPL * BN * BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
+    const int xld = NPL * a.Cin;          // row stride of x / of one weight tap, in 4-byte units
 
     const int tilesN = (a.Cout + BN - 1) / BN;
     const int tilesG = ((a.M + BM - 1) / BM) * tilesN;
@@ -515,41 +529,89 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
 
     // writer side: this lane fills slot (lane % F4) of tile row ins * RPI + lane / F4 of every load it issues
     const int lrow = lane / F4;
-    int ld_tap = it0 / cpt, ld_c0 = (it0 - ld_tap * cpt) * BK;
+    // K order: tap-major (all channel chunks of a tap, then the next tap), or -- plane operands (dbg bit 3: tap-major) --
+    // channel-major (the taps of one channel chunk back to back: the shifted re-reads of an input row are then a few stages
+    // apart instead of a whole channel sweep, i.e. they hit the XCD's L2 instead of the Infinity Cache)
+    const bool cmaj = P3 && (!RADET_P3_DBG || !(a.dbg & 8));
+    int ld_tap = cmaj ? it0 % KTt : it0 / cpt, ld_c0 = cmaj ? (it0 / KTt) * BK : (it0 - ld_tap * cpt) * BK;
     int arow[A_PW], akq[A_PW];
     const float* wp[B_PW];
 #pragma unroll
     for (int k = 0; k < A_PW; ++k) {
-        const int r = (wave + 4 * k) * RPI + lrow;
+        const int r = (wave + NW * k) * RPI + lrow;
         akq[k] = 4 * ((lane % F4) ^ ((r / RPB) % F4));
-        arow[k] = (nK > 0 && wave + 4 * k < A_INSTR) ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : -1;
+        arow[k] = (nK > 0 && wave + NW * k < A_INSTR) ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : -1;
     }
 #pragma unroll
     for (int k = 0; k < B_PW; ++k) {
-        const int r = (wave + 4 * k) * RPI + lrow;
+        const int r = (wave + NW * k) * RPI + lrow;
         const int n = n0 + r;
-        wp[k] = (wave + 4 * k < B_INSTR && n < a.Cout)
-                    ? P.w + (size_t)n * a.KTw * a.Cin + 4 * ((lane % F4) ^ ((r / RPB) % F4)) : nullptr;
+        wp[k] = (wave + NW * k < B_INSTR && n < a.Cout)
+                    ? P.w + (size_t)n * a.KTw * xld + 4 * ((lane % F4) ^ ((r / RPB) % F4)) : nullptr;
     }
-    constexpr bool A_FULL = A_INSTR % 4 == 0, B_FULL = B_INSTR % 4 == 0;   // every wave owns A_PW / B_PW loads
+    constexpr bool A_FULL = A_INSTR % NW == 0, B_FULL = B_INSTR % NW == 0;   // every wave owns A_PW / B_PW loads
     int wtap = nK > 0 ? a.tap_ids[tbase + ld_tap] : 0;
-    auto issue_stage = [&](int buf) {
+    // the loads of one K stage as individually issuable pieces (piece q < NPIECE: plane p of this wave's k-th A load, then
+    // of its k-th B load), so that the plane-operand loop can spread them between its MFMAs; advance_stage() moves the
+    // (tap, channel chunk) cursor and fetches the next gather rows
+    constexpr int NPIECE = NPL * (A_PW + B_PW);
+    // plane operands: per load k a base pointer (row start, or the zero page for padding rows) and a mask that cancels the
+    // stage offset on padding rows -- a select between two LOADS per piece costs exec-mask juggling and a branch each
+    const float* abase[A_PW];
+    const float* wbase[B_PW];
+    unsigned amask[A_PW], wmask[B_PW];
+    auto set_abase = [&]() {
+        if constexpr (P3) {
 #pragma unroll
-        for (int k = 0; k < A_PW; ++k) {
-            const int ins = wave + 4 * k;
-            if (A_FULL || ins < A_INSTR) {
-                const float* src = arow[k] >= 0 ? P.x + (size_t)arow[k] * a.Cin + ld_c0 + akq[k] : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
+            for (int k = 0; k < A_PW; ++k) {
+                amask[k] = arow[k] >= 0 ? 0xFFFFFFFFu : 0u;
+                const unsigned long long real = (unsigned long long)(P.x + (size_t)(arow[k] & (int)amask[k]) * xld + akq[k]);
+                const unsigned long long zero = (unsigned long long)(radet_zero_page + lane * 4);
+                const unsigned long long m = (unsigned long long)(long long)(int)amask[k];
+                abase[k] = (const float*)((real & m) | (zero & ~m));
             }
         }
-        const int woff = wtap * a.Cin + ld_c0;
+    };
+    if constexpr (P3) {
 #pragma unroll
         for (int k = 0; k < B_PW; ++k) {
-            const int ins = wave + 4 * k;
-            if (B_FULL || ins < B_INSTR) {
-                const float* src = wp[k] ? wp[k] + woff : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][ins * 256]), 16, 0, 0);
+            wmask[k] = wp[k] ? 0xFFFFFFFFu : 0u;
+            wbase[k] = wp[k] ? wp[k] : radet_zero_page + lane * 4;
+        }
+    }
+    set_abase();
+    auto issue_piece = [&](int buf, auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < NPL * A_PW) {
+            constexpr int k = q / NPL, p = q % NPL;
+            const int ins = wave + NW * k;
+            if (A_FULL || ins < A_INSTR) {
+                // plane rows: 32-channel groups of [hi | mid | lo] x 16 units -> chunk ld_c0 starts at unit 3 * ld_c0
+                const float* src;
+                if constexpr (P3) src = abase[k] + ((unsigned)(NPL * ld_c0 + p * BK) & amask[k]);
+                else src = arow[k] >= 0 ? P.x + (size_t)arow[k] * xld + NPL * ld_c0 + akq[k] + p * BK : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][p * BM * BK + ins * 256]), 16, 0, 0);
             }
+        } else {
+            constexpr int k = (q - NPL * A_PW) / NPL, p = (q - NPL * A_PW) % NPL;
+            const int ins = wave + NW * k;
+            if (B_FULL || ins < B_INSTR) {
+                const float* src;
+                if constexpr (P3) src = wbase[k] + ((unsigned)(wtap * xld + NPL * ld_c0 + p * BK) & wmask[k]);
+                else src = wp[k] ? wp[k] + wtap * xld + NPL * ld_c0 + p * BK : radet_zero_page + lane * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][p * BN * BK + ins * 256]), 16, 0, 0);
+            }
+        }
+    };
+    auto advance_stage = [&]() {
+        if (cmaj) {
+            if (++ld_tap == KTt) { ld_tap = 0; ld_c0 += BK; }
+            wtap = a.tap_ids[tbase + ld_tap];
+#pragma unroll
+            for (int k = 0; k < A_PW; ++k)
+                if (A_FULL || wave + NW * k < A_INSTR)
+                    arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + NW * k) * RPI + lrow];
+            return;                     // (abase follows in refresh_abase(), right before the next stage's first piece)
         }
         ld_c0 += BK;
         if (ld_c0 == a.Cin) {
@@ -559,10 +621,15 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
                 wtap = a.tap_ids[tbase + ld_tap];
 #pragma unroll
                 for (int k = 0; k < A_PW; ++k)
-                    if (A_FULL || wave + 4 * k < A_INSTR)
-                        arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + 4 * k) * RPI + lrow];
+                    if (A_FULL || wave + NW * k < A_INSTR)
+                        arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + NW * k) * RPI + lrow];
             }
         }
+    };
+    auto issue_stage = [&](int buf) {
+        set_abase();
+        static_for<0, NPIECE>([&](auto qc) { issue_piece(buf, qc); });
+        advance_stage();
     };
 
     f32x16 acc[TM][TN];
@@ -575,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
 
     // vmcnt(LOADS) = "everything except the newest stage's loads has landed" (in-order return); only valid when every
     // wave owns exactly A_PW + B_PW loads per stage
-    constexpr int LOADS = (A_FULL && B_FULL) ? A_PW + B_PW : 0;
+    constexpr int LOADS = (A_FULL && B_FULL) ? NPL * (A_PW + B_PW) : 0;
     // prologue: stages 0 .. NSTG-2 in flight, stage 0 landed
     if (nK > 0) issue_stage(0);
     if (NSTG >= 3 && nK >= NSTG - 1) {
@@ -691,6 +758,100 @@ __global__ __launch_bounds__(256) void conv_igemmg_kernel(const ConvArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    if constexpr (P3) {
+        // Plane operands: per K = 16 slice 3 (TM + TN) fragment reads (one ds_read_b128 = the 8 bf16 of one plane a lane
+        // feeds to v_mfma_f32_32x32x16_bf16) and 6 TM TN MFMAs, nothing else.  Everything that is not an MFMA is spread
+        // BETWEEN the MFMAs: a slice is six groups of TM TN MFMAs (one plane product each), and behind each group go a few
+        // of the fragment reads of the next slice and -- in the last slice of a stage -- of the tile loads that refill the
+        // buffer released by the stage's barrier.  These tiles own the CU's LDS (one workgroup per CU, two waves per SIMD in
+        // lockstep): issued in a block after the barrier, the loads of both waves idle the SIMD's matrix pipe together.
+        // The pipeline is rotated by one slice: the barrier that ends stage `it` sits in front of the MFMAs of its last
+        // slice, whose fragments are in registers already.
+        f32x4 fa[2][3][TM], fb[2][3][TN];
+        constexpr int NRD = 3 * (TM + TN);
+        // fragment read r of slice s of buffer BUF into fragment set pp: order A hi, B hi, A mid, B mid, A lo, B lo
+        auto read_one = [&](auto bufc, auto sc, auto ppc, auto rc) {
+            constexpr int BUF = decltype(bufc)::value, s = decltype(sc)::value, pp = decltype(ppc)::value, r = decltype(rc)::value;
+            constexpr int AO = BUF * NPL * BM * BK * 4, BO = BUF * NPL * BN * BK * 4, RO = 32 * BK * 4;
+            constexpr int pl = r / (TM + TN), e = r % (TM + TN);
+            // (the buffer offset goes into the address register: a ds_read immediate holds 16 bits)
+            if constexpr (e < TM) lds_read128<pl * BM * BK * 4 + e * RO>(fa[pp][pl][e], aaddr[s] + (unsigned)AO);
+            else lds_read128<pl * BN * BK * 4 + (e - TM) * RO>(fb[pp][pl][e - TM], baddr[s] + (unsigned)BO);
+        };
+        // the six MFMA groups of fragment set PP; behind group g: reads [g NRD / 5, (g + 1) NRD / 5) of the next fragment set
+        // (none behind the last group: they would not be back by the next slice) and, with LD, the pieces of the refill
+        auto slice = [&](auto ppc, auto rbufc, auto rsc, bool do_read, auto ldc, int ld_buf, bool do_load) {
+            constexpr int PP = decltype(ppc)::value;
+            constexpr bool LD = decltype(ldc)::value;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[PP][pl][i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[PP][pl][j]));
+            }
+            static_for<0, 6>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;          // terms: hi hi, mid hi, hi mid, mid mid, lo hi, hi lo
+                constexpr int pa = t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0), pb = t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0);
+                if (!RADET_P3_DBG || !(a.dbg & 2)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PP][pa][i]),
+                                                                            __builtin_bit_cast(bf16x8, fb[PP][pb][j]), acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (LD) {
+                    if (do_load) {
+                        if constexpr (t == 0) set_abase();
+                        static_for<t * NPIECE / 6, (t + 1) * NPIECE / 6>([&](auto qc) { issue_piece(ld_buf, qc); });
+                        if constexpr (t == 5) advance_stage();
+                    }
+                }
+                if constexpr (t < 5) {
+                    if (do_read)
+                        static_for<t * NRD / 5, (t + 1) * NRD / 5>([&](auto rc) { read_one(rbufc, rsc, std::integral_constant<int, PP ^ 1>{}, rc); });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto stage_p3 = [&](auto bufc, int it) {
+            constexpr int BUF = decltype(bufc)::value;
+            static_for<0, NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int PP = s & 1;                                      // parity of the global slice index (NS even)
+                lds_wait<0>();                                                 // fragment set PP has arrived
+                if constexpr (s + 1 < NS) {
+                    slice(std::integral_constant<int, PP>{}, bufc, std::integral_constant<int, s + 1>{},
+                          !RADET_P3_DBG || !(a.dbg & 4), std::false_type{}, 0, false);
+                } else {
+                    // (this wave has no read of buffer BUF in flight any more)
+                    if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                                           // stage it + 1 landed, buffer BUF released
+                    slice(std::integral_constant<int, PP>{}, std::integral_constant<int, (BUF + 1) % NSTG>{},
+                          std::integral_constant<int, 0>{}, it + 1 < nK && (!RADET_P3_DBG || !(a.dbg & 4)), std::true_type{}, BUF,
+                          it + NSTG < nK && (!RADET_P3_DBG || !(a.dbg & 1)));
+                }
+            });
+        };
+        static_assert(NS % 2 == 0, "fragment double buffer: compile-time slice parity");
+        if (nK > 0) {
+            if (NSTG - 1 < nK) issue_stage(NSTG - 1);
+            static_for<0, NRD>([&](auto rc) {
+                read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rc);
+            });
+        }
+        for (int it = 0; it < nK; it += NSTG) {
+            stage_p3(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < nK) stage_p3(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (NSTG >= 3)
+                if (it + 2 < nK) stage_p3(std::integral_constant<int, 2>{}, it + 2);
+            if constexpr (NSTG >= 4)
+                if (it + 3 < nK) stage_p3(std::integral_constant<int, 3>{}, it + 3);
+        }
+    } else
     for (int it = 0; it < nK; it += NSTG) {
         stage(std::integral_constant<int, 0>{}, it);
         if (it + 1 < nK) stage(std::integral_constant<int, 1>{}, it + 1);
@@ -1753,6 +1914,184 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, plane operands
+// conv_wgrad9h_kernel's tiling and data path (256 output channels x 32 input channels x 9 taps per 8-wave workgroup,
+// [4 pixels][16 channels] bf16 sub-tiles by LDS-DMA, ds_read_b64_tr_b16 operands) for operands that arrive as bf16 plane
+// triples: dy rows [3][ld_dy], x rows [3][Cin] (hi | mid | lo, hi + mid + lo = the fp32 value exactly; written once by the
+// producers, see radet_split_planes / the GroupNorm kernels).  Per tap the 6 plane products of conv_igemmg_kernel's X3 / P3
+// modes; no operand split in the loop.  16 pixels (one K = 16 MFMA step) per stage: 3 planes x (8 KiB dy + 9 KiB x) = 51
+// KiB per stage, two stages; 54 MFMAs per wave between barriers, two waves per SIMD.
+__global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
+    constexpr int BP = 16, NW = 8, BM = 256, BC = 32, KT = 9;
+    constexpr int CBA = BM / 16, CBB = BC / 16;
+    constexpr int A_PL = BP * BM, B_PL = BP * BC;           // bf16 elements per dy plane tile / per (tap, plane) x tile
+    constexpr int A_Q = A_PL * 2 / 1024;                    // wave loads per dy plane tile: 8
+    constexpr int A_INSTR = 3 * A_Q;                        // 24
+    constexpr int B_INSTR = KT * 3;                         // 27: one wave load per (tap, plane)
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 7
+    static_assert(B_PL * 2 == 1024, "one wave load per x tile");
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][3 * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KT * 3 * B_PL];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    // x-tile load bi = tap * 3 + plane: the 8 sub-tiles [4 pixel quads][2 channel blocks] of that tap and plane
+    int brow[PER_WAVE];
+    bool bok[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        bok[k] = false;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int m = p_begin + 4 * (l_blk / CBB) + l_prow;
+            brow[k] = a.rowtab[(size_t)(bi / 3) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+            bok[k] = m < p_end;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
+                const void* src = (bok[k] && brow[k] >= 0)
+                                      ? (const void*)(xh + (size_t)brow[k] * 3 * a.Cin + radet_plane_off(c) + 32 * (bi % 3))
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * B_PL]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
+                const int m = p0 + 4 * (blk / CBA) + l_prow;
+                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+                const void* src = (m < p_end && o < a.Cout)
+                                      ? (const void*)(dyh + (size_t)m * 3 * a.ld_dy + radet_plane_off(o) + 32 * pl)
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int m = p0 + BP + 4 * (l_blk / CBB) + l_prow;
+                brow[k] = a.rowtab[(size_t)(bi / 3) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[k] = m < p_end;
+            }
+        }
+    };
+
+    f32x16 acc[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    // per-lane LDS byte addresses of the (inline-asm) transposing reads, see conv_wgradh: pixel quad 2 lh (+ 1), channel
+    // sub-tile of the wave's 32 channels + g16, bytes 8 m16 of the sub-tile
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + wave * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + g16) * 128 + m16 * 8);
+
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        const unsigned ab = a_thr + (unsigned)buf * (3 * A_PL * 2), bb = b_thr + (unsigned)buf * (KT * 3 * B_PL * 2);
+        s16x4v al[3], ah[3], bl[2][3], bh[2][3];
+        static_for<0, 3>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * A_PL * 2>(al[pl], ab);
+            lds_read_tr16<pl * A_PL * 2 + CBA * 128>(ah[pl], ab);
+        });
+        static_for<0, 3>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * B_PL * 2>(bl[0][pl], bb);
+            lds_read_tr16<pl * B_PL * 2 + CBB * 128>(bh[0][pl], bb);
+        });
+        bf16x8 af[3];
+        static_for<0, KT>([&](auto tc_) {
+            constexpr int t = decltype(tc_)::value, pp = t & 1;
+            if constexpr (t + 1 < KT) {
+                static_for<0, 3>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    lds_read_tr16<((t + 1) * 3 + pl) * B_PL * 2>(bl[pp ^ 1][pl], bb);
+                    lds_read_tr16<((t + 1) * 3 + pl) * B_PL * 2 + CBB * 128>(bh[pp ^ 1][pl], bb);
+                });
+                lds_wait<6>();
+            } else {
+                lds_wait<0>();
+            }
+            if constexpr (t == 0) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    asm volatile("" : "+v"(al[pl])); asm volatile("" : "+v"(ah[pl]));
+                    af[pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[pl], ah[pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+            bf16x8 bf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                asm volatile("" : "+v"(bl[pp][pl])); asm volatile("" : "+v"(bh[pp][pl]));
+                bf[pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[pp][pl], bh[pp][pl], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            mfma_x3(acc[t], af[0], af[1], af[2], bf[0], bf[1], bf[2]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order; (hi + mid) + lo is exact
+            const int cb = tid >> 4, cc = tid & 15;
+            const __bf16* ap = reinterpret_cast<const __bf16*>(&As[buf][0]);
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
+                bsum += ((float)ap[e] + (float)ap[A_PL + e]) + (float)ap[2 * A_PL + e];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < a.Cout) out[((size_t)o * KT + t) * a.Cin + c] = acc[t][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------ gather table
 __global__ void gather_table_kernel(int* __restrict__ tab, const RadetSegs segs, int M, int Mp, int KH, int KW, int so,
                                     int sr, int off, int div) {
@@ -1807,7 +2146,25 @@ static const RadetSwitches& radet_switches() {
     return s;
 }
 
+// plane-operand instantiations (TAG bit 4): K step 16 units (32 channels) with 2 or 3 LDS stages, or 8 units with 2 or 4;
+// a configuration whose tiles would not fit the CU's 160 KiB of LDS falls back to the next smaller one
 template <int BM, int BN, int WM, int WN>
+static void launch_p3(const ConvArgs& a, hipStream_t st, int tag, int bk, int stages, int tiles) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int STG16 = 3 * (BM + BN) * 16 * 4;                                   // LDS bytes per stage
+    constexpr int LDS_MAX = 160 * 1024;
+#define RADET_LAUNCH_P3(TAGV, BKV, NSV) \
+    hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, NSV>), dim3(tiles, a.sk), dim3(NT), 0, st, a)
+    if constexpr (3 * STG16 <= LDS_MAX) {
+        if (stages >= 3) { RADET_LAUNCH_P3(16, 16, 3); return; }
+    }
+    if constexpr (2 * STG16 <= LDS_MAX) {
+        if (tag & 1) RADET_LAUNCH_P3(17, 16, 2); else RADET_LAUNCH_P3(16, 16, 2);
+    }
+#undef RADET_LAUNCH_P3
+}
+
+template <int BM, int BN, int WM, int WN, bool P3ONLY = false>
 static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, int stages, int skw) {
     ConvArgs a = a_in;
     const int T = a.groups * ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
@@ -1848,8 +2205,12 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.sk_wgs > 0 ? a.sk_wgs : a.n_full + (T - a.n_full) * a.sk_tail;
+    if (tag & 16) {
+        launch_p3<BM, BN, WM, WN>(a, st, tag, bk, stages, tiles);
+        return;
+    }
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
-    {
+    if constexpr (!P3ONLY) {
         if (a.sk_wgs > 0) {                                            // stream-K: tag 0, 2 stages
             if (bk == 32) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 32, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 0, 16, 2, true>), dim3(tiles, 1), dim3(256), 0, st, a);
@@ -1885,8 +2246,8 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
 }
 
 static long igemm_tiles(int M, int N, int choice) {
-    const int bm = choice == 3 ? 64 : 128;
-    const int bn = choice == 1 ? 128 : (choice == 4 ? 32 : 64);
+    const int bm = choice == 3 ? 64 : (choice >= 6 ? 256 : 128);
+    const int bn = (choice == 1 || choice >= 5) ? 128 : (choice == 4 ? 32 : 64);
     return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
@@ -1899,7 +2260,8 @@ static double tile_score(int M, int N, int bm, int bn, double intrinsic) {
     return quant * pad * intrinsic;
 }
 
-extern "C" int radet_gather_table_rows(int M) { return (M + 127) / 128 * 128; }
+// rows per tap of a gather table: whole 256-row tiles (the largest block tile reads table rows [m0, m0 + 256) unguarded)
+extern "C" int radet_gather_table_rows(int M) { return (M + 255) / 256 * 256; }
 
 extern "C" int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, int off, int div,
                                         const int* seg_desc, int nseg, void* stream) {
@@ -1986,7 +2348,10 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
                       int tile_override, float* splitk_ws, size_t splitk_ws_floats, const int* out_rows,
                       const int* tap_ids, int kt_w, void* stream, const ConvPtrs* second, const int* cls) {
     const int h16 = (tile_override >> 11) & 1;                 // 0x800: bf16 storage, 0x10000: fp32 output from bf16 inputs
-    if (h16) {
+    // 0x2000000: x and w are bf16 plane triples (x rows [3][Cin], w [Cout][taps][3][Cin]; hi + mid + lo = the fp32 value);
+    // y / addend / mask / bias stay fp32.  +0x4000000: K step of 16 instead of 32 channels
+    const int p3 = ((tile_override >> 25) & 1) && !h16;
+    if (h16 || p3) {
         if (Cin % 32 != 0) return RADET_ERR_ARG;               // 16 channel pairs per K step at least
         Cin /= 2;                                              // K is counted in channel pairs (4-byte units) from here on
     }
@@ -2004,6 +2369,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         }
     }
     a.KTw = kt_w > 0 ? kt_w : KH * KW;
+    { static const int dbg = getenv("RADET_DBG_IGEMM") ? atoi(getenv("RADET_DBG_IGEMM")) : 0; a.dbg = dbg; }
     a.p[0].x = x; a.p[0].w = w; a.p[0].bias = bias; a.p[0].addend = addend; a.p[0].mask = mask; a.p[0].y = y;
     a.p[1] = a.p[0];
     a.groups = 1;
@@ -2019,9 +2385,12 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     int bk = ((tile_override >> 9) & 1) ? 32 : 16;
     if (Cin % 32 != 0) bk = 16;
     // 0x1000000: fp32 tensors, products from three bf16 planes per operand (6 bf16 MFMAs per K = 16 step); K step 32
-    const bool x3 = ((tile_override >> 24) & 1) && !h16 && !((tile_override >> 10) & 1) && Cin % 32 == 0;
+    const bool x3 = ((tile_override >> 24) & 1) && !h16 && !p3 && !((tile_override >> 10) & 1) && Cin % 32 == 0;
     if (x3) { bk = 32; tag |= 8; }
+    if (p3) { tag = 16 | ((tile_override >> 8) & 1); bk = 16; }
     int choice = tile_override & 0xFF;
+    if (choice > 4 && !p3) return RADET_ERR_ARG;               // the 8-wave tiles exist for plane operands only
+    if (choice >= 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
     if (choice <= 0) {
         if (Cout <= 32) choice = 4;
         else {
@@ -2068,6 +2437,8 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         case 2: launch_igemm<128, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
         case 3: launch_igemm<64, 64, 2, 2>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
         case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
+        case 5: launch_igemm<128, 128, 2, 4, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
+        case 6: launch_igemm<256, 128, 4, 2, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();
@@ -2163,6 +2534,15 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     const int chunks = (a.M + 15) / 16;
     a.chunks_per_split = (chunks + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & 0x200) {   // plane operands: dy rows [3][ld_dy] bf16, x rows [3][Cin] bf16 (hi | mid | lo)
+        if ((ld_dy & 31) || (Cin & 31) || (flags & 3)) return RADET_ERR_ARG;
+        if (KH == 3 && KW == 3 && Cin % 32 == 0) {
+            const int tiles9 = ((Cout + 255) / 256) * (Cin / 32) * S;
+            hipLaunchKernelGGL(conv_wgrad9p_kernel, dim3(tiles9), dim3(512), 0, st, a);
+            return radet_check_launch();
+        }
+        return RADET_ERR_ARG;
+    }
     if (flags & 2) {   // bf16 storage: dy / x are bf16 (ld_dy, Cin in elements; 16-byte aligned rows)
         if ((ld_dy & 7) || (Cin & 7)) return RADET_ERR_ARG;
         if (use_wgrad9(M, Cin, Cout, KH, KW) && wgrad9_bm(Cout) == 256 && !(flags & 0x40) && !radet_switches().no_wgrad9) {

@@ -217,9 +217,20 @@ extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W,
 // transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
 #define FOLD_TO 16
 #define FOLD_TC 32
-__device__ __forceinline__ void stw(float* p, size_t i, float v, int w16) {     // folded weight store, fp32 or bf16
-    if (w16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
-    else p[i] = v;
+// folded weight store: element `col` of row `row` (row length ld): fp32, bf16 (w16 = 1) or bf16 plane triple (w16 = 2:
+// rows of ld / 32 groups [hi | mid | lo] x 32 channels, see common.h; ld % 32 == 0)
+__device__ __forceinline__ void stw(float* p, size_t row, int col, int ld, float v, int w16) {
+    if (w16 == 2) {
+        const unsigned h = __float_as_uint(v) & 0xFFFF0000u;
+        const float r = v - __uint_as_float(h);
+        const unsigned m = __float_as_uint(r) & 0xFFFF0000u;
+        const unsigned l = __float_as_uint(r - __uint_as_float(m));
+        unsigned short* q = reinterpret_cast<unsigned short*>(p) + row * 3 * (size_t)ld + radet_plane_off(col);
+        q[0] = (unsigned short)(h >> 16);
+        q[32] = (unsigned short)(m >> 16);
+        q[64] = (unsigned short)(l >> 16);
+    } else if (w16) reinterpret_cast<__bf16*>(p)[row * ld + col] = (__bf16)v;
+    else p[row * ld + col] = v;
 }
 __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
@@ -237,8 +248,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             float s = 1.f;
             if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
             const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
-            stw(d.wf, i, v, d.w16);
-            if (d.wft) stw(d.wft, ((size_t)c * KT + t) * (d.wft_ld ? d.wft_ld : d.cout) + d.wft_off + o, v, d.w16);
+            stw(d.wf, oc, c, d.cin, v, d.w16);
+            if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16);
         }
     } else {
         const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + FOLD_TC - 1) / FOLD_TC;
@@ -276,14 +287,14 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             for (int i = tid; i < no * run; i += 256) {
                 const int oo = i / run, r = i - oo * run;
                 const int t = r / nc, cl = r - t * nc;
-                stw(d.wf, ((size_t)(o0 + oo) * KT + t) * d.cin + c0 + cl, tile[oo][cl * KT + t] * ssc[oo], d.w16);
+                stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, tile[oo][cl * KT + t] * ssc[oo], d.w16);
             }
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
                 for (int i = tid; i < no * run; i += 256) {
                     const int oo = i % no, r = i / no;      // r = cl*KT + t
                     const int cl = r / KT, t = r - cl * KT;
-                    stw(d.wft, ((size_t)(c0 + cl) * KT + t) * ld_t + d.wft_off + o0 + oo, tile[oo][r] * ssc[oo], d.w16);
+                    stw(d.wft, (size_t)(c0 + cl) * KT + t, d.wft_off + o0 + oo, ld_t, tile[oo][r] * ssc[oo], d.w16);
                 }
             }
         }
@@ -441,8 +452,9 @@ struct GnFwdSet {
     const T* z;
     float* partial;
     const float *gamma, *beta;
-    T* y;
+    T* y;             // may be null when yp is given
     float* stats;
+    __bf16* yp;       // optional second output: y as bf16 plane triples (rows [3][256], common.h) for the conv GEMMs
 };
 template <class T>
 struct GnFwdArgs {
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
     const float* __restrict__ gamma = args.p[blockIdx.y].gamma;
     const float* __restrict__ beta = args.p[blockIdx.y].beta;
     T* __restrict__ y = args.p[blockIdx.y].y;
+    __bf16* __restrict__ yp = args.p[blockIdx.y].yp;
     float* __restrict__ stats = args.p[blockIdx.y].stats;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
@@ -558,7 +571,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
             r.z = (v.z - mean) * rstd * gm.z + bt.z;
             r.w = (v.w - mean) * rstd * gm.w + bt.w;
             if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-            st4(y, (size_t)(c.row0 + p) * 64 + col, r);
+            if (y) st4(y, (size_t)(c.row0 + p) * 64 + col, r);
+            if (yp) st4_planes(yp, (size_t)(c.row0 + p), 256, col, r);
         }
     }
     if (c.chunk_in_img == 0 && tid < 32) {
@@ -573,8 +587,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
 template <class T>
 static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T* y, float* stats,
                             float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
-                            int nseg, void* stream, const GnFwdSet<T>* second = nullptr) {
-    if (C != 256 || groups != 32) return RADET_ERR_ARG;
+                            int nseg, void* stream, const GnFwdSet<T>* second = nullptr, __bf16* yp = nullptr) {
+    if (C != 256 || groups != 32 || (y == nullptr && yp == nullptr)) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
     segs.nseg = nseg;
@@ -586,7 +600,7 @@ static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T
     const int chunks = gn_total_chunks(segs, B);
     hipStream_t st = (hipStream_t)stream;
     GnFwdArgs<T> args;
-    args.p[0] = GnFwdSet<T>{z, partial_ws, gamma, beta, y, stats};
+    args.p[0] = GnFwdSet<T>{z, partial_ws, gamma, beta, y, stats, yp};
     args.p[1] = second ? *second : args.p[0];
     const int sets = second ? 2 : 1;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, sets), dim3(256), 0, st, args, segs, B);
@@ -600,7 +614,7 @@ extern "C" int radet_gn_relu_fwd_pair(const float* z0, const float* gamma0, cons
                                       float* partial_ws0, const float* z1, const float* gamma1, const float* beta1,
                                       float* y1, float* stats1, float* partial_ws1, int B, int C, int groups, float eps,
                                       int relu, const int* seg_desc, int nseg, void* stream) {
-    const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1};
+    const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1, nullptr};
     return gn_relu_fwd_impl<float>(z0, gamma0, beta0, y0, stats0, partial_ws0, B, C, groups, eps, relu, seg_desc, nseg,
                                    stream, &second);
 }
@@ -609,7 +623,7 @@ extern "C" int radet_gn_relu_fwd_pair_h(const void* z0, const float* gamma0, con
                                         float* partial_ws0, const void* z1, const float* gamma1, const float* beta1,
                                         void* y1, float* stats1, float* partial_ws1, int B, int C, int groups, float eps,
                                         int relu, const int* seg_desc, int nseg, void* stream) {
-    const GnFwdSet<__bf16> second{(const __bf16*)z1, partial_ws1, gamma1, beta1, (__bf16*)y1, stats1};
+    const GnFwdSet<__bf16> second{(const __bf16*)z1, partial_ws1, gamma1, beta1, (__bf16*)y1, stats1, nullptr};
     return gn_relu_fwd_impl<__bf16>((const __bf16*)z0, gamma0, beta0, (__bf16*)y0, stats0, partial_ws0, B, C, groups, eps,
                                     relu, seg_desc, nseg, stream, &second);
 }
@@ -625,6 +639,24 @@ extern "C" int radet_gn_relu_fwd_h(const void* z, const float* gamma, const floa
                                    int nseg, void* stream) {
     return gn_relu_fwd_impl<__bf16>((const __bf16*)z, gamma, beta, (__bf16*)y, stats, partial_ws, B, C, groups, eps, relu,
                                     seg_desc, nseg, stream);
+}
+
+// fp32 in, outputs as fp32 (y, may be NULL) and / or bf16 plane triples (yp, may be NULL): the tower activations are read
+// by conv GEMMs only, which take plane operands (radet_conv2d_igemm tile_override 0x2000000)
+extern "C" int radet_gn_relu_fwd_p(const float* z, const float* gamma, const float* beta, float* y, void* yp, float* stats,
+                                   float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                                   int nseg, void* stream) {
+    return gn_relu_fwd_impl<float>(z, gamma, beta, y, stats, partial_ws, B, C, groups, eps, relu, seg_desc, nseg, stream,
+                                   nullptr, (__bf16*)yp);
+}
+extern "C" int radet_gn_relu_fwd_pair_p(const float* z0, const float* gamma0, const float* beta0, float* y0, void* yp0,
+                                        float* stats0, float* partial_ws0, const float* z1, const float* gamma1,
+                                        const float* beta1, float* y1, void* yp1, float* stats1, float* partial_ws1, int B,
+                                        int C, int groups, float eps, int relu, const int* seg_desc, int nseg, void* stream) {
+    if (y1 == nullptr && yp1 == nullptr) return RADET_ERR_ARG;
+    const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1, (__bf16*)yp1};
+    return gn_relu_fwd_impl<float>(z0, gamma0, beta0, y0, stats0, partial_ws0, B, C, groups, eps, relu, seg_desc, nseg,
+                                   stream, &second, (__bf16*)yp0);
 }
 
 extern "C" int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg) {
@@ -713,7 +745,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ gpart, T* __restrict__ dz,
-                                                           const RadetSegs segs, int B, int relu) {
+                                                           __bf16* __restrict__ dzp, const RadetSegs segs, int B,
+                                                           int relu) {
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ float m1s[32], m2s[32];
@@ -762,7 +795,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             r.y = rstd * (d.y * gm.y - m1 - xh.y * m2);
             r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
             r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
-            st4(dz, (size_t)(c.row0 + p) * 64 + col, r);
+            if (dz) st4(dz, (size_t)(c.row0 + p) * 64 + col, r);
+            if (dzp) st4_planes(dzp, (size_t)(c.row0 + p), 256, col, r);      // plane triples for the dgrad / wgrad GEMMs
         }
     }
 }
@@ -802,8 +836,9 @@ __global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restri
 template <class T>
 static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const float* gamma,
                             const float* beta, T* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
-                            int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
-    if (C != 256 || groups != 32) return RADET_ERR_ARG;
+                            int C, int groups, int relu, const int* seg_desc, int nseg, void* stream,
+                            __bf16* dzp = nullptr) {
+    if (C != 256 || groups != 32 || (dz == nullptr && dzp == nullptr)) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
     segs.nseg = nseg;
@@ -818,8 +853,8 @@ static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
                        segs, B, relu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, segs,
-                       B, relu);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, dzp,
+                       segs, B, relu);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(32), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
 }
@@ -829,6 +864,14 @@ extern "C" int radet_gn_relu_bwd(const float* dy, const float* z, const float* s
                                  int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
     return gn_relu_bwd_impl<float>(dy, z, stats, gamma, beta, dz, dgamma, dbeta, partial_ws, B, C, groups, relu, seg_desc,
                                    nseg, stream);
+}
+
+// fp32 in, dz as fp32 (may be NULL) and / or bf16 plane triples (dzp, may be NULL)
+extern "C" int radet_gn_relu_bwd_p(const float* dy, const float* z, const float* stats, const float* gamma,
+                                   const float* beta, float* dz, void* dzp, float* dgamma, float* dbeta, float* partial_ws,
+                                   int B, int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
+    return gn_relu_bwd_impl<float>(dy, z, stats, gamma, beta, dz, dgamma, dbeta, partial_ws, B, C, groups, relu, seg_desc,
+                                   nseg, stream, (__bf16*)dzp);
 }
 
 extern "C" int radet_gn_relu_bwd_h(const void* dy, const void* z, const float* stats, const float* gamma,
@@ -983,6 +1026,43 @@ extern "C" int radet_convert_rows(const void* src, void* dst, size_t rows, int n
     else
         hipLaunchKernelGGL((convert_rows_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const __bf16*)src, (float*)dst, rows, ncols, src_ld, src_off, dst_ld, dst_off);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ fp32 rows -> bf16 plane triples
+// dst rows [3][C] bf16 (hi | mid | lo, common.h) from src rows of C fp32 (row stride src_ld floats); and back.
+__global__ void split_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, size_t rows, int C4, int src_ld4) {
+    const size_t total = rows * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        st4_planes(dst, r, C4 * 4, c, reinterpret_cast<const float4*>(src)[r * src_ld4 + c]);
+    }
+}
+__global__ void merge_planes_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, size_t rows, int C4, int dst_ld4) {
+    const size_t total = rows * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        reinterpret_cast<float4*>(dst)[r * dst_ld4 + c] = ld4_planes(src, r, C4 * 4, c);
+    }
+}
+extern "C" int radet_split_planes(const float* src, void* dst, size_t rows, int C, int src_ld, void* stream) {
+    if (C <= 0 || (C & 31) || (src_ld & 3) || src_ld < C) return RADET_ERR_ARG;
+    if (rows == 0) return RADET_OK;
+    const size_t total = rows * (size_t)(C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, rows, C / 4,
+                       src_ld / 4);
+    return radet_check_launch();
+}
+extern "C" int radet_merge_planes(const void* src, float* dst, size_t rows, int C, int dst_ld, void* stream) {
+    if (C <= 0 || (C & 31) || (dst_ld & 3) || dst_ld < C) return RADET_ERR_ARG;
+    if (rows == 0) return RADET_OK;
+    const size_t total = rows * (size_t)(C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(merge_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst, rows,
+                       C / 4, dst_ld / 4);
     return radet_check_launch();
 }
 

@@ -74,6 +74,10 @@ class Engine:
         self.x3 = math == "fp32" and os.environ.get("RADET_X3", "1") != "0"
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
+        # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only
+        # conv GEMMs read -- tower activations, their gradients, the towers' folded weights -- are stored as bf16 plane triples
+        # by their producers (GroupNorm kernels, fold), and the tower GEMMs run without any operand split in their K loops
+        self.p3 = self.x3 and self.tower_mode == "pairbwd" and feat % 32 == 0 and os.environ.get("RADET_P3", "1") != "0"
         self.math_name = math
         self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
@@ -92,7 +96,7 @@ class Engine:
     TOWER_TAG = 0x100 | 0x200 | 3        # backward: 64 x 64 tile, K step 32
     TOWER_TAG_FWD = 0x100 | 0x200 | 2    # forward: 128 x 64 tile (2 accumulators per wave), K step 32
 
-    def _ttile(self, c, bwd=False, tag=True):
+    def _ttile(self, c, bwd=False, tag=True, pair=True):
         """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step
         (the forward launches are grouped cls + reg pairs, which the single-conv timing of the autotuner does not
         represent: it picked K step 16 for bf16 storage, 138 instead of 102 us per launch): 128 x 64, two accumulators
@@ -101,6 +105,10 @@ class Engine:
         take 3 LDS stages.  Backward: 64 x 64 in fp32 (128 x 64 / 128 x 128 measured equal next to the wgrad streams),
         autotuned in the bf16 modes."""
         fp32 = not self.math and not self.h16
+        if self.p3:
+            # plane operands: 256 x 128 tiles, 8 waves (one workgroup per CU owns its LDS: 2 x 72 KiB of stages) for the
+            # grouped cls + reg launches, 128 x 128 / 8 waves for a single tower GEMM (tools/bench_p3.py)
+            return (6 if pair else 5) | (0x100 if tag else 0)
         if fp32 and self.x3:
             # products from bf16 planes: the operand split is VALU work per fragment, so the tile with the most MFMAs per
             # fragment wins -- 128 x 128 (4 accumulators per wave), 2 LDS stages, forward (178 vs 158 TFLOP/s fp32-equivalent
@@ -195,7 +203,9 @@ class Engine:
                 n_wft += c.cin * c.k * c.k * ld
         self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
         o_w = o_b = o_t = 0
+        towers = (self.cls_tower + self.reg_tower) if self.p3 else []
         for c in self.convs:
+            c.w16 = 2 if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
             c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
             c.bias_f = self.bias_arena[o_b:o_b + c.cout]
@@ -207,6 +217,9 @@ class Engine:
                     n = c.cin * c.k * c.k * (c.wft_ld or c.cout)
                     c.wft = self.wft_arena[o_t:o_t + n]
                     o_t += n
+            if c.w16 == 2:            # plane triples: rows (o, tap) x Cin and (c, tap) x Cout (include/radet_hip.h, "planes")
+                c.wf = K.Planes(c.cout * c.k * c.k, c.cin, device=dev)
+                c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev)
 
     # ------------------------------------------------------------------ geometry-dependent plan
     # Geometry plans: everything that depends on (B, H, W) -- activation / gradient buffers, conv geometries and their
@@ -307,14 +320,22 @@ class Engine:
         new("P", R, f)
         new("dP", R, f)
         new("dP_tmp", R, f)
+        if self.p3:
+            self.buf["Pp"] = K.Planes(R, f, device=dev)          # P as planes: input of both towers' first conv / wgrad
         for t in ("cls", "reg"):
             for i in range(self.stacked_convs):
                 new(f"{t}.z{i}", R, f)
-                new(f"{t}.y{i}", R, f)
+                if self.p3 and i < self.stacked_convs - 1:      # read by tower GEMMs only: stored as planes
+                    self.buf[f"{t}.y{i}"] = K.Planes(R, f, device=dev)
+                else:
+                    new(f"{t}.y{i}", R, f)
                 self.buf[f"{t}.stats{i}"] = torch.empty(len(hw) * B * 64, device=dev)
             new(f"{t}.dy", R, f)
-            new(f"{t}.dz0", R, f)      # two alternating GN-backward outputs: the async wgrad of layer i may still
-            new(f"{t}.dz1", R, f)      # read dz[i & 1] while layer i-1 writes the other one
+            for nm in (f"{t}.dz0", f"{t}.dz1"):  # two alternating GN-backward outputs: the async wgrad of layer i may still
+                if self.p3:                      # read dz[i & 1] while layer i-1 writes the other one
+                    self.buf[nm] = K.Planes(R, f, device=dev)
+                else:
+                    new(nm, R, f)
             self.buf[f"{t}.dz"] = self.buf[f"{t}.dz0"]
         for c in self.cls_tower + self.reg_tower:
             c.geom = ConvGeom(self.plv, f, f, 3, 1, 1)
@@ -430,7 +451,7 @@ class Engine:
         arr = (_lib.RadetConvDesc * n)()
 
         def ptr(t):
-            return None if t is None else C.c_void_p(t.data_ptr())
+            return None if t is None else C.c_void_p(t.data_ptr())      # (tensors and K.Planes alike)
 
         for d, c in zip(arr, self.convs):
             p, g = self.p, self.g
@@ -443,7 +464,7 @@ class Engine:
             d.cout, d.cin, d.kh, d.kw = c.cout, c.cin, c.k, c.k
             d.eps = 1e-5
             d.wft_ld, d.wft_off = c.wft_ld, c.wft_off
-            d.w16 = 1 if (self.h16 and c is not self.stem) else 0
+            d.w16 = c.w16
             d.nsplit = c.geom.nsplit if c.geom is not None else 1
             if c.trainable and c.geom is not None:
                 d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
@@ -681,6 +702,13 @@ class Engine:
         self._tower_launch(K.conv_fwd_pair, cc.geom, dict(x=xc, w=cc.wf, y=zc), dict(x=xr, w=cr.wf, y=zr),
                            tile=self._ttile(cc))
         gc, gr = f"bbox_head.cls_convs.{i}.gn", f"bbox_head.reg_convs.{i}.gn"
+        if self.p3:
+            pl = K._isp(yc)             # the last layer's output feeds the predictor convs: fp32
+            K.gn_relu_fwd_pair_p(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], None if pl else yc, yc if pl else None,
+                                            b[f"cls.stats{i}"], self.gn_ws),
+                                 (zr, p[gr + ".weight"], p[gr + ".bias"], None if pl else yr, yr if pl else None,
+                                  b[f"reg.stats{i}"], self.gn_ws2))
+            return yc, yr
         # both GroupNorms in one pair of launches (on two streams the fork and the join idled the device for longer
         # than the 23 us of kernels they overlapped)
         K.gn_relu_fwd_pair(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], yc, b[f"cls.stats{i}"], self.gn_ws),
@@ -692,6 +720,9 @@ class Engine:
         n = self.stacked_convs
         if self.tower_mode in ("pair", "hybrid", "pairbwd"):
             xc = xr = P
+            if self.p3:
+                K.split_planes(P, b["Pp"])
+                xc = xr = b["Pp"]
             for i in range(n):
                 xc, xr = self._tower_pair_fwd(i, xc, xr)
             if self.x3 and self.feat % 16 == 0 and os.environ.get("RADET_PRED_PATCH", "1") != "0":
@@ -836,9 +867,13 @@ class Engine:
                     ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
-                    K.gn_relu_bwd(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
-                                  p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
-                    x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
+                    if self.p3:
+                        K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                        p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
+                    else:
+                        K.gn_relu_bwd(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                      p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
+                    x = b[f"{t}.y{i - 1}"] if i > 0 else (b["Pp"] if self.p3 else b["P"])
                     wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 cc, cr = self.cls_tower[i], self.reg_tower[i]
                 dzc, dzr = b[f"cls.dz{i & 1}"], b[f"reg.dz{i & 1}"]
@@ -846,8 +881,8 @@ class Engine:
                     launch(K.conv_dgrad_pair, cc.geom, dict(x=dzc, w=cc.wft, y=b["cls.dy"]),
                                        dict(x=dzr, w=cr.wft, y=b["reg.dy"]), tile=self._ttile(cc, bwd=True, tag=tagged))
                 else:   # both write dL/dP: the second accumulates onto the first
-                    launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self._ttile(cc, bwd=True, tag=tagged))
-                    launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self._ttile(cr, bwd=True, tag=tagged))
+                    launch(K.conv_dgrad, cc.geom, dzc, cc.wft, dP, tile=self._ttile(cc, bwd=True, tag=tagged, pair=False))
+                    launch(K.conv_dgrad, cr.geom, dzr, cr.wft, dP, addend=dP, tile=self._ttile(cr, bwd=True, tag=tagged, pair=False))
         elif self.use_streams:
             side = self._side()
             self._fork(side)

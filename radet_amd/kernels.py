@@ -223,7 +223,7 @@ def _strided_dgrad_group(g):
             for c in cls:
                 starts.append(m)
                 m += -(-c["rows"] // 128) * 128
-            tab = np.full((kmax, m), -1, np.int32)
+            tab = np.full((kmax, _lib.load().radet_gather_table_rows(m)), -1, np.int32)   # row stride = the launcher's Mp
             orow = np.full(m, -1, np.int32)
             tids = [0] * 16
             for i, (c, s0) in enumerate(zip(cls, starts)):
@@ -390,13 +390,68 @@ STREAMK = 0x100000                        # * w (1..7): stream-K schedule with w
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
 
 
+P3 = 0x2000000                            # x / w arrive as bf16 plane triples (rows [3][C]); fp32 outputs
+P3_BK8 = 0x4000000                        # ... with a K step of 16 instead of 32 channels
+
+
+class Planes:
+    """A [rows, C] fp32 tensor stored as bf16 plane triples: `t` is a bf16 tensor [rows, 3 * C] whose row r holds
+    hi | mid | lo with hi + mid + lo == the fp32 value exactly (include/radet_hip.h, "planes").  Only the conv GEMMs read it."""
+
+    def __init__(self, rows, C, device=None, t=None):
+        self.rows, self.C = int(rows), int(C)
+        self.t = t if t is not None else torch.empty(self.rows, 3 * self.C, device=device, dtype=torch.bfloat16)
+
+    def __getitem__(self, sl):
+        assert isinstance(sl, slice) and sl.step in (None, 1)
+        v = self.t[sl]
+        return Planes(v.shape[0], self.C, t=v)
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def to_float(self):
+        out = torch.empty(self.rows, self.C, device=self.t.device)
+        merge_planes(self, out)
+        return out
+
+    @staticmethod
+    def from_float(x):
+        p = Planes(x.shape[0], x.shape[1], device=x.device)
+        split_planes(x, p)
+        return p
+
+
+def _isp(t):
+    return isinstance(t, Planes)
+
+
+def _ptr_any(t):
+    return _ptr(t.t) if _isp(t) else _ptr(t)
+
+
+def split_planes(src, dst):
+    """dst (Planes) = exact bf16 plane split of the 2-D fp32 tensor src (row stride may exceed the width)"""
+    assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1 and dst.C == src.shape[1]
+    _lib.call("radet_split_planes", C.c_void_p(src.data_ptr()), _ptr(dst.t), C.c_size_t(src.shape[0]), src.shape[1],
+              src.stride(0), _stream())
+
+
+def merge_planes(src, dst):
+    assert dst.dim() == 2 and dst.dtype == torch.float32 and dst.stride(1) == 1 and src.C == dst.shape[1]
+    _lib.call("radet_merge_planes", _ptr(src.t), C.c_void_p(dst.data_ptr()), C.c_size_t(dst.shape[0]), dst.shape[1],
+              dst.stride(0), _stream())
+
+
 def _is16(t):
-    return t is not None and t.dtype == torch.bfloat16
+    return t is not None and not _isp(t) and t.dtype == torch.bfloat16
 
 
 def _tile(g, tile, default, x=None, y=None):
     """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
     t = (tile or default) | (MATH_BF16 if g.math else 0)
+    if _isp(x):
+        return (t & ~(MATH_BF16 | 0x200)) | P3          # plane operands: 0x200 (the fp32 paths' K-step bit) has no meaning here
     if getattr(g, "x3", False) and not g.math and not _is16(x):
         t |= X3
     if _is16(x):
@@ -407,7 +462,7 @@ def _tile(g, tile, default, x=None, y=None):
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
     tile = _tile(g, tile, g.fwd_tile, x, y)
     ws = splitk_ws() if splitk else None
-    _lib.call("radet_conv2d_igemm", _ptr(x), _ptr(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
+    _lib.call("radet_conv2d_igemm", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
               g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
               _stream())
 
@@ -502,7 +557,7 @@ def autotune_wgrad(g, reps=None):
 def conv_fwd_pair(g, a, b, relu=False, tile=0):
     """a, b: dicts(x, w, bias, addend, mask, y) -- two convs of geometry g in one launch."""
     ws = splitk_ws()
-    q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
+    q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.fwd_table), g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu),
               _tile(g, tile, g.fwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
@@ -511,7 +566,7 @@ def conv_dgrad_pair(g, a, b, tile=0):
     """a, b: dicts(x=dy, w=wft, addend, mask, y=dx) -- two stride-1 dgrads of geometry g in one launch."""
     assert g.stride == 1
     ws = splitk_ws()
-    q = lambda d: [_ptr(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
+    q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.bwd_table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
               _tile(g, tile, g.bwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
 
@@ -542,12 +597,17 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
                       (32 if _is16(dy) else 16) if c["zero"] else kc, g.cin,
                       tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
         return
-    _lib.call("radet_conv2d_igemm", _ptr(dy), _ptr(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
+    _lib.call("radet_conv2d_igemm", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
 
 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
+    if _isp(dy):
+        assert _isp(x)
+        _lib.call("radet_conv2d_wgrad", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
+                  g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x200 | (g.wgrad_flags & 0x40), _stream())
+        return
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
               g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit,
               (2 if _is16(dy) else (1 if g.math else (0x100 if getattr(g, "x3", False) else 0))) | g.wgrad_flags, _stream())
@@ -630,6 +690,27 @@ def gn_relu_fwd_pair(levels, a, b, eps=1e-5, relu=True):
     d, n = _gn_desc(levels)
     _lib.call(_h("radet_gn_relu_fwd_pair", a[0]), *[_ptr(t) for t in a], *[_ptr(t) for t in b], levels.B, 256, 32, eps,
               int(relu), d, n, _stream())
+
+
+def gn_relu_fwd_p(levels, z, gamma, beta, y, yp, stats, ws, eps=1e-5, relu=True):
+    """fp32 z -> y (fp32 tensor or None) and / or yp (Planes or None)"""
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_fwd_p", _ptr(z), _ptr(gamma), _ptr(beta), _ptr(y), _ptr_any(yp), _ptr(stats), _ptr(ws), levels.B,
+              256, 32, eps, int(relu), d, n, _stream())
+
+
+def gn_relu_fwd_pair_p(levels, a, b, eps=1e-5, relu=True):
+    """a / b = (z, gamma, beta, y or None, yp (Planes) or None, stats, ws)"""
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_fwd_pair_p", *[_ptr_any(t) for t in a], *[_ptr_any(t) for t in b], levels.B, 256, 32, eps,
+              int(relu), d, n, _stream())
+
+
+def gn_relu_bwd_p(levels, dy, z, stats, gamma, beta, dz, dzp, dgamma, dbeta, ws, relu=True):
+    """like gn_relu_bwd with dz as fp32 (or None) and / or Planes dzp (or None)"""
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_bwd_p", _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr_any(dzp),
+              _ptr(dgamma), _ptr(dbeta), _ptr(ws), levels.B, 256, 32, int(relu), d, n, _stream())
 
 
 def gn_relu_bwd(levels, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws, relu=True):

@@ -843,3 +843,97 @@ def test_cabi_error_codes(K):
     with pytest.raises(_lib.RadetHipError):                               # wgrad: dy row stride must hold whole float4s
         _lib.call("radet_conv2d_wgrad", K._ptr(y), K._ptr(x), K._ptr(y), None, K._ptr(g2.fwd_table), 64, 48, 32, 30, 1, 1, 1, 0,
                   K._stream())
+
+
+# ---------------------------------------------------------------------------------------------- plane operands
+PLANE_CASES = [
+    # B, Cin, Cout, H, W, k, stride, tile
+    (2, 64, 64, 20, 24, 1, 1, 3),
+    (2, 64, 256, 20, 24, 1, 1, 2),
+    (1, 128, 128, 17, 23, 3, 1, 3),            # ragged last M tile, image-border taps
+    (2, 256, 256, 30, 40, 3, 1, 1),
+    (2, 256, 256, 30, 40, 3, 1, 5),            # 128 x 128, 8 waves
+    (2, 256, 256, 30, 40, 3, 1, 6),            # 256 x 128, 8 waves
+    (1, 512, 512, 15, 20, 3, 1, 0x3003),       # forced split-K = 3
+    (4, 256, 256, 80, 80, 3, 1, 0x20001),      # 3 LDS stages, tail split
+    (1, 1024, 256, 15, 20, 1, 1, 0x2003),      # forced split-K = 2
+]
+
+
+@pytest.mark.parametrize("case", PLANE_CASES)
+def test_plane_operand_conv(K, case):
+    """radet_conv2d_igemm with x / w as bf16 plane triples (tile_override 0x2000000): the plane split is exact, and the
+    conv is held to the same fp64 reference and tolerance as the fp32 paths (forward with bias + residual + ReLU, dgrad
+    with mask); the 3x3 / 256-channel cases also run the plane-operand all-taps wgrad."""
+    B, Cin, Cout, H, W, k, s, tile = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    y_ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=pad)
+    Ho, Wo = y_ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g)
+    out_ref = F.relu(y_ref + res.double())
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    gx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride=s, padding=pad)
+
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    xr = to_rows(x).to(dev)
+    xp = K.Planes.from_float(xr)
+    assert torch.equal(xp.to_float(), xr)                       # hi + mid + lo == x, bit for bit
+    wp = K.Planes.from_float(fold_w(w).reshape(Cout * k * k, Cin).to(dev))
+    y = torch.empty(B * Ho * Wo, Cout, device=dev)
+    K.conv_fwd(geom, xp, wp, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)
+    assert rel_err(from_rows(y, B, Ho, Wo), out_ref) < 1e-5
+    dyr = to_rows(dy).to(dev)
+    dyp = K.Planes.from_float(dyr)
+    wtp = K.Planes.from_float(w.permute(1, 2, 3, 0).reshape(Cin * k * k, Cout).contiguous().to(dev))
+    dx = torch.empty(B * H * W, Cin, device=dev)
+    mask = to_rows(torch.randn(B, Cin, H, W, generator=g)).to(dev)
+    K.conv_dgrad(geom, dyp, wtp, dx, mask=mask, tile=tile)
+    gx_m = gx * (from_rows(mask.cpu(), B, H, W) > 0)
+    assert rel_err(from_rows(dx, B, H, W), gx_m) < 1e-5
+    if k == 3 and Cin % 32 == 0 and Cout == 256:
+        gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=s, padding=pad)
+        S = geom.nsplit
+        slabs = torch.empty(S, Cout, k * k, Cin, device=dev)
+        K.conv_wgrad(geom, dyp, xp, slabs)
+        gw_mine = slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        assert rel_err(gw_mine, gw) < 2e-5
+
+
+def test_plane_outputs_of_groupnorm_and_fold(K):
+    """GroupNorm + ReLU forward / backward with plane outputs == the fp32 outputs bit for bit (the split is exact)."""
+    dev = "cuda"
+    lv = K.Levels([(12, 16), (6, 8), (3, 4)], 2)
+    R = lv.rows
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(R, 256, generator=g).to(dev)
+    gam, bet = (torch.rand(256, generator=g) + 0.5).to(dev), (torch.randn(256, generator=g) * 0.1).to(dev)
+    stats = torch.empty(len(lv) * lv.B * 64, device=dev)
+    ws = torch.empty(K.gn_ws_floats(lv), device=dev)
+    y = torch.empty_like(z)
+    K.gn_relu_fwd(lv, z, gam, bet, y, stats, ws)
+    yp, y2 = K.Planes(R, 256, device=dev), torch.empty_like(z)
+    K.gn_relu_fwd_p(lv, z, gam, bet, y2, yp, stats, ws)
+    assert torch.equal(y2, y) and torch.equal(yp.to_float(), y)
+    yq, zb = K.Planes(R, 256, device=dev), torch.randn(R, 256, generator=g).to(dev)
+    yb = torch.empty_like(z)
+    stats_b, ws_b = torch.empty_like(stats), torch.empty_like(ws)
+    K.gn_relu_fwd_pair_p(lv, (z, gam, bet, None, yp, stats, ws), (zb, gam, bet, yb, yq, stats_b, ws_b))
+    K.gn_relu_fwd(lv, zb, gam, bet, y2, stats_b, ws_b)
+    assert torch.equal(yp.to_float(), y) and torch.equal(yq.to_float(), y2) and torch.equal(yb, y2)
+    dy = torch.randn(R, 256, generator=g).to(dev)
+    dz, dg, db = torch.empty_like(z), torch.empty(256, device=dev), torch.empty(256, device=dev)
+    K.gn_relu_bwd(lv, dy, z, stats, gam, bet, dz, dg, db, ws)
+    dzp, dg2, db2 = K.Planes(R, 256, device=dev), torch.empty(256, device=dev), torch.empty(256, device=dev)
+    K.gn_relu_bwd_p(lv, dy, z, stats, gam, bet, None, dzp, dg2, db2, ws)
+    assert torch.equal(dzp.to_float(), dz) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    # special values survive the split: zeros, tiny and huge magnitudes, a full 24-bit significand (inputs in fp32's own
+    # denormal range are outside the contract: their low planes are bf16 denormals)
+    v = torch.tensor([0.0, -0.0, 1e-30, -3.4e38, 1.0 + 2.0 ** -23, 2.0 ** -120, 65504.0, -(2.0 - 2.0 ** -23)] * 4, device=dev).reshape(1, 32)
+    back = K.Planes.from_float(v).to_float()
+    assert torch.equal(back, v), (back - v)

@@ -194,16 +194,18 @@ def test_config5_r101_800x800_bs2_full_size():
             x = torch.randn(g.lin.rows, 256, generator=gen).cuda()
             w = (torch.randn(256, 9, 256, generator=gen) * 0.02).cuda()
             y1, y2 = torch.empty(g.lout.rows, 256, device="cuda"), torch.empty(g.lout.rows, 256, device="cuda")
-            K.conv_fwd(g, x, w, None, y1, tile=e._ttile(e.cls_tower[0], tag=False))
-            K.conv_fwd(g, 2 * x, w / 4, None, y2, tile=e._ttile(e.cls_tower[0], tag=False))
+            # the tower GEMMs take plane operands by default (engine.p3): same property, operands in the towers' format
+            op = (lambda t: K.Planes.from_float(t.reshape(-1, 256))) if e.p3 else (lambda t: t)
+            K.conv_fwd(g, op(x), op(w), None, y1, tile=e._ttile(e.cls_tower[0], tag=False))
+            K.conv_fwd(g, op(2 * x), op(w / 4), None, y2, tile=e._ttile(e.cls_tower[0], tag=False))
             assert torch.equal(y2 * 2, y1)
-            K.conv_dgrad(g, x, w, y1, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False))
-            K.conv_dgrad(g, x * 0.5, w * 8, y2, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False))
+            K.conv_dgrad(g, op(x), op(w), y1, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False, pair=False))
+            K.conv_dgrad(g, op(x * 0.5), op(w * 8), y2, tile=e._ttile(e.cls_tower[0], bwd=True, tag=False, pair=False))
             assert torch.equal(y2 * 0.25, y1)
             S = g.nsplit
             s1, s2 = torch.empty(S, 256, 9, 256, device="cuda"), torch.empty(S, 256, 9, 256, device="cuda")
-            K.conv_wgrad(g, y1, x, s1)
-            K.conv_wgrad(g, y1 * 4, x * 0.5, s2)
+            K.conv_wgrad(g, op(y1), op(x), s1)
+            K.conv_wgrad(g, op(y1 * 4), op(x * 0.5), s2)
             assert torch.equal(s2 * 0.5, s1)
             lg = e.stages[2][5]["c2"].geom                             # a layer3 3x3 (50 x 50, M = 5000: split-K territory)
             x3 = torch.randn(lg.lin.rows, lg.cin, generator=gen).cuda()

@@ -861,7 +861,12 @@ class Engine:
             self._tower_bwd_head_async("cls")
             self._tower_bwd_head_async("reg")
             wg_done = {}
+            # plane-operand GEMMs own a CU's LDS per workgroup: a weight-gradient launch already running starves the other
+            # tower's GroupNorm backward of dispatch slots (20 -> 190 us per layer on the dependent chain), so with them both
+            # GroupNorms go first and the two weight-gradient GEMMs follow
+            gn_first = self.p3 and os.environ.get("RADET_GN_FIRST", "1") != "0"
             for i in range(n - 1, -1, -1):
+                pending = []
                 for t, tower in (("cls", self.cls_tower), ("reg", self.reg_tower)):
                     gn = f"bbox_head.{t}_convs.{i}.gn"
                     ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
@@ -874,6 +879,11 @@ class Engine:
                         K.gn_relu_bwd(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
                                       p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
                     x = b[f"{t}.y{i - 1}"] if i > 0 else (b["Pp"] if self.p3 else b["P"])
+                    if gn_first:
+                        pending.append((t, tower, x))
+                    else:
+                        wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
+                for t, tower, x in pending:
                     wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 cc, cr = self.cls_tower[i], self.reg_tower[i]
                 dzc, dzr = b[f"cls.dz{i & 1}"], b[f"reg.dz{i & 1}"]

@@ -431,9 +431,48 @@ def gen_model(det, assign):
     save("model", **out)
 
 
+def gen_model_grads(det, assign):
+    """Sampled gradient ELEMENTS of every trainable parameter (model.npz holds only their norms, which a tap transposition
+    or a sign error inside a tensor would preserve): same weights / batch as gen_model."""
+    B = 2
+    img = synth.synth_images(0, B)
+    tags = ["g8", "g3"]
+    gt_b = [torch.from_numpy(assign[t + "_boxes"]) for t in tags]
+    gt_l = [torch.from_numpy(assign[t + "_labels"]) for t in tags]
+    p2g = [torch.from_numpy(assign[t + "_p2g"].astype(np.int64)) for t in tags]
+    pw = [torch.from_numpy(assign[t + "_w"]) for t in tags]
+    det.train()
+    det.zero_grad()
+    losses = det(img=img, img_metas=synth.img_metas(B), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    loss, _ = det._parse_losses(losses)
+    loss.backward()
+    g = torch.Generator().manual_seed(11)
+    names, off, idx, val, rms = [], [0], [], [], []
+    for n, p in det.named_parameters():
+        if p.grad is None:
+            continue
+        k = min(48, p.numel())
+        i = torch.randperm(p.numel(), generator=g)[:k]
+        names.append(n)
+        idx.append(i.numpy().astype(np.int64))
+        val.append(p.grad.reshape(-1)[i].numpy())
+        rms.append(float(p.grad.double().pow(2).mean().sqrt()))
+        off.append(off[-1] + k)
+    save("model_grads", names=np.asarray(names), offsets=np.asarray(off, np.int64), idx=np.concatenate(idx),
+         val=np.concatenate(val), rms=np.asarray(rms, np.float64))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ops2":       # only the second op set (the other fixtures stay as committed)
         gen_ops2()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "grads":      # only model_grads.npz (inputs from the committed assigner.npz)
+        torch.manual_seed(0)
+        model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
+        det = build_detector(model_cfg, train_cfg=train_cfg, test_cfg=test_cfg)
+        synth.fill_state_dict(det.state_dict(), seed=0)
+        gen_model_grads(det, dict(np.load(os.path.join(HERE, "assigner.npz"))))
         return
     torch.manual_seed(0)
     model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
@@ -446,6 +485,7 @@ def main():
     synth.fill_state_dict(det.state_dict(), seed=0)
     gen_head(det, assign)
     gen_model(det, assign)
+    gen_model_grads(det, assign)
 
 
 if __name__ == "__main__":

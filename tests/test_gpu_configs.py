@@ -66,6 +66,66 @@ def test_train_step_vs_oracle(depth, H, W):
         if p.requires_grad:
             a, b = p.grad.double().norm().item(), og[n].double().norm().item()
             assert abs(a - b) <= 1e-3 * b + 1e-6 * tot, (n, a, b)
+    # element-wise: every parameter's gradient TENSOR against the oracle's (a norm survives a tap transposition)
+    from _grads import assert_grads_close
+    assert_grads_close({n: p.grad for n, p in det.named_parameters() if p.requires_grad}, og)
+
+
+def _headline_batch(B=4):
+    """bench.make_batch's inputs (the GPU assigner is the product path; the oracle gets the same targets)"""
+    import bench
+    img, boxes, labels, p2g, pw = bench.make_batch(0, B, torch.device("cuda"))
+    return (img, [torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels],
+            [t.cpu() for t in p2g], [t.cpu() for t in pw])
+
+
+@pytest.mark.parametrize("math", ["fp32", "fp32-mfma"])
+def test_headline_size_bs4_640x480_vs_oracle(math):
+    """BASELINE configs[1] at its full size -- r50, 640 x 480, bs 4, the bench's own batch -- against the CPU oracle: loss
+    triple within 1e-4 and every parameter's gradient TENSOR against the oracle's (tests/_grads.py: 3e-3 per parameter, median
+    5e-4 -- a wiring error is of order 1); both fp32
+    arithmetics (products from bf16 planes = the default, native fp32 MFMA)."""
+    from oracle import model as om, synth
+    from _grads import assert_grads_close
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(det.state_dict(), seed=0)
+    det = det.cuda().train()
+    rt = det.runtime(math=math)
+    img, gt_b, gt_l, p2g, pw = _headline_batch()
+    tg = rt.pack_targets(gt_b, gt_l, [t.cuda() for t in p2g], [t.cuda() for t in pw])
+    rt.forward(img)
+    losses = rt.loss(tg).clone().cpu()
+    rt.backward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    odet = om.OracleDetector(50, seed=0)
+    ol = odet.forward_train(img.cpu(), gt_b, gt_l, p2g, pw)
+    om.parse_losses(ol).backward()
+    for k, a in zip(("loss_cls", "loss_bbox", "loss_iou"), losses.tolist()):
+        assert abs(a - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), (k, a, ol[k].item())
+    mine = {n: rt.flat.g[n] for n in rt.flat.train_names}             # views of the gradient arena (after un-folding)
+    worst = assert_grads_close(mine, odet.named_grads())
+    print("worst parameter (||d||, ||g||):", worst)
+
+
+def test_r101_800x800_bs2_losses_vs_oracle():
+    """BASELINE configs[4] at its full size (R101, 800 x 800, bs 2): loss triple against the CPU oracle (forward + loss)."""
+    from oracle import model as om, synth
+    det = make(101)
+    img, gt_b, gt_l, p2g, pw = batch(800, 800, 2, G=(4, 2))
+    det.train()
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, 800, 800), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    odet = om.OracleDetector(101, seed=1)
+    with torch.no_grad():
+        ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), (k, losses[k].item(), ol[k].item())
 
 
 def test_empty_batch_and_batched_nms_branch():

@@ -78,6 +78,10 @@ def test_train_forward_backward(det, golden):
     bad = [(n, a, b) for n, a, b in zip(names, mine, ref) if abs(a - b) > 5e-4 * b + 1e-6 * float(g["total_grad_norm"])]
     assert not bad, bad[:10]
     assert all(named[n].grad is None for n in named if not named[n].requires_grad)
+    # the gradient tensors themselves against elements sampled from the reference's gradients (model_grads.npz)
+    from _grads import assert_sampled_grads
+    assert_sampled_grads({n: named[n].grad for n in names}, golden("model_grads"), atol_total=2e-6,
+                         total=float(g["total_grad_norm"]))      # (floor: see tests/_grads.py::assert_grads_close)
 
 
 def test_simple_test(det, golden):

@@ -238,6 +238,9 @@ def test_full_model_against_reference(golden):
     assert sorted(names) == sorted(grads.keys())
     mine = np.array([grads[n].double().norm().item() for n in names])
     assert np.allclose(mine, g["grad_norms"], rtol=2e-4, atol=1e-6 * float(g["total_grad_norm"]))
+    # ... and the gradient tensors themselves: sampled elements of every parameter's gradient, written by the reference
+    from _grads import assert_sampled_grads
+    assert_sampled_grads(grads, golden("model_grads"), atol_total=1e-7, total=float(g["total_grad_norm"]))
     dets = det.simple_test(img, synth.img_metas(2))
     for i, (db, dl) in enumerate(dets):
         ref = g[f"det_{i}"]

@@ -70,7 +70,28 @@ def main():
     out.append(f"{'kernel':72s} calls   sum_ms  avg_us  %busy")
     for k, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         out.append(f"{k:72s} {c:5d} {d / 1e6:8.3f} {d / c / 1e3:7.1f} {100.0 * d / busy:6.1f}")
+    # phases of the step, delimited by marker kernels (start of the first occurrence)
+    def first(prefix, last=False):
+        c = [r for r in ks if r[0].startswith(prefix)]
+        return (c[-1] if last else c[0]) if c else None
+    marks = [("backbone + neck forward", first("stem_kernel")), ("head forward", first("gn_stats_kernel")),
+             ("loss", first("loss_prep_rows_kernel")), ("head backward", first("gn_bwd_stats_kernel")),
+             ("neck backward", first("upsample_add_bwd_kernel")), ("backbone backward", first("relu_bwd_kernel")),
+             ("clip + AdamW", first("sqnorm_kernel"))]
+    marks = [(n, r[1]) for n, r in marks if r is not None]
+    if marks:
+        out.append("phases (wall between marker kernels; the head-forward marker is the first GroupNorm, one tower GEMM late):")
+        for i, (n, t) in enumerate(marks):
+            t_next = marks[i + 1][1] if i + 1 < len(marks) else t0 + wall
+            seg = [(a, st, e) for a, st, e, _ in ks if st >= t and st < t_next]
+            out.append(f"   {n:28s} +{(t - t0) / 1e6:7.3f} ms  {(t_next - t) / 1e6:7.3f} ms   summed kernel time "
+                       f"{sum(e - st for _, st, e in seg) / 1e6:7.3f} ms in {len(seg)} launches")
     txt = "\n".join(out)
+    if len(sys.argv) > 4:                  # flat kernel list of the median step
+        with open(sys.argv[4], "w") as fh:
+            fh.write("name,start_us,dur_us,queue\n")
+            for a, st, e, q in ks:
+                fh.write(f'"{a}",{(st - t0) / 1e3:.1f},{(e - st) / 1e3:.1f},{q}\n')
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(txt + "\n")
     print(txt)

@@ -399,10 +399,10 @@ def get_bboxes(cls_scores, bbox_preds, iou_preds, img_metas, test_cfg, rescale=T
 class OracleDetector:
     """State-dict-driven detector. `sd` tensors that are trainable get requires_grad=True."""
 
-    def __init__(self, depth=50, seed=None, test_cfg=None, math="fp32"):
+    def __init__(self, depth=50, seed=None, test_cfg=None, math="fp32", num_classes=NUM_CLASSES):
         from . import synth
-        self.depth, self.math = depth, math
-        self.sd = make_state_dict(depth)
+        self.depth, self.math, self.num_classes = depth, math, num_classes
+        self.sd = make_state_dict(depth, num_classes)
         if seed is not None:
             synth.fill_state_dict(self.sd, seed)
         for n, t in self.sd.items():
@@ -418,7 +418,7 @@ class OracleDetector:
     def forward_train(self, img, gt_bboxes, gt_labels, p2g, pw):
         with conv_math(self.math):
             outs = head(self.sd, self.extract_feat(img))
-        losses, _ = head_loss(*outs, gt_bboxes, gt_labels, p2g, pw)
+        losses, _ = head_loss(*outs, gt_bboxes, gt_labels, p2g, pw, num_classes=self.num_classes)
         return losses
 
     def simple_test(self, img, img_metas, rescale=True):

@@ -100,14 +100,17 @@ def save_checkpoint(model, path, meta=None, runtime=None):
     return path
 
 
-def load_checkpoint(model, path, strict=False, runtime=None):
+def load_checkpoint(model, path, strict=False, runtime=None, sync=True):
+    """Load a reference-format checkpoint.  With `runtime` and an initialised process group this is COLLECTIVE (sync=True):
+    every rank must call it, and all continue from rank 0's parameters / optimizer state / step counter -- so a file that
+    only rank 0 can read reaches every replica.  Pass sync=False for rank-local use (rank-0 evaluation, conversion)."""
     ckpt = torch.load(path, map_location="cpu")
     sd = ckpt.get("state_dict", ckpt)
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     missing = model.load_state_dict(sd, strict=strict)      # copies in place: parameters stay in the flat arena
     if runtime is not None and "optimizer" in ckpt and runtime.opt_state is not None:
         load_optimizer_state_dict(model, runtime, ckpt["optimizer"])
-    if runtime is not None:
+    if runtime is not None and sync:
         runtime.sync_replicas()                              # data-parallel: every rank continues from rank 0's state
     return ckpt.get("meta", {}), missing
 

@@ -293,10 +293,11 @@ __device__ __forceinline__ bool streamk_publish(const EpiArgs& a, f32x16 (&acc)[
     const bool last = ws[0] + nseg == nKs;
     __syncthreads();                                           // ws is LDS tile memory: the next segment's loads may reuse it
     if (!last) return false;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // every wave acquires for itself (agent scope: invalidates this CU's L1 before the partial tiles of other
+    // workgroups, published with write-through stores + a drained vmcnt + the ticket, are read with plain loads)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x == 0)
         __hip_atomic_store(&a.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -330,10 +331,10 @@ __device__ __forceinline__ void igemm_store(const EpiArgs& e, const ConvPtrs& P,
             ws[0] = __hip_atomic_fetch_add(&e.counters[ctile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (ws[0] != nsplit - 1) return;                       // uniform: not the last arriver of this tile
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // every wave acquires for itself (see streamk_publish)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0)
             __hip_atomic_store(&e.counters[ctile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i)

@@ -252,11 +252,14 @@ class Engine:
             self._plans = collections.OrderedDict()
         if self.geo_key is not None:
             self._plans[self.geo_key] = self._snapshot()          # most recently used goes last
+            requested = self._plans.pop(key, None)                # never evict the plan that is being asked for
             while len(self._plans) >= max(self.max_plans, 1):
                 # evict the least recently used plan (frees its buffers): nothing on any stream may still be using them
                 # when the caching allocator hands the blocks to the new plan
                 torch.cuda.synchronize()
                 self._plans.popitem(last=False)
+            if requested is not None:
+                self._plans[key] = requested
         self.geo_key = key
         if key in self._plans:
             self._restore(self._plans.pop(key))
@@ -493,7 +496,10 @@ class Engine:
         # mode) never change between steps: ~0.1 ms per step that sat in front of the stem on the main stream.  The
         # trainable convs change with every optimizer step (`params_changed()`), but not between inference calls.
         # A write through torch (load_state_dict, checkpoint load, replica sync, a torch optimizer) moves the tensors'
-        # version counters and is seen here; after a write torch does not track call `invalidate_fold()`.
+        # version counters and is seen here, as is a rebound `.data` (storage pointers are part of the key).  A write
+        # THROUGH `.data` (`p.data.copy_()`, an EMA hook) has a version counter of its own and is not: the module-level
+        # entry points that can follow user code invalidate explicitly (`RADet.train() / eval()`, `load_state_dict`,
+        # `RADet.invalidate_folded_weights()`), raw kernels call `invalidate_fold()`.
         vf, vt = self._part_version(0, nf), self._part_version(nf, n) + (self._param_epoch,)
         do_f = nf > 0 and vf != self._folded[0]
         do_t = nf < n and vt != self._folded[1]
@@ -536,7 +542,7 @@ class Engine:
                         watched += list(self.watch.get(k, (self.p[k],)))
             self._watched[key] = watched
         # (views of one arena share a version counter: a write to any of them re-folds the whole part -- conservative)
-        return (tuple(t._version for t in watched), tuple(t.data_ptr() for t in watched[:1]), self.h16, self.math)
+        return (tuple(t._version for t in watched), tuple(t.data_ptr() for t in watched), self.h16, self.math)
 
     def params_changed(self):
         """The trainable parameters were written by a kernel torch does not see (the fused clip + AdamW step)."""
@@ -725,7 +731,8 @@ class Engine:
                 xc = xr = b["Pp"]
             for i in range(n):
                 xc, xr = self._tower_pair_fwd(i, xc, xr)
-            if self.x3 and self.feat % 16 == 0 and os.environ.get("RADET_PRED_PATCH", "1") != "0":
+            if self.x3 and self.feat % 16 == 0 and self.pred_cls.cout <= 32 and self.pred_reg.cout + self.pred_iou.cout <= 32 \
+                    and os.environ.get("RADET_PRED_PATCH", "1") != "0":      # (the patch kernel's tile has 32 output columns)
                 # direct convolution from an LDS patch: the tower output is fetched 1.4 times instead of 9, reg + iou
                 # share one launch
                 pc, pr, pi = self.pred_cls, self.pred_reg, self.pred_iou

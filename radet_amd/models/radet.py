@@ -97,6 +97,23 @@ class RADet(nn.Module):
             rt.owner = weakref.ref(self)
         return rt
 
+    def invalidate_folded_weights(self):
+        """Re-fold the conv weights (BN scale, layouts, plane triples) on the next call.  Needed only after writing
+        parameters or BN statistics through `.data` (e.g. `p.data.copy_()`, an EMA hook) or with a raw kernel: writes
+        torch tracks -- `load_state_dict`, optimizers, `copy_` on the Parameter -- are seen by themselves."""
+        rt = self._runtime
+        if rt is not None:
+            rt.engine.invalidate_fold()
+
+    def train(self, mode=True):
+        # mode switches are rare and typically follow user code (checkpoint surgery, EMA swaps): fold again afterwards
+        self.invalidate_folded_weights()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_folded_weights()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     # ------------------------------------------------------------------ reference API
     def extract_feat(self, img):
         return self.runtime().extract_feat_api(img)

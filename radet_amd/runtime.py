@@ -174,7 +174,8 @@ class DetectorRuntime:
         self.buckets = compute_buckets(self.flat, [c.name for c in self.engine.convs],
                                        [c.trainable for c in self.engine.convs])
         self.reducer = None
-        self.sync_replicas()       # data-parallel replicas start from rank 0's parameters (DDP's initial broadcast)
+        # (no collective here: a runtime may be built by a subset of the ranks -- rank-0 evaluation, checkpoint
+        # conversion.  Data-parallel replicas are equalised by init_optimizer(), the entry point of every training run.)
 
     def sync_replicas(self, src=0):
         """Broadcast the parameter arenas (trainable + frozen / BN statistics) and, once it exists, the optimizer
@@ -279,12 +280,17 @@ class DetectorRuntime:
                 bucket_hook(bucket)
 
     # ------------------------------------------------------------------ optimiser
-    def init_optimizer(self, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0):
+    def init_optimizer(self, lr=4e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, max_norm=35.0, sync=True):
+        """AdamW state for the trainable arena.  COLLECTIVE when a process group is initialised (sync=True): every rank
+        must call it; the replicas then start from rank 0's parameters -- the broadcast MMDistributedDataParallel does at
+        construction in the reference (radet/apis/train.py:73-81)."""
         n = self.flat.n_train
         self.opt_state = dict(m=torch.zeros(n, device=self.dev), v=torch.zeros(n, device=self.dev), lr=lr, betas=betas,
                               eps=eps, wd=weight_decay, max_norm=max_norm,
                               partials=torch.zeros(1024, device=self.dev), grad_norm=torch.zeros(1, device=self.dev))
         self.step_count = 0
+        if sync:
+            self.sync_replicas()
 
     def optimizer_step(self, lr=None, grad_div=1.0):
         st = self.opt_state
@@ -511,7 +517,10 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
             with torch.cuda.graph(graph, stream=cap_stream):    # the parameters of the moment, like the eager path
                 self.forward(static_img)
                 outs = _post_launch(self, hw, sf, test_cfg)
-            g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs, plan=self.engine.buf)
+            # the captured launches hold raw pointers into the decode / NMS workspaces: the record keeps them alive when
+            # the `_posts` cache drops its reference
+            g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs, plan=self.engine.buf,
+                                  keep=list(self.__dict__.get("_posts", {}).values()))
         else:
             hw, sf = _meta_tensors(self, img_metas, rescale)
             g["hw"].copy_(hw)

@@ -289,3 +289,54 @@ def test_bf16_storage_inference_close_to_fp32(monkeypatch):
     for a_, b_ in zip(outs["fp32"][:3], outs["bf16-storage"][:3]):
         err = (a_ - b_).abs().max().item()
         assert err <= 0.05 * a_.std().item() + 0.03 * a_.abs().max().item(), (err, a_.std().item(), a_.abs().max().item())
+
+
+def test_head_with_more_than_32_classes():
+    """num_classes = 40: the predictor convs do not fit the 32-column LDS-patch kernel and must take the implicit-GEMM
+    path (forward, loss, backward, detection) -- against the oracle."""
+    from oracle import model as om, synth
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    cfg.model["bbox_head"]["num_classes"] = 40
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(det.state_dict(), seed=2)
+    det = det.cuda().train()
+    H, W = 160, 192
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2, G=(3, 2))
+    gt_l = [l + 17 for l in gt_l]                          # labels up to 37
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    sum(losses.values()).backward()
+    odet = om.OracleDetector(50, seed=2, num_classes=40)      # same seeded weights by parameter name
+    ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+    om.parse_losses(ol).backward()
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), k
+    from _grads import assert_grads_close
+    # (K = 48 after padding: the cls predictor's dgrad / wgrad run on the native fp32 MFMA, whose distance to the CPU
+    # oracle is ~3e-4 per GEMM -- tools/_probe/gradcmp.py -- and every gradient passes through it)
+    assert_grads_close({n: p.grad for n, p in det.named_parameters() if p.requires_grad}, odet.named_grads(),
+                       rtol=5e-3, median_rtol=2e-3)
+    assert det.runtime().engine.pred_cls.cout == 40
+
+
+def test_stale_data_write_is_refolded():
+    """A parameter written through `.data` (its own version counter: the engine cannot see it) is picked up after
+    `invalidate_folded_weights()` / a train()-eval() switch; a tracked write (copy_ on the Parameter) by itself."""
+    from oracle import synth
+    det = make(50).eval()
+    img = synth.synth_images(9, 1, 128, 160).cuda()
+    with torch.no_grad():
+        ref0 = torch.cat([f.reshape(-1) for f in det.extract_feat(img)]).clone()
+        w = det.neck.fpn_convs[0].conv.weight
+        w.data.mul_(2.0)                                     # untracked
+        det.invalidate_folded_weights()
+        a = torch.cat([f.reshape(-1) for f in det.extract_feat(img)]).clone()
+        assert not torch.equal(a, ref0)
+        w.data.mul_(0.5)
+        det.train(); det.eval()                              # mode switches fold again
+        assert torch.equal(torch.cat([f.reshape(-1) for f in det.extract_feat(img)]), ref0)
+        w.mul_(2.0)                                          # tracked by torch: seen without help
+        assert torch.equal(torch.cat([f.reshape(-1) for f in det.extract_feat(img)]), a)

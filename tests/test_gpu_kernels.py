@@ -937,3 +937,36 @@ def test_plane_outputs_of_groupnorm_and_fold(K):
     v = torch.tensor([0.0, -0.0, 1e-30, -3.4e38, 1.0 + 2.0 ** -23, 2.0 ** -120, 65504.0, -(2.0 - 2.0 ** -23)] * 4, device=dev).reshape(1, 32)
     back = K.Planes.from_float(v).to_float()
     assert torch.equal(back, v), (back - v)
+
+
+def test_split_k_in_launch_reduction_under_uneven_load(K):
+    """The in-launch split-K reduction (write-through partial tiles, arrival ticket, per-wave agent acquire in the last
+    arriver) repeated 3000 times while another stream keeps the chip unevenly busy, with a tile count that puts the
+    splits of one tile on different XCDs: every launch must reproduce the first result bit for bit, for the fp32 kernels
+    and the plane-operand kernel (8 waves)."""
+    dev = "cuda"
+    B, Cin, Cout, H, W = 1, 512, 192, 15, 20                 # 5 x 3 = 15 tiles of 64 x 64: 15 % 8 != 0
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, 3, 1, 1)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(lv.rows, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout * 9, Cin, generator=g) * 0.02).to(dev)
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(4096, 4096, device=dev)
+    for mode in ("fp32", "x3", "planes"):
+        geom.x3 = mode == "x3"
+        xs, ws = (K.Planes.from_float(x), K.Planes.from_float(w)) if mode == "planes" else (x, w.view(-1))
+        tile = (5 if mode == "planes" else 3) | 0x5000       # forced split-K = 5
+        y0, y = torch.empty(lv.rows, Cout, device=dev), torch.empty(lv.rows, Cout, device=dev)
+        K.conv_fwd(geom, xs, ws, None, y0, tile=tile)
+        torch.cuda.synchronize()
+        bad = 0
+        for it in range(3000):
+            if it % 50 == 0:
+                with torch.cuda.stream(side):                # bursts of unrelated work: uneven load, dirty L2 lines
+                    noise_a.mul_(1.0001)
+            K.conv_fwd(geom, xs, ws, None, y, tile=tile)
+            if it % 100 == 99:
+                bad += int(not torch.equal(y, y0))
+        torch.cuda.synchronize()
+        assert bad == 0 and torch.equal(y, y0), (mode, bad)

@@ -128,6 +128,127 @@ def cpu_baseline(steps=3):
                        f"step's work), best of {n_timed} timed step(s), {nthreads} threads")
 
 
+def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
+    """`roofline` (+ companions) from the per-launch HIP events of the instrumented pass.
+    Per kernel instantiation: launches per step, average duration in the step, algorithmic flops, share of the summed
+    conv-GEMM time.  `roofline` = the instantiation with the LARGEST share, in the step and alone on the device (every
+    distinct launch of it replayed by itself); `roofline_all_conv_gemms` = all of them together; `roofline_tower_forward` =
+    the grouped head-tower forward launch (the kernel the previous rounds reported).  The plane arithmetics issue 6 bf16
+    MACs per algorithmic fp32 MAC: `achieved` is priced in issued bf16 flop against the dense bf16 MFMA peak, the
+    fp32-equivalent rate is next to it."""
+    fam = {}
+    for ev in events:
+        f = fam.setdefault(ev["key"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, evs=[]))
+        d = ev["start"].elapsed_time(ev["end"])
+        f["n"] += 1; f["ms"] += d; f["flops"] += ev["flops"]; f["bytes"] += ev["bytes"]; f["evs"].append(ev)
+    tot_ms = sum(f["ms"] for f in fam.values())
+    tot_fl = sum(f["flops"] for f in fam.values())
+    def igemm_tag(k):                       # TAG template argument of a conv_igemmg_kernel<BM, BN, WM, WN, TAG, BK, NSTG, SK> key
+        if not k.startswith("conv_igemmg_kernel<") or "heuristic" in k:
+            return None
+        return int(k.split("<")[1].split(">")[0].split(", ")[4])
+
+    def planes(k):                          # launches whose products are formed from bf16 planes (6 bf16 MACs per fp32 MAC)
+        t = igemm_tag(k)
+        return (t is not None and (t & 24) != 0) or "pred3x3" in k or ("wgrad" in k and ("planes" in k or "9p" in k))
+
+    def entry(k, f, alone=False):
+        mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if planes(k) else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        e = {"kernel": k, "launches_per_step": round(f["n"] / steps, 2), "avg_us": round(f["ms"] / f["n"] * 1e3, 2),
+             "flop_per_launch": f["flops"] / f["n"], "algorithmic_bytes_per_launch": round(f["bytes"] / f["n"]),
+             "share_of_conv_gemm_time": round(f["ms"] / tot_ms, 4),
+             "algorithmic_tflops": round(tf, 2), "achieved": round(tf * mult, 2), "peak": peak, "unit": "TFLOP/s",
+             "frac": round(tf * mult / peak, 4), "bound": "mfma"}
+        if alone:                           # every distinct launch of one step replayed alone (3 warm + 5 timed, back to back)
+            per_step = f["evs"][:max(1, f["n"] // steps)]
+            a_ms = 0.0
+            for ev in per_step:
+                for _ in range(3):
+                    ev["replay"]()
+                torch.cuda.synchronize()
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                for _ in range(5):
+                    ev["replay"]()
+                e_.record(); e_.synchronize()
+                a_ms += s_.elapsed_time(e_) / 5
+            a_tf = sum(ev["flops"] for ev in per_step) / (a_ms * 1e-3) / 1e12
+            e["alone"] = {"avg_us": round(a_ms / len(per_step) * 1e3, 2), "algorithmic_tflops": round(a_tf, 2),
+                          "achieved": round(a_tf * mult, 2), "frac": round(a_tf * mult / peak, 4),
+                          "note": "the same launches one at a time on an otherwise idle device"}
+        return e
+    order = sorted(fam.items(), key=lambda kv: -kv[1]["ms"])
+    dom_k, dom = order[0]
+    roof = entry(dom_k, dom, alone=True)
+    traffic, tnote = None, None             # HBM bytes / launch from the committed PMC passes, if they cover this kernel
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("kernel", "").replace(" ", "") == dom_k.replace(" ", ""):
+            traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
+    roof["traffic"] = traffic
+    if tnote:
+        roof["traffic_note"] = tnote
+    roof["selection"] = ("largest share of the summed conv-GEMM kernel time of the step (HIP events around every conv launch, "
+                         "second pass of the same K steps)")
+    mult_all = 6.0 if x3 else 1.0
+    peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+    all_tf = tot_fl / (tot_ms * 1e-3) / 1e12
+    rep = {"roofline": roof,
+           "roofline_all_conv_gemms": {
+               "bound": "mfma", "flop_per_step": tot_fl / steps, "summed_kernel_ms_per_step": round(tot_ms / steps, 3),
+               "algorithmic_tflops_over_summed_kernel_time": round(all_tf, 2),
+               "achieved": round(all_tf * mult_all, 2), "peak": peak_all, "unit": "TFLOP/s", "frac": round(all_tf * mult_all / peak_all, 4),
+               "step_level": {"algorithmic_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
+                              "achieved": round(value * TRAIN_FLOP_PER_IMG / 1e12 * mult_all, 2),
+                              "frac": round(value * TRAIN_FLOP_PER_IMG / 1e12 * mult_all / peak_all, 4),
+                              "note": "images/s x 341.1 GFLOP/img (SURVEY 8d) over the wall time of the step: streams overlap, so this is above the summed-kernel-time figure"},
+               "kernels": [entry(k, f) for k, f in order[:8]]},
+           "kernel_events": {"ms_per_step_with_events": round(dt_ev / steps * 1e3, 3), "ms_per_step": round(ms_clean, 3),
+                             "conv_launches_per_step": round(len(events) / steps, 1)}}
+    tower = [(k, f) for k, f in order if abs(f["flops"] / f["n"] - 2.0 * rt.engine.tower_gemm_flops()) < 1.0 and
+             igemm_tag(k) is not None and (igemm_tag(k) & 1)]            # the tagged symbol: grouped forward launches only
+    if tower:
+        rep["roofline_tower_forward"] = entry(*tower[0])
+        rep["roofline_tower_forward"]["note"] = ("grouped cls_convs[i] + reg_convs[i] forward launch (2 GEMMs of M = B*6400, N = 256, "
+                                                 "K = 2304), alone on the device in the step")
+    return rep
+
+
+def _child(argv, timeout=900):
+    import subprocess
+    r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not line:
+        raise RuntimeError((r.stderr or r.stdout)[-300:])
+    return json.loads(line[-1])
+
+
+def extras(args):
+    """Secondary measurements, each in a child process (its own streams / hardware queues): BASELINE configs[3] (inference)
+    and configs[4] (R101 800x800 bs 2) as short runs, and the headline step on seeded trained-like parameters."""
+    out = {}
+    cfgs = os.path.join(ROOT, "tools", "bench_configs.py")
+    for key, argv in (("infer", [cfgs, "infer", "--json", "--images", "200"]), ("r101", [cfgs, "r101", "--json", "--steps", "8"])):
+        try:
+            out[key] = _child(argv)
+        except Exception as e:                   # the headline line must not depend on the secondary runs
+            out[key] = {"error": repr(e)[:200]}
+    try:
+        d = _child([os.path.abspath(__file__), "--weights", "synth", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                    "--no-cpu-baseline", "--no-kernel-events", "--no-mfma-line", "--no-extras"])
+        out["synthetic_trained_like_weights"] = {
+            "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"],
+            "note": "same step, `python bench.py --weights synth`: seeded trained-like parameters / running statistics "
+                    "(radet_amd/utils/synth_init.py) -> dense, decorrelated activations; the plane arithmetic runs against "
+                    "the power envelope, so its speed depends on the operands' bit activity (DESIGN.md 6)"}
+    except Exception as e:
+        out["synthetic_trained_like_weights"] = {"error": repr(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +257,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-mfma-line", action="store_true", help="skip the native-f32-MFMA comparison measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (inference config 4, R101 config 5, synthetic trained-like weights)")
+    ap.add_argument("--weights", choices=("init", "synth"), default="init",
+                    help="init = the detector's own random initialisation (headline); synth = seeded trained-like parameters "
+                         "and running statistics (radet_amd/utils/synth_init.py): dense, decorrelated activations")
     ap.add_argument("--math", choices=("fp32", "fp32-mfma", "bf16", "bf16-storage"), default="fp32",
                     help="fp32 = the headline metric (BASELINE configs[1]); bf16 = configs[2] arithmetic: conv operands "
                          "rounded to bf16 into the matrix cores, fp32 accumulate / storage / optimizer (secondary line)")
@@ -158,6 +284,9 @@ def main():
     cfg.model["pretrained"] = None
     torch.manual_seed(0)                      # identical replicas on every rank
     det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).to(device).train()
+    if args.weights == "synth":
+        from radet_amd.utils.synth_init import synth_fill
+        synth_fill(det, seed=0)
     rt = det.runtime(math=args.math)
     o = cfg.optimizer
     rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
@@ -179,8 +308,6 @@ def main():
         if first is None:
             first = out_l.clone()
     sync()
-    events = None if args.no_kernel_events else []
-    rt.engine.tower_events = events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_l = rt.train_step(img, tg)
@@ -190,8 +317,21 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    rt.engine.tower_events = None
     losses = rt.engine.losses.cpu().numpy()
+    # the same K steps once more with a pair of HIP events around EVERY conv GEMM launch, on the stream it is launched on
+    # (radet_amd.kernels.EVENTS): the per-kernel table behind `roofline`.  Kept out of the region above so that `value` is
+    # the uninstrumented step; the instrumented step time is reported next to it.
+    events, dt_ev = None, None
+    if rank == 0 and world == 1 and not args.no_kernel_events:
+        from radet_amd import kernels as K
+        torch.cuda.synchronize()
+        K.EVENTS = events = []
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            rt.train_step(img, tg)
+        torch.cuda.synchronize()
+        dt_ev = time.perf_counter() - t1
+        K.EVENTS = None
     assert np.isfinite(losses).all(), f"non-finite losses {losses}"
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -224,47 +364,15 @@ def main():
         else:
             out["metric"] += " [bf16 math mode: NOT the headline fp32 metric]"
             out["config"]["workload"] = out["config"]["workload"].replace("fp32", "bf16-math").replace("configs[1]", "configs[2] arithmetic")
-        if events and args.math.startswith("fp32"):
-            traffic = None          # HBM bytes/launch of the roofline kernel from the committed PMC pass (offline)
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json" if x3 else "roofline_traffic_fp32_mfma.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get("traffic_bytes_per_launch")
-            ms_list = [s.elapsed_time(e) for s, e in events]
-            avg_ms = float(np.mean(ms_list))
-            # pair mode: most tower launches are grouped (cls + reg layer in one launch = 2x the flops)
-            flops = rt.engine.tower_gemm_flops()
-            pair = rt.engine.tower_mode == "pair"
-            hybrid = rt.engine.tower_mode in ("hybrid", "pairbwd")
-            if hybrid:
-                flops = flops * 2.0     # every tagged launch = cls_convs[i] + reg_convs[i] grouped, forward only
-            if pair:
-                n_per_step = len(ms_list) // args.steps
-                # per step: 4 fwd pairs + 3 dgrad pairs (2 GEMMs each) + 2 single dgrads into dL/dP
-                flops = flops * 16.0 / n_per_step
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            # x3: the kernel runs on the bf16 matrix pipe and issues 6 bf16 MACs per algorithmic f32 MAC: priced against
-            # the dense bf16 MFMA peak with the flops it actually issues; the f32-equivalent rate is given next to it
-            issued, peak = (6.0 * ach, BF16_MFMA_PEAK_TFLOPS) if x3 else (ach, FP32_MFMA_PEAK_TFLOPS)
-            out["roofline"] = {"bound": "mfma", "achieved": round(issued, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(issued / peak, 4), "traffic": traffic,
-                               "algorithmic_tflops": round(ach, 2), "frac_of_fp32_mfma_peak": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "kernel": ("conv_igemmg_kernel<128,128,2,2,TAG=9,BK=32,NSTG=2> (f32 operands split into 3 bf16 planes, "
-                                          "6 v_mfma_f32_32x32x16_bf16 per K=16 step; `achieved` = issued bf16 flop = 6 x algorithmic)"
-                                          if x3 else "conv_igemmg_kernel<128,64,2,2,TAG=1,BK=32,NSTG=3>")
-                                         + ": head-tower 3x3 conv GEMM (M=B*6400, N=256, K=2304)"
-                                         + ("; forward launches, cls_convs[i] + reg_convs[i] grouped per launch (2 GEMMs), alone on the device"
-                                            if hybrid else "; fwd+dgrad launches, cls+reg layers grouped per launch, flop_per_launch = average"
-                                            if pair else "; fwd+dgrad launches, cls and reg towers run concurrently on two streams"),
-                               "launches": len(ms_list), "avg_us": round(avg_ms * 1e3, 2),
-                               "flop_per_launch": flops}
+        if events:
+            out.update(kernel_report(events, args.steps, rt, x3, dt_ev, ms, value))
         if world == 1 and x3 and not args.no_mfma_line:
             # the same step with the native f32 matrix instruction: a child process (its own streams and hardware
             # queues; measured inside this process after the main run it shared queues with the first runtime)
             import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--math", "fp32-mfma", "--steps", str(args.steps),
-                                    "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-kernel-events"],
+                                    "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-kernel-events", "--no-extras"],
                                    capture_output=True, text=True, timeout=600)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
                 d2 = json.loads(line)
@@ -273,6 +381,8 @@ def main():
                                            "note": "same step, `python bench.py --math fp32-mfma` (v_mfma_f32_32x32x2_f32), child process"}
             except Exception as e:      # the headline line must not depend on the comparison run
                 out["fp32_mfma_native"] = {"error": repr(e)[:200]}
+        if world == 1 and args.math == "fp32" and args.weights == "init" and not args.no_extras:
+            out.update(extras(args))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

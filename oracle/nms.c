@@ -160,7 +160,23 @@ void oracle_cluster_nms(const float *boxes, const float *scores, const int64_t *
 }
 
 /* mmcv-style batched hard NMS: boxes offset by label*(max_coord+1) (fp32), greedy, IoU > thr
- * suppresses.  keep[] receives kept input indices in descending-score order. Returns count. */
+ * suppresses.  keep[] receives kept input indices in descending-score order. Returns count.
+ *
+ * PARITY UNPINNED (mmcv 1.3.18 is neither in /root/reference nor in this image).  Knife-edges this
+ * restatement had to decide without a reference to check against:
+ *   1. the comparison at exact equality: a box is suppressed when IoU > thr (strict), the rule of
+ *      mmcv's CPU `nms` (nms_cpu: `if (ovr > iou_threshold) suppressed = 1`), which is the path the
+ *      north star's "PyTorch-CPU" reference takes.  mmcv's CUDA kernel (nms_cuda: `devIoU(...) >
+ *      threshold` on a bit-mask tile) is strict as well in 1.3.x to the builder's recollection, but
+ *      the two were written independently and nobody can run either here: IoU == thr exactly is
+ *      undecided by any fixture.  tests/test_gpu_kernels.py::test_nms_ops_bit_exact holds the HIP
+ *      kernel to THIS rule (oracle and kernel agree on ties by construction);
+ *   2. the IoU denominator: area_a + area_b - inter with offset = 0 (no "+1" pixel convention),
+ *      no epsilon; a zero-area pair gives 0/0 = NaN, which compares false (kept);
+ *   3. the class offset is added in fp32 before the IoU (as mmcv does), so coordinates above 2^24 /
+ *      (labels + 1) lose low bits exactly as in mmcv;
+ *   4. score ties: descending score, then ascending input index (torch.sort's order for equal keys
+ *      is unspecified; fixtures avoid ties). */
 int64_t oracle_batched_nms(const float *boxes, const float *scores, const int64_t *labels, int64_t n,
                            float thr, int class_agnostic, int64_t *keep) {
     float *ob = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));

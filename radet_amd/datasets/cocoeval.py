@@ -4,7 +4,19 @@
 pycocotools is not part of the reference tree nor of this image, so this is a restatement of its published algorithm
 (cocoeval.py of pycocotools 2.0.x: per image / category / area range greedy matching in descending score order,
 101-point interpolated precision, the 12 summary statistics).  PARITY UNPINNED against pycocotools itself; checked
-on hand-worked cases in tests/test_bop.py.  Pure host code: no kernels, no GPU."""
+on hand-worked cases in tests/test_bop.py.  Pure host code: no kernels, no GPU.
+
+Knife-edges decided here from the published algorithm, with nothing to check them against:
+  * matching: a detection takes the unmatched gt with the HIGHEST IoU among those with IoU >= min(t, 1 - 1e-10) (pycocotools
+    starts `iou = min([t, 1 - 1e-10])` and skips candidates with `ious < iou`, i.e. equality at the threshold MATCHES);
+    equal IoUs keep the first gt in the evaluator's order (non-ignored gts first, then ignored / crowd);
+  * detections are ranked by score with a STABLE merge sort (`np.argsort(-score, kind="mergesort")`), so equal scores keep
+    file order -- per image and again across images in accumulate();
+  * area ranges are closed on both ends (`area < lo or area > hi` is out of range); bbox areas come from the annotation's
+    `area` field for gts and w * h for detections;
+  * precision = tp / (tp + fp + eps) with eps = np.spacing(1), recall thresholds searched with `np.searchsorted(..., "left")`,
+    empty categories / ranges report -1;
+  * `segm` and `proposal_fast` are not implemented (boxes only)."""
 import collections
 import copy
 import json

@@ -67,6 +67,48 @@ class _LRU(dict):
 
 
 _TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometry (~80 per (B, H, W) plan)
+
+# Measurement hook (bench.py): when EVENTS is a list, every conv GEMM launch issued through this module is bracketed by a
+# pair of HIP events on the stream it is launched on and appended as dict(key, flops, start, end, replay).  `key` names
+# the kernel instantiation the launcher dispatches to, `flops` = 2 * rows * Cout * Cin * taps of the launch (x 2 for a
+# grouped pair), `replay()` issues the same launch again (same buffers) for the "alone on the device" timing.
+EVENTS = None
+_TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2"}
+
+
+def _igemm_key(t, x):
+    """kernel symbol an implicit-GEMM launch with tile_override word t dispatches to (conv_igemm.hip: igemm_impl)"""
+    tid = t & 0xFF
+    if tid == 0:
+        return "conv_igemmg_kernel<launcher heuristic>"
+    if t & P3:
+        tag, bk = 16 | ((t >> 8) & 1), 16
+    elif t & STORE_BF16:
+        tag, bk = 4 | ((t >> 8) & 1), 32 if t & 0x200 else 16
+    elif t & X3:
+        tag, bk = 8 | ((t >> 8) & 1), 32
+    else:
+        tag, bk = ((t >> 8) & 1) | (2 if t & MATH_BF16 else 0), 32 if t & 0x200 else 16
+    skw = (t >> 20) & 7
+    stages = 3 if (t & STAGES3) and (tag < 2 or tag & 24) and not skw else 2
+    return f"conv_igemmg_kernel<{_TILES[tid]}, {tag}, {bk}, {stages}, {'true' if skw and tag == 0 else 'false'}>"
+
+
+def _timed(key, flops, fn, nbytes=0.0):
+    ev = EVENTS
+    if ev is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    ev.append(dict(key=key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn))
+
+
+def _conv_bytes(g, groups=1):
+    """algorithmic HBM bytes of one conv launch at fp32: input once + weights + output once"""
+    return 4.0 * groups * (g.lin.rows * g.cin + g.cout * g.k * g.k * g.cin + g.lout.rows * g.cout)
+
 STRIDED_DGRAD_CLASSES = True   # parity-class dgrad for strided convs (False = one dense launch)
 
 
@@ -462,9 +504,13 @@ def _tile(g, tile, default, x=None, y=None):
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
     tile = _tile(g, tile, g.fwd_tile, x, y)
     ws = splitk_ws() if splitk else None
-    _lib.call("radet_conv2d_igemm", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(g.fwd_table),
-              g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
-              _stream())
+    table = g.fwd_table
+
+    def launch():
+        _lib.call("radet_conv2d_igemm", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
+                  g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
+                  _stream())
+    _timed(_igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g))
 
 
 def _pred_tiles(lv):
@@ -490,8 +536,9 @@ def pred_conv_patch(lv, x, a, b=None):
     t = _pred_tiles(lv)
     cin = x.shape[1]
     w1, b1, y1, c1 = b if b is not None else (None, None, None, 0)
-    _lib.call("radet_pred3x3_patch", _ptr(x), cin, _ptr(t), t.shape[0], _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), a[3],
-              _ptr(w1), _ptr(b1), _ptr(y1), c1, _stream())
+    _timed("pred3x3_patch_kernel", 2.0 * lv.rows * (a[3] + c1) * cin * 9,
+           lambda: _lib.call("radet_pred3x3_patch", _ptr(x), cin, _ptr(t), t.shape[0], _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), a[3],
+                             _ptr(w1), _ptr(b1), _ptr(y1), c1, _stream()))
 
 
 _WTUNE_CACHE = _LRU(8192)
@@ -558,8 +605,10 @@ def conv_fwd_pair(g, a, b, relu=False, tile=0):
     """a, b: dicts(x, w, bias, addend, mask, y) -- two convs of geometry g in one launch."""
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
-    _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.fwd_table), g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu),
-              _tile(g, tile, g.fwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
+    t, table = _tile(g, tile, g.fwd_tile, a["x"], a["y"]), g.fwd_table
+    _timed(_igemm_key(t, a["x"]), 4.0 * g.lout.rows * g.cout * g.cin * g.k * g.k,
+           lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lout.rows, g.cin, g.cout, g.k, g.k,
+                             int(relu), t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
 
 
 def conv_dgrad_pair(g, a, b, tile=0):
@@ -567,8 +616,10 @@ def conv_dgrad_pair(g, a, b, tile=0):
     assert g.stride == 1
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
-    _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(g.bwd_table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
-              _tile(g, tile, g.bwd_tile, a["x"], a["y"]), _ptr(ws), C.c_size_t(ws.numel()), _stream())
+    t, table = _tile(g, tile, g.bwd_tile, a["x"], a["y"]), g.bwd_table
+    _timed(_igemm_key(t, a["x"]), 4.0 * g.lin.rows * g.cout * g.cin * g.k * g.k,
+           lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
+                             t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
@@ -579,6 +630,18 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
     kc = g.cout if k_channels is None else k_channels
     tile = _tile(g, tile, g.bwd_tile, dy, dx)
     ws = splitk_ws() if splitk else None
+    if EVENTS is not None:
+        # algorithmic work of the dgrad = that of the forward conv (a strided conv's dgrad touches each weight tap once
+        # per output pixel; the padded K of the small predictor heads is not counted)
+        real_k = min(kc, g.cout)
+        _timed(_igemm_key(tile, dy) + (" [strided dgrad, class launch]" if g.stride > 1 else ""),
+               2.0 * g.lout.rows * real_k * g.cin * g.k * g.k,
+               lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows), _conv_bytes(g))
+        return
+    _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows)
+
+
+def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows):
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         grp = _strided_dgrad_group(g)
         if grp is not None:
@@ -601,7 +664,29 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
 
 
+def _wgrad_key(g, dy, co):
+    if _isp(dy):
+        return "conv_wgrad9p_kernel"
+    nine = g.k == 3 and g.cin % 32 == 0 and co >= 256 and g.lout.rows >= 16384 and not (g.wgrad_flags & 0x40)
+    mode = "bf16 storage" if _is16(dy) else ("bf16 math" if g.math else ("planes in registers" if getattr(g, "x3", False) else "fp32 MFMA"))
+    if nine:
+        return f"conv_wgrad9{'h' if _is16(dy) else 'g'}_kernel ({mode})"
+    tf = (g.wgrad_flags >> 4) & 3
+    tile = {0: "launcher tile", 1: "128, 128", 2: "64, 64", 3: "128, 64"}[tf] if co > 32 else "32, 128"
+    return f"conv_wgrad{'h' if _is16(dy) else 'g'}_kernel<{tile}> ({mode}{', 32 px' if g.wgrad_flags & 0x80 else ''})"
+
+
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
+    if EVENTS is not None:
+        co_ = g.cout if cout is None else cout
+        _timed(_wgrad_key(g, dy, co_), 2.0 * g.lout.rows * co_ * g.cin * g.k * g.k,
+               lambda: _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy),
+               4.0 * (g.lout.rows * co_ + g.lin.rows * g.cin + g.nsplit * co_ * g.k * g.k * g.cin))
+        return
+    _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy)
+
+
+def _conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     if _isp(dy):
         assert _isp(x)

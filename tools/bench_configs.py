@@ -56,9 +56,14 @@ def infer(n_images=1000, B=8):
     print(f"config4 inference: {n_images / dt:.1f} images/sec, {ndet / dt:.0f} detections/sec "
           f"(B={B}, {100 * passed:.1f} % of cls scores > 0.05, {cand / B:.0f} candidates/img into vote-NMS, "
           f"{ndet / (n_images // B * B):.0f} dets/img)")
+    n_run = n_images // B * B
+    return {"metric": "images/sec inference (backbone + FPN + head + decode + vote-NMS), r50_ycbv_pbr 640x480 (BASELINE configs[3])",
+            "value": round(n_run / dt, 1), "unit": "images/sec", "detections_per_sec": round(ndet / dt), "images": n_run,
+            "batch": B, "candidates_per_image_into_nms": round(cand / B), "detections_per_image": round(ndet / n_run),
+            "frac_cls_scores_above_thr": round(passed, 4), "dtype": "f32", "data": "synthetic"}
 
 
-def r101():
+def r101(n=8):
     cfg, det = build(101)
     det.train()
     rt = det.runtime()
@@ -79,7 +84,6 @@ def r101():
         rt.train_step(img, tg)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 8
     for _ in range(n):
         rt.train_step(img, tg)
     torch.cuda.synchronize()
@@ -87,11 +91,22 @@ def r101():
     fl = 995.1e9 * B
     print(f"config5 R101 800x800 bs2: {dt * 1e3:.2f} ms/step, {B / dt:.1f} images/sec, {fl / dt / 1e12:.1f} TFLOP/s "
           f"({fl / dt / 1e12 / 157.3:.3f} of fp32 MFMA peak), losses {rt.engine.losses.cpu().numpy()}")
+    return {"metric": "images/sec train-step, ResNet-101 800x800 bs=2/GPU (BASELINE configs[4] on one GPU)",
+            "value": round(B / dt, 2), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": n,
+            "step_tflops": round(fl / dt / 1e12, 2), "losses": [float(v) for v in rt.engine.losses.cpu()], "dtype": "f32",
+            "data": "synthetic"}
 
 
 if __name__ == "__main__":
+    import json
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    av = sys.argv[2:]
+    opt = lambda name, default: int(av[av.index(name) + 1]) if name in av else default  # noqa: E731
+    res = []
     if which in ("all", "infer"):
-        infer()
+        res.append(infer(n_images=opt("--images", 1000)))
     if which in ("all", "r101"):
-        r101()
+        res.append(r101(n=opt("--steps", 8)))
+    if "--json" in av:                      # one JSON line per configuration (bench.py's `infer` / `r101` objects)
+        for r in res:
+            print(json.dumps(r), flush=True)

@@ -273,6 +273,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("RADET_FORCE_REDUCER") == "1":   # the latter: 1-rank RCCL run of the bucketed exchange
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")      # per-collective durations for the `comm` report
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -338,6 +339,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    comm = None
+    if rt.reducer is not None:                # data-parallel runs: a few more steps with the bucket exchange traced
+        rt.reducer.enable_trace(True)
+        for _ in range(min(args.steps, 8)):
+            rt.train_step(img, tg)
+        comm = rt.comm_report()
+        rt.reducer.enable_trace(False)
+        if comm is not None:
+            comm["note"] = ("this rank; ms after the start of the backward pass: `ready` = bucket handed to RCCL (its slab reduction "
+                            "finished on the side stream), `allreduce_ms` = RCCL's own start-to-end time of the collective, `done_by` = "
+                            "seen complete by the main stream (upper bound); exposed = what the main stream waits for the exchange "
+                            "after its last backward kernel (clip + AdamW start later by this much)")
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -354,6 +367,8 @@ def main():
                        "step_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
                        "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
+        if comm is not None:
+            out["comm"] = comm
         x3 = bool(rt.engine.x3)
         if args.math.startswith("fp32"):
             out["config"]["arithmetic"] = (

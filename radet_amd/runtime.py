@@ -130,6 +130,15 @@ class GradReducer:
         self.grads, self.device, self.bf16 = grads, device, bf16
         self.works = []
         self.staging = torch.empty(grads.numel(), dtype=torch.bfloat16, device=device) if bf16 else None
+        # diagnostics (enable_trace()): per bucket an event on the producing stream when the bucket is handed over, an event
+        # on the main stream right behind finish()'s wait for it ("done by": an upper bound of the completion, exact for the
+        # bucket the optimizer really waits for) and -- with TORCH_NCCL_ENABLE_TIMING=1 -- RCCL's own start-to-end time of
+        # the collective.  (Taking the completion on a stream of its own that only waits for the work was tried: that
+        # stream's barrier packets stalled the main stream's hardware queue, +45 % step time under tracing.)
+        self.trace = None
+
+    def enable_trace(self, on=True):
+        self.trace = [] if on else None
 
     def _convert(self, src, dst):
         if src.is_cuda:
@@ -139,16 +148,28 @@ class GradReducer:
 
     def bucket_ready(self, bucket):
         b, e = bucket["arena"]
+        ready = None
+        if self.trace is not None and self.grads.is_cuda:
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record()
         if self.bf16:
             st = self.staging[b:e]
             self._convert(self.grads[b:e], st)
-            self.works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True), b, e))
+            w = dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True)
         else:
-            self.works.append((dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, async_op=True), b, e))
+            w = dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, async_op=True)
+        self.works.append((w, b, e))
+        if ready is not None:
+            self.trace.append(dict(prefix=bucket["prefix"], bytes=(e - b) * (2 if self.bf16 else 4), ready=ready, done=None, work=w))
 
     def finish(self):
         for w, b, e in self.works:
             w.wait()
+            if self.trace is not None and self.grads.is_cuda:
+                for t in self.trace[-len(self.works):]:
+                    if t["work"] is w and t["done"] is None:
+                        t["done"] = torch.cuda.Event(enable_timing=True)
+                        t["done"].record()
             if self.bf16:
                 self._convert(self.staging[b:e], self.grads[b:e])
         self.works = []
@@ -301,12 +322,62 @@ class DetectorRuntime:
                      st["grad_norm"])
         self.engine.params_changed()              # the kernel wrote the arena behind torch's back: fold again next step
 
+    def bf16_buckets(self):
+        """Gradient buckets travel as bf16 (fp32 arena -> bf16 staging -> all-reduce -> back) by default in the bf16-STORAGE
+        mode only: its step is half as long as the fp32 one while the fp32 exchange (127.7 MB per step, ~1.5 ms of per-link
+        ring time on xGMI) stays the same, so the exchange is twice as exposed there; the mode's activation
+        gradients are bf16 already, and the reference's fp16 training (apis/train.py:113-117) all-reduces half-precision
+        gradients as well.  fp32 and the bf16-math mode (fp32 tensors) keep fp32 buckets.  RADET_BF16_BUCKETS=0 / 1 overrides."""
+        env = os.environ.get("RADET_BF16_BUCKETS")
+        if env is not None:
+            return env == "1" and self.engine.math_name != "fp32"
+        return self.engine.math_name == "bf16-storage"
+
+    def comm_report(self):
+        """Diagnostics of the traced steps since reducer.enable_trace() (averaged), times in ms after the start of the
+        backward pass: per bucket `ready` (handed to RCCL: its slab reduction finished on the side stream), `allreduce_ms`
+        (RCCL's own start-to-end time, with TORCH_NCCL_ENABLE_TIMING=1) and `done_by` (the main stream saw it complete in
+        finish(): an upper bound, exact for the bucket that is waited for); `exposed_comm_ms` = how long the main stream
+        waits for the exchange after its last backward kernel -- what clip + AdamW pays.  Host-synchronising: call it after
+        the steps, not between them."""
+        tr = self.reducer.trace if self.reducer is not None else None
+        marks = self.__dict__.get("comm_marks")
+        if not tr or not marks:
+            return None
+        torch.cuda.synchronize()
+        n, lo = len(marks), 0
+        acc = None
+        fwd = bwd = exposed = 0.0
+        for ev_b, ev0, ev1, hi in marks:
+            step = tr[lo:hi]
+            lo = hi
+            def dur(w):                          # RCCL's own timing of the collective (TORCH_NCCL_ENABLE_TIMING=1), else -1
+                try:
+                    return float(w._get_duration())
+                except Exception:
+                    return -1.0
+            rows = [(t["prefix"], t["bytes"], ev0.elapsed_time(t["ready"]), ev0.elapsed_time(t["done"]), dur(t["work"])) for t in step]
+            b = ev0.elapsed_time(ev1)
+            fwd += ev_b.elapsed_time(ev0); bwd += b
+            exposed += max(0.0, max(r[3] for r in rows) - b)
+            acc = rows if acc is None else [(a[0], a[1], a[2] + r[2], a[3] + r[3], a[4] + r[4]) for a, r in zip(acc, rows)]
+        rep = dict(steps=n, forward_loss_ms=round(fwd / n, 3), backward_ms=round(bwd / n, 3),
+                   exposed_comm_ms=round(exposed / n, 3), bf16_buckets=bool(self.reducer.bf16),
+                   buckets=[dict(bucket=a[0], mbytes=round(a[1] / 1e6, 2), ready_ms=round(a[2] / n, 3), done_by_ms=round(a[3] / n, 3),
+                                 allreduce_ms=(round(a[4] / n, 3) if a[4] >= 0 else None)) for a in acc])
+        self.reducer.trace.clear()
+        self.comm_marks.clear()
+        return rep
+
     # ------------------------------------------------------------------ data-parallel train step
     def train_step(self, img, tg, lr=None):
         """One optimisation step. With torch.distributed initialised (backend nccl = RCCL) gradients
         are summed across ranks per bucket on a side stream while the backward of earlier layers is
         still running; the mean (1/world) is folded into the fused clip+AdamW kernel."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.reducer is not None and self.reducer.trace is not None:
+            self._ev_begin = torch.cuda.Event(enable_timing=True)
+            self._ev_begin.record()
         self.forward(img)
         self.loss(tg, grad_scale=self.loss_weights)
         # a 1-rank process group still exercises the bucketed exchange when forced (single-GPU test of the RCCL path)
@@ -314,10 +385,16 @@ class DetectorRuntime:
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
         if use_reducer:
             if self.reducer is None:
-                # bf16 buckets: opt-in (RADET_BF16_BUCKETS=1) in the mixed-precision modes
-                self.reducer = GradReducer(self.flat.grads, self.dev,
-                                           bf16=os.environ.get("RADET_BF16_BUCKETS") == "1" and self.engine.math_name != "fp32")
+                self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets())
+            tr = self.reducer.trace is not None
+            if tr:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()                     # (after forward + loss: the exchange can only overlap the backward pass)
             self.backward(self.reducer.bucket_ready)
+            if tr:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()                     # end of the backward pass on the main stream
+                self.__dict__.setdefault("comm_marks", []).append((self._ev_begin, ev0, ev1, len(self.reducer.trace)))
             self.reducer.finish()
         else:
             self.backward()

@@ -158,6 +158,37 @@ def test_rccl_bucket_exchange_single_rank(det, golden):
         assert torch.equal(la, lb)
         assert ra.reducer is not None and rb.reducer is None
         assert torch.equal(ra.flat.grads, rb.flat.grads) and torch.equal(ra.flat.params, rb.flat.params)
+        # the traced step: every bucket handed over during the backward pass and completed; report well-formed
+        ra.reducer.enable_trace(True)
+        os.environ["RADET_FORCE_REDUCER"] = "1"
+        ra.train_step(img, tg)
+        rep = ra.comm_report()
+        assert [b["bucket"] for b in rep["buckets"]] == [b["prefix"] for b in ra.buckets]
+        assert all(0.0 <= b["ready_ms"] <= b["done_by_ms"] for b in rep["buckets"]) and rep["exposed_comm_ms"] >= 0.0
+        assert rep["steps"] == 1 and rep["backward_ms"] > 0.0
+        assert abs(sum(b["mbytes"] for b in rep["buckets"]) - ra.flat.n_train * 4 / 1e6) < 1.0
+        # ... and the collectives run on a stream of their own: with the main stream parked in a long spin kernel BEFORE the
+        # hand-over and the handing (side) stream parked in one AFTER it, the all-reduce still completes at once
+        from radet_amd.runtime import GradReducer
+        g = torch.ones(1 << 20, device="cuda")
+        red = GradReducer(g, torch.device("cuda", 0))
+        side, probe = torch.cuda.Stream(), torch.cuda.Stream()
+        main_ev, side_ev, done_ev = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(4e8))                      # ~0.2 s on the main stream
+        main_ev.record()
+        with torch.cuda.stream(side):
+            red.bucket_ready(dict(prefix="probe", arena=(0, g.numel())))
+            torch.cuda._sleep(int(4e8))
+            side_ev.record()
+        with torch.cuda.stream(probe):                   # a third stream that only waits for the collective
+            red.works[-1][0].wait()
+            done_ev.record()
+        done_ev.synchronize()                            # host waits for the collective only
+        parked = (not main_ev.query(), not side_ev.query())
+        torch.cuda.synchronize()
+        red.finish()
+        assert parked == (True, True), parked
     finally:
         os.environ["RADET_FORCE_REDUCER"] = "0"
         dist.destroy_process_group()

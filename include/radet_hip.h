@@ -247,7 +247,10 @@ int radet_decode_candidates(const float* cls, const float* reg_u, const float* i
  *      Outputs (capacity max_out per image, heads in descending cluster score):
  *        out_boxes [B,max_out,4], out_scores [B,max_out], out_labels i64 [B,max_out], out_count [B];
  *      mode 2: instance_id i64 [B,cap], cluster_num i64 [B,cap]; mode 3: keep i64 [B,max_out] (input index).
- *      ws: workspace of radet_nms_ws_bytes(B, cap) bytes. cap <= 8192. */
+ *      ws: workspace of radet_nms_ws_bytes(B, cap) bytes.  cap <= 65536: up to 8192 candidates per image the sorts run in
+ *      LDS and a crowded label's greedy pass out of registers; above, the sorts run in global memory and label segments
+ *      longer than 8192 boxes take a general pass (same results; the reference ops have no size limit,
+ *      cluster_ext.cpp:4-87 / vote_ext.cpp:70-207). */
 size_t radet_nms_ws_bytes(int B, int cap);
 int radet_nms(const float* boxes, const float* cluster_scores, const float* vote_scores, const int64_t* labels,
               const int* counts, int B, int cap, int mode, float iou_thr, int iou_enable, float sigma, int max_out,

@@ -426,6 +426,26 @@ __device__ void bitonic_sort_u64(unsigned long long* keys, int m) {
     }
 }
 
+// the same network over keys in GLOBAL memory (more than 8192 candidates per image do not fit the LDS sort): one
+// 1024-thread workgroup, a barrier per step (workgroup-visible global stores); m <= 65536.  A rarely taken path --
+// the detector's own configurations stay below 8192 -- so it is written for exactness, not speed.
+__device__ void bitonic_sort_u64_global(unsigned long long* __restrict__ keys, int m) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (m >> 1); t += 1024) {
+                const int i = ((t / j) * (j << 1)) + (t % j);
+                const int p = i + j;
+                const bool up = ((i & k) == 0);
+                const unsigned long long a = keys[i], b = keys[p];
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
 __device__ __forceinline__ float iou_ref(float x1i, float y1i, float x2i, float y2i, float area_i, float x1j,
                                          float y1j, float x2j, float y2j) {
     const float xl = fmaxf(x1j, x1i), yt = fmaxf(y1j, y1i);
@@ -449,8 +469,17 @@ struct NmsWs {   // per-image global workspace (cap entries each unless noted)
     int* seg;    // [cap + 1] label-segment starts (sorted positions), seg[nseg] = n
     int* big;    // [cap / (64 * NMS_KREG) + 1] indices of the segments longer than 64 * NMS_KREG
     int* misc;   // [8]: 0 nseg, 1 nbig, 2 nheads, 3 K
+    unsigned long long* gkeys;  // [pow2 >= cap] sort keys in global memory (cap > NMS_LDS_SORT only)
     unsigned long long* mask;   // [cap][(cap + 63) / 64] suppression bits of the crowded segments (row = sorted position)
 };
+#define NMS_LDS_SORT 8192       // candidates per image the LDS sorts / the register-resident resolve pass hold
+#define NMS_MAX_CAP 65536       // 16-bit positions in the sort keys
+__host__ __device__ inline size_t nms_gkeys_bytes(int cap) {
+    if (cap <= NMS_LDS_SORT) return 0;
+    size_t m = 1;
+    while (m < (size_t)cap) m <<= 1;
+    return m * 8;
+}
 
 __device__ __forceinline__ NmsWs nms_ws(char* ws_all, size_t ws_per_image, int b, int cap) {
     char* w = ws_all + (size_t)b * ws_per_image;
@@ -465,7 +494,9 @@ __device__ __forceinline__ NmsWs nms_ws(char* ws_all, size_t ws_per_image, int b
     ws.seg = (int*)w; w += (size_t)(cap + 8) * 4;
     ws.big = (int*)w; w += (size_t)(cap / (64 * NMS_KREG) + 8) * 4;
     ws.misc = (int*)w; w += 64;
-    ws.mask = (unsigned long long*)(ws_all + (size_t)b * ws_per_image + (((size_t)(w - (ws_all + (size_t)b * ws_per_image)) + 15) & ~(size_t)15));
+    char* a16 = ws_all + (size_t)b * ws_per_image + (((size_t)(w - (ws_all + (size_t)b * ws_per_image)) + 15) & ~(size_t)15);
+    ws.gkeys = (unsigned long long*)a16;
+    ws.mask = (unsigned long long*)(a16 + nms_gkeys_bytes(cap));
     return ws;
 }
 
@@ -483,7 +514,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
                                                         const int* __restrict__ counts, int cap, int mode,
                                                         char* __restrict__ ws_all, size_t ws_per_image) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
+    unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(smem);  // [m] when m <= NMS_LDS_SORT
     int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8);            // [64]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts[b];
@@ -491,6 +522,8 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
     while (m < n) m <<= 1;
     if (m < 2) m = 2;
     const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    const bool in_lds = m <= NMS_LDS_SORT;                                    // uniform
+    unsigned long long* keys = in_lds ? lkeys : ws.gkeys;
     const float* bsrc = boxes + (size_t)b * cap * 4;
     const float* csrc = cscores + (size_t)b * cap;
     const float* vsrc = vscores + (size_t)b * cap;
@@ -520,8 +553,10 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
         }
         keys[i] = key;
     }
+    __threadfence_block();
     __syncthreads();
-    bitonic_sort_u64(keys, m);
+    if (in_lds) bitonic_sort_u64(lkeys, m);
+    else bitonic_sort_u64_global(ws.gkeys, m);
     for (int i = tid; i < n; i += 1024) {
         const int o = (int)(keys[i] & 0xFFFFull);
         const int lab = (int)lsrc[o];
@@ -799,6 +834,7 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(int cap, int mode, int
     if ((int)blockIdx.x >= ws.misc[1]) return;
     const int s = ws.big[blockIdx.x];
     const int p0 = ws.seg[s], cnt = ws.seg[s + 1] - p0;
+    if (cnt > NMS_LDS_SORT) return;                          // nms_resolve_any_kernel
     const int capw = (cap + 63) >> 6, nbw = (cnt + 63) >> 6;
     // thread t stages words (t & 127) of rows (t >> 7) + 2 k of the chunk: 16 loads in flight per thread
     unsigned long long st[NMS_RROWS / 2];
@@ -865,6 +901,50 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(int cap, int mode, int
     }
 }
 
+// Segments of more than 8192 boxes (cap > 8192 only): the same greedy pass over the mask rows with the suppressed bits in
+// LDS instead of registers -- rows are visited in order, a row whose bit is clear is a head and ORs its row into the
+// suppressed set (one barrier per HEAD, none per suppressed row).  Same heads / head assignment / decay as the pass above.
+__global__ __launch_bounds__(256) void nms_resolve_any_kernel(int cap, int mode, int iou_enable, float sigma,
+                                                              char* __restrict__ ws_all, size_t ws_per_image) {
+    __shared__ unsigned long long sup[NMS_MAX_CAP / 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    if ((int)blockIdx.x >= ws.misc[1]) return;
+    const int s = ws.big[blockIdx.x];
+    const int p0 = ws.seg[s], cnt = ws.seg[s + 1] - p0;
+    if (cnt <= NMS_LDS_SORT) return;                         // nms_resolve_kernel
+    const int capw = (cap + 63) >> 6, nbw = (cnt + 63) >> 6;
+    for (int w = tid; w < nbw; w += 256) sup[w] = 0ull;
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+        if ((sup[i >> 6] >> (i & 63)) & 1ull) continue;      // uniform: every thread reads the same word
+        if (tid == 0) ws.head[p0 + i] = p0 + i;
+        const unsigned long long* row = ws.mask + (size_t)(p0 + i) * capw;
+        for (int w = (i >> 6) + tid; w < nbw; w += 256) {    // (words left of the diagonal are never written)
+            const unsigned long long r = row[w];
+            unsigned long long nw = r & ~sup[w];
+            sup[w] |= r;
+            while (nw) { ws.head[p0 + w * 64 + __ffsll((long long)nw) - 1] = p0 + i; nw &= nw - 1ull; }
+        }
+        __syncthreads();
+        if (mode == 1) break;                                // global vote: one head per label, the rest is dropped
+    }
+    if (iou_enable && mode <= 1) {
+        __threadfence();
+        __syncthreads();
+        for (int j = tid; j < cnt; j += 256) {
+            const int h = ws.head[p0 + j];
+            if (h < 0 || h == p0 + j) continue;
+            const float x1 = ws.bx[h], y1 = ws.bx[cap + h], x2 = ws.bx[2 * cap + h], y2 = ws.bx[3 * cap + h];
+            const int jj = p0 + j;
+            const float iou = iou_ref(x1, y1, x2, y2, (x2 - x1) * (y2 - y1), ws.bx[jj], ws.bx[cap + jj], ws.bx[2 * cap + jj],
+                                      ws.bx[3 * cap + jj]);
+            const float f = -(1 - iou) * (1 - iou) / sigma;
+            ws.vs[jj] = ws.vs[jj] * expf(f);
+        }
+    }
+}
+
 // ---- 4. order the cluster heads (score desc, original index asc); mode 2 / 3 outputs
 __global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
                                                          int cap, int mode, int max_out, float* __restrict__ out_boxes,
@@ -873,7 +953,7 @@ __global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict
                                                          int64_t* __restrict__ aux1, char* __restrict__ ws_all,
                                                          size_t ws_per_image) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [m]
+    unsigned long long* lkeys = reinterpret_cast<unsigned long long*>(smem);  // [m] when m <= NMS_LDS_SORT
     int* s_misc = reinterpret_cast<int*>(smem + (size_t)8192 * 8);            // [64]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts[b];
@@ -881,6 +961,8 @@ __global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict
     while (m < n) m <<= 1;
     if (m < 2) m = 2;
     const NmsWs ws = nms_ws(ws_all, ws_per_image, b, cap);
+    const bool in_lds = m <= NMS_LDS_SORT;
+    unsigned long long* keys = in_lds ? lkeys : ws.gkeys;
     const float* bsrc = boxes + (size_t)b * cap * 4;
     for (int i = tid; i < m; i += 1024) {
         unsigned long long key = ~0ull;
@@ -889,8 +971,10 @@ __global__ __launch_bounds__(1024) void nms_heads_kernel(const float* __restrict
                   (unsigned long long)i;
         keys[i] = key;
     }
+    __threadfence_block();
     __syncthreads();
-    bitonic_sort_u64(keys, m);
+    if (in_lds) bitonic_sort_u64(lkeys, m);
+    else bitonic_sort_u64_global(ws.gkeys, m);
     {
         int c = 0;
         for (int i = tid; i < n; i += 1024) c += keys[i] != ~0ull ? 1 : 0;
@@ -1018,7 +1102,7 @@ __global__ __launch_bounds__(64) void nms_vote_kernel(const int* __restrict__ co
 
 static size_t nms_ws_per_image(int cap) {
     return ((size_t)cap * (16 + 4 * 6) + (size_t)(cap + 8) * 4 + (size_t)(cap / (64 * NMS_KREG) + 8) * 4 + 64 +
-            (size_t)cap * ((cap + 63) / 64) * 8 + 16 + 255) / 256 * 256;
+            nms_gkeys_bytes(cap) + (size_t)cap * ((cap + 63) / 64) * 8 + 16 + 255) / 256 * 256;
 }
 
 extern "C" size_t radet_nms_ws_bytes(int B, int cap) { return (size_t)B * nms_ws_per_image(cap); }
@@ -1027,7 +1111,7 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
                          const int64_t* labels, const int* counts, int B, int cap, int mode, float iou_thr,
                          int iou_enable, float sigma, int max_out, float* out_boxes, float* out_scores,
                          int64_t* out_labels, int* out_count, int64_t* aux0, int64_t* aux1, void* ws, void* stream) {
-    if (cap < 1 || cap > 8192 || mode < 0 || mode > 3 || B < 1) return RADET_ERR_ARG;
+    if (cap < 1 || cap > NMS_MAX_CAP || mode < 0 || mode > 3 || B < 1) return RADET_ERR_ARG;
     if (mode == 3 && max_out <= 0) return RADET_ERR_ARG;
     const size_t smem_sort = (size_t)8192 * 8 + 64 * 4;
     const size_t smem_big = (size_t)65536 + 8192 + (8 + 64 + 64 + 256) * 4;
@@ -1048,13 +1132,16 @@ extern "C" int radet_nms(const float* boxes, const float* cluster_scores, const 
                        counts, cap, mode, (char*)ws, wpi);
     hipLaunchKernelGGL(nms_small_kernel, dim3(32, B), dim3(256), 0, st, cap, mode, iou_thr, iou_enable, sigma, (char*)ws, wpi);
     static const bool blocked = [] { const char* e = getenv("RADET_NMS_BLOCKED"); return e && e[0] == '1'; }();
-    if (blocked) {
+    if (blocked && cap <= NMS_LDS_SORT) {
         hipLaunchKernelGGL(nms_big_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(1024), smem_big, st, cap, mode, iou_thr,
                            iou_enable, sigma, (char*)ws, wpi);
     } else {
         hipLaunchKernelGGL(nms_mask_kernel, dim3(B >= 8 ? 64 : (B >= 2 ? 128 : 256), B), dim3(256), 0, st, cap, iou_thr, (char*)ws, wpi);
         hipLaunchKernelGGL(nms_resolve_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(256), 0, st, cap, mode, iou_enable,
                            sigma, (char*)ws, wpi);
+        if (cap > NMS_LDS_SORT)       // a label segment longer than the register-resident pass holds: at most cap / 8192 of them
+            hipLaunchKernelGGL(nms_resolve_any_kernel, dim3(cap / (64 * NMS_KREG) + 1, B), dim3(256), 0, st, cap, mode,
+                               iou_enable, sigma, (char*)ws, wpi);
     }
     hipLaunchKernelGGL(nms_heads_kernel, dim3(B), dim3(1024), smem_sort, st, boxes, counts, cap, mode, max_out, out_boxes,
                        out_scores, out_labels, out_count, aux0, aux1, (char*)ws, wpi);

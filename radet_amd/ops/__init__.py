@@ -9,7 +9,7 @@ from .. import kernels as K
 __all__ = ["vote_nms", "global_vote_nms", "cluster_nms", "batched_nms", "MBD_box2distance", "GDT_box2distance", "MBD", "GDT",
            "mbd_batch", "gdt_batch", "border_seeds", "resize_batch", "gaussian_blur9_batch", "sobel_edge_batch"]
 
-_MAX = 8192
+_MAX = 65536      # 16-bit positions in the kernel's sort keys (above 8192 the sorts run in global memory)
 
 
 def _dev():
@@ -28,7 +28,7 @@ def _t(x, dtype):
 def _run(mode, boxes, cscore, vscore, labels, thr, iou_enable=False, sigma=0.025, max_out=0):
     n = int(boxes.shape[0])
     if n > _MAX:
-        raise ValueError(f"NMS input of {n} boxes exceeds the on-chip sort capacity ({_MAX})")
+        raise ValueError(f"NMS input of {n} boxes exceeds the kernel's capacity ({_MAX})")
     dev = _dev()
     cap = max(n, 1)
     cnt = torch.tensor([n], dtype=torch.int32, device=dev)

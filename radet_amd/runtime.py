@@ -509,8 +509,8 @@ def _post_launch(self, hw, sf, test_cfg, head_out=None):
     if nms_pre <= 0:
         nms_pre = max(h * w for h, w in ho["level_hw"]) * self.num_classes
     cap = nlvl * nms_pre
-    if cap > 8192:
-        raise NotImplementedError(f"nms_pre={nms_pre}: more than 8192 candidates per image exceed the on-chip NMS sort")
+    if cap > 65536:
+        raise NotImplementedError(f"nms_pre={nms_pre}: more than 65536 candidates per image exceed the NMS kernel's 16-bit positions")
     key = ("post", B, nlvl, nms_pre)
     posts = self.__dict__.setdefault("_posts", {})
     if key not in posts:

@@ -143,10 +143,14 @@ def test_assigner_shared_rng_consumes_one_stream_in_order():
 
 
 @pytest.mark.parametrize("n,n_labels,crowd", [(700, 1, 4), (1024, 1, 30), (1025, 1, 4), (4096, 1, 30), (4097, 1, 30),
-                                              (8192, 1, 30), (6000, 2, 4), (5000, 3, 1)])
+                                              (8192, 1, 30), (6000, 2, 4), (5000, 3, 1),
+                                              # above the LDS sorts (8192): global-memory sorts; a single label of > 8192
+                                              # boxes also takes the general greedy pass over the mask rows
+                                              (8193, 1, 30), (12000, 2, 4), (20000, 21, 30), (20000, 1, 30), (30000, 5, 8)])
 def test_nms_long_label_segments(n, n_labels, crowd):
-    """Crowded classes: every clustering path of the kernel -- register-resident segments (<= 1024 boxes), the
-    workgroup-cooperative path with LDS-staged coordinates (<= 4096) and through L2 (> 4096) -- bit-exact, all modes."""
+    """Crowded classes: every clustering path of the kernel -- register-resident segments (<= 64 boxes), the mask +
+    register-resident greedy pass (<= 8192 per label), and for N > 8192 (the reference ops take any N: cluster_ext.cpp:4-87,
+    vote_ext.cpp:70-207) the global-memory sorts and the general greedy pass -- bit-exact, all modes."""
     from oracle import nms as onms
     from radet_amd import ops
     rs = np.random.RandomState(n + n_labels)

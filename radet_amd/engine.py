@@ -890,6 +890,10 @@ class Engine:
                         pending.append((t, tower, x))
                     else:
                         wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
+                if pending and os.environ.get("RADET_TOWER_WGRAD_MAIN") == "1":     # experiment: no co-running in the towers
+                    for t, tower, x in pending:
+                        K.conv_wgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
+                    pending = []
                 for t, tower, x in pending:
                     wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 cc, cr = self.cls_tower[i], self.reg_tower[i]

@@ -487,6 +487,49 @@ def _detect(self, img, img_metas, test_cfg, rescale=False):
         return _post_collect(self, *_post_launch(self, hw, sf, test_cfg))
 
 
+def _detect_stream(self, batches, test_cfg, rescale=False):
+    """`detect` over an iterable of (img, img_metas) batches with the host one batch behind the device: batch k + 1's
+    device program (forward, decode, NMS) is enqueued BEFORE the host waits for batch k's detection counts, so the GPU
+    never idles on the per-batch hand-over (what the reference's `single_gpu_test` loop -- apis/test.py -- pays per batch
+    as a device synchronisation).  Yields exactly what `detect` returns, in order.  The small per-batch uploads (image
+    sizes, scale factors) go through pinned memory and the counts come back on a copy stream behind an event: nothing in
+    the loop synchronises the main stream."""
+    copy = self.__dict__.setdefault("_copy_stream", None) or torch.cuda.Stream(device=self.dev)
+    self._copy_stream = copy
+
+    def collect(rec):
+        outs, ev, pinned = rec
+        with torch.cuda.stream(copy):
+            copy.wait_event(ev)
+            pinned.copy_(outs[3], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        done.synchronize()                                      # the host waits for THIS batch only
+        counts = pinned.numpy()
+        ob, osc, ol, _ = outs
+        return [(torch.cat([ob[i, :int(counts[i])], osc[i, :int(counts[i]), None]], -1), ol[i, :int(counts[i])])
+                for i in range(ob.shape[0])]
+
+    def upload(a):
+        return torch.from_numpy(a).pin_memory().to(self.dev, non_blocking=True)
+
+    prev = None
+    with torch.no_grad():
+        for img, img_metas in batches:
+            hw = upload(np.asarray([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], np.float32))
+            sf = upload(np.stack([np.asarray(m["scale_factor"], np.float32).reshape(4) for m in img_metas])) if rescale else None
+            self.forward(img.to(self.dev, non_blocking=True))
+            outs = _post_launch(self, hw, sf, test_cfg)
+            ev = torch.cuda.Event()
+            ev.record()
+            rec = (outs, ev, torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory())
+            if prev is not None:
+                yield collect(prev)
+            prev = rec
+        if prev is not None:
+            yield collect(prev)
+
+
 def _meta_tensors(self, img_metas, rescale):
     hw = torch.tensor([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], device=self.dev)
     sf = None
@@ -661,6 +704,7 @@ def _head_forward_api(self, feats):
 
 
 DetectorRuntime.detect = _detect
+DetectorRuntime.detect_stream = _detect_stream
 DetectorRuntime.detect_graph = _detect_graph
 
 

@@ -329,3 +329,21 @@ def test_multi_geometry_plans_no_retune_no_realloc():
     assert len(rt.engine._plans) <= rt.engine.max_plans
     again = rt.detect(img1, metas, det.test_cfg)
     assert torch.equal(again[0][0], first[0][0])
+
+
+def test_detect_stream_matches_detect():
+    """rt.detect_stream (host one batch behind the device) yields the same detections as rt.detect, batch by batch."""
+    import numpy as np
+    det = make_det().eval()
+    rt = det.runtime()
+    with torch.no_grad():
+        det.bbox_head.atss_cls.bias += 2.0
+    metas = [dict(img_shape=(160, 192, 3), scale_factor=np.ones(4, np.float32)) for _ in range(2)]
+    g = torch.Generator().manual_seed(4)
+    imgs = [torch.randn(2, 3, 160, 192, generator=g).cuda() for _ in range(4)]
+    ref = [rt.detect(im, metas, det.test_cfg, rescale=True) for im in imgs]
+    got = list(rt.detect_stream(((im, metas) for im in imgs), det.test_cfg, rescale=True))
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        for (da, la), (db, lb) in zip(a, b):
+            assert torch.equal(da, db) and torch.equal(la, lb) and da.shape[0] > 0

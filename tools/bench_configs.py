@@ -43,9 +43,13 @@ def infer(n_images=1000, B=8):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ndet = 0
-    for _ in range(n_images // B):
-        out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
-        ndet += sum(int(d.shape[0]) for d, _ in out)
+    if os.environ.get("RADET_INFER_SYNC") == "1":           # one batch at a time (the host waits for every batch's counts)
+        for _ in range(n_images // B):
+            out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
+            ndet += sum(int(d.shape[0]) for d, _ in out)
+    else:                                                   # the host one batch behind the device (rt.detect_stream)
+        for out in rt.detect_stream(((imgs, metas) for _ in range(n_images // B)), det.test_cfg, rescale=True):
+            ndet += sum(int(d.shape[0]) for d, _ in out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     post = next(iter(rt._posts.values()))           # the decode / NMS buffers of this (B, nms_pre)

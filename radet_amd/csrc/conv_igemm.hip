@@ -1922,6 +1922,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
 // producers, see radet_split_planes / the GroupNorm kernels).  Per tap the 6 plane products of conv_igemmg_kernel's X3 / P3
 // modes; no operand split in the loop.  16 pixels (one K = 16 MFMA step) per stage: 3 planes x (8 KiB dy + 9 KiB x) = 51
 // KiB per stage, two stages; 54 MFMAs per wave between barriers, two waves per SIMD.
+// (a 4-wave / 128-channel variant, two workgroups per CU, measured 201 vs 184 us on the tower shape: not kept)
 __global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
     constexpr int BP = 16, NW = 8, BM = 256, BC = 32, KT = 9;
     constexpr int CBA = BM / 16, CBB = BC / 16;

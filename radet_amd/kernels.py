@@ -91,10 +91,11 @@ def _igemm_key(t, x):
         tag, bk = ((t >> 8) & 1) | (2 if t & MATH_BF16 else 0), 32 if t & 0x200 else 16
     skw = (t >> 20) & 7
     stages = 3 if (t & STAGES3) and (tag < 2 or tag & 24) and not skw else 2
-    return f"conv_igemmg_kernel<{_TILES[tid]}, {tag}, {bk}, {stages}, {'true' if skw and tag == 0 else 'false'}>"
+    return f"conv_igemmg_kernel<{_TILES.get(tid, '?')}, {tag}, {bk}, {stages}, {'true' if skw and tag == 0 else 'false'}>"
 
 
 def _timed(key, flops, fn, nbytes=0.0):
+    """key: the kernel's name, or a callable producing it (only evaluated when a measurement is running)"""
     ev = EVENTS
     if ev is None:
         return fn()
@@ -102,7 +103,7 @@ def _timed(key, flops, fn, nbytes=0.0):
     s.record()
     fn()
     e.record()
-    ev.append(dict(key=key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn))
+    ev.append(dict(key=key() if callable(key) else key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn))
 
 
 def _conv_bytes(g, groups=1):
@@ -510,7 +511,7 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
         _lib.call("radet_conv2d_igemm", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
                   g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
                   _stream())
-    _timed(_igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g))
+    _timed(lambda: _igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g))
 
 
 def _pred_tiles(lv):
@@ -606,7 +607,7 @@ def conv_fwd_pair(g, a, b, relu=False, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     t, table = _tile(g, tile, g.fwd_tile, a["x"], a["y"]), g.fwd_table
-    _timed(_igemm_key(t, a["x"]), 4.0 * g.lout.rows * g.cout * g.cin * g.k * g.k,
+    _timed(lambda: _igemm_key(t, a["x"]), 4.0 * g.lout.rows * g.cout * g.cin * g.k * g.k,
            lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lout.rows, g.cin, g.cout, g.k, g.k,
                              int(relu), t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
 
@@ -617,7 +618,7 @@ def conv_dgrad_pair(g, a, b, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     t, table = _tile(g, tile, g.bwd_tile, a["x"], a["y"]), g.bwd_table
-    _timed(_igemm_key(t, a["x"]), 4.0 * g.lin.rows * g.cout * g.cin * g.k * g.k,
+    _timed(lambda: _igemm_key(t, a["x"]), 4.0 * g.lin.rows * g.cout * g.cin * g.k * g.k,
            lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
                              t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
 

@@ -57,7 +57,7 @@ def run_shape(name, lv, cin, cout, k, stride, pair=False, tiles=None):
           f"{t_ref:8.1f} us  {flop / t_ref / 1e6:7.1f} TFLOP/s")
     y1 = torch.empty_like(y0)
     y1b = torch.empty_like(y0)
-    cands = tiles or [(1, 0), (1, K.STAGES3), (2, 0), (3, 0), (5, 0), (6, 0), (7, 0)]
+    cands = tiles or [(1, 0), (2, 0), (3, 0), (3, K.STAGES3), (5, 0), (6, 0)]
     for t, fl in cands:
         def run():
             if pair:
@@ -134,7 +134,7 @@ if __name__ == "__main__":
     if what in ("tower", "all"):
         run_gn(plv)
         run_shape("tower", plv, 256, 256, 3, 1, pair=False)
-        run_shape("tower pair", plv, 256, 256, 3, 1, pair=True, tiles=[(1, 0), (2, 0), (5, 0), (6, 0), (7, 0)])
+        run_shape("tower pair", plv, 256, 256, 3, 1, pair=True, tiles=[(1, 0), (2, 0), (3, 0), (5, 0), (6, 0)])
         run_wgrad(plv)
     if what in ("layer3", "all"):
         run_shape("layer3 3x3", Levels([(30, 40)], B), 256, 256, 3, 1)

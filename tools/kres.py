@@ -24,7 +24,7 @@ for ln in err.splitlines():
         k, v = t.split(":", 1)
         rows[cur][k.strip()] = v.strip()
 for name, r in rows.items():
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", name], capture_output=True, text=True).stdout.strip()
+    dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r"\(.*", "", dem).replace("void ", "")
     if pat and not pat.search(dem):
         continue

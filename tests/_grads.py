@@ -16,7 +16,7 @@ def grad_rel_errors(mine, ref):
 
 def assert_grads_close(mine, ref, rtol=3e-3, atol_total=2e-6, median_rtol=5e-4):
     """per parameter: ||g - g_ref|| <= rtol * ||g_ref|| + atol_total * ||all gradients||, and the median over the
-    parameters of ||g - g_ref|| / ||g_ref|| <= median_rtol.  Measured (tools/_probe/gradcmp.py): median 5e-6 .. 4e-5 with
+    parameters of ||g - g_ref|| / ||g_ref|| <= median_rtol.  Measured (tools/gradcmp.py): median 5e-6 .. 4e-5 with
     the default arithmetic (3e-4 with the native fp32 MFMA), single parameters up to 1.5e-3: two correct fp32
     implementations decide a handful of ReLU masks differently (pre-activations within an ulp of zero, summation orders
     that the autotuner picks per run), and one flipped mask moves a whole row of a weight gradient.  A wiring error --

@@ -316,7 +316,7 @@ def test_head_with_more_than_32_classes():
         assert abs(losses[k].item() - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), k
     from _grads import assert_grads_close
     # (K = 48 after padding: the cls predictor's dgrad / wgrad run on the native fp32 MFMA, whose distance to the CPU
-    # oracle is ~3e-4 per GEMM -- tools/_probe/gradcmp.py -- and every gradient passes through it)
+    # oracle is ~3e-4 per GEMM -- tools/gradcmp.py -- and every gradient passes through it)
     assert_grads_close({n: p.grad for n, p in det.named_parameters() if p.requires_grad}, odet.named_grads(),
                        rtol=5e-3, median_rtol=2e-3)
     assert det.runtime().engine.pred_cls.cout == 40

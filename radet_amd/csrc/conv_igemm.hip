@@ -465,6 +465,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     // bf16-storage path (K counted in channel pairs, a 16-byte LDS slot = 8 bf16 = one MFMA operand); outputs stay fp32
     constexpr bool P3 = (TAG & 16) != 0;
     constexpr int NPL = P3 ? 3 : 1;
+    // bit 5 (with bit 3): the waves divide the K step as well as the tile.  A stage of BK = 16 KD channels is cut into KD
+    // k-groups; wave (kg, nh) accumulates ALL BM rows x its BN / WNK columns over k-group kg, and the KD partial tiles of a
+    // column group are added through LDS after the K loop.  A wave's operand splits (VALU work) and fragment reads (LDS
+    // bandwidth) then serve TMA x TNA accumulator blocks instead of one: (TMA + TNA) splits per 6 TMA TNA MFMAs -- for the
+    // 64 x 64 tile 1 split per 6 MFMAs with KD = 4 (2 x 2 blocks per wave) or 1.5 with KD = 2 (2 x 1), against 2 for the
+    // 2 x 2-wave tile whose waves each split one A and one B fragment per 6 MFMAs
+    constexpr bool KW = (TAG & 32) != 0;
+    constexpr int KD = KW ? BK / 16 : 1;                                  // k-groups per stage
+    constexpr int WNK = NW / KD;                                          // column groups of waves
+    constexpr int TMA = KW ? BM / 32 : TM, TNA = KW ? BN / (32 * WNK) : TN;      // accumulator blocks of a wave
+    static_assert(!KW || (X3 && !SK && NW == 4 && KD * WNK == NW && TM == 1 && TN == 1 && TMA * TNA == KD && NSTG == 2),
+                  "K-divided tile: one 32 x 32 block per wave after the reduction");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(!P3 || BK == 16, "plane rows are laid out in 32-channel groups: one group per K stage");
     // NSTG LDS stages: loads run NSTG - 1 K steps ahead of the MFMAs.  3 stages hide more L2 latency (+8 % on the
@@ -561,8 +573,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     const float* abase[A_PW];
     const float* wbase[B_PW];
     unsigned amask[A_PW], wmask[B_PW];
+    constexpr bool BMASK = P3 || KW;
+    int pc0 = 0, pwt = 0;                 // (channel chunk, weight tap) of the stage whose pieces are being issued
     auto set_abase = [&]() {
-        if constexpr (P3) {
+        pc0 = ld_c0; pwt = wtap;
+        if constexpr (BMASK) {
 #pragma unroll
             for (int k = 0; k < A_PW; ++k) {
                 amask[k] = arow[k] >= 0 ? 0xFFFFFFFFu : 0u;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             }
         }
     };
-    if constexpr (P3) {
+    if constexpr (BMASK) {
 #pragma unroll
         for (int k = 0; k < B_PW; ++k) {
             wmask[k] = wp[k] ? 0xFFFFFFFFu : 0u;
@@ -589,8 +604,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             if (A_FULL || ins < A_INSTR) {
                 // plane rows: 32-channel groups of [hi | mid | lo] x 16 units -> chunk ld_c0 starts at unit 3 * ld_c0
                 const float* src;
-                if constexpr (P3) src = abase[k] + ((unsigned)(NPL * ld_c0 + p * BK) & amask[k]);
-                else src = arow[k] >= 0 ? P.x + (size_t)arow[k] * xld + NPL * ld_c0 + akq[k] + p * BK : radet_zero_page + lane * 4;
+                if constexpr (BMASK) src = abase[k] + ((unsigned)(NPL * pc0 + p * BK) & amask[k]);
+                else src = arow[k] >= 0 ? P.x + (size_t)arow[k] * xld + NPL * pc0 + akq[k] + p * BK : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][p * BM * BK + ins * 256]), 16, 0, 0);
             }
         } else {
@@ -598,8 +613,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             const int ins = wave + NW * k;
             if (B_FULL || ins < B_INSTR) {
                 const float* src;
-                if constexpr (P3) src = wbase[k] + ((unsigned)(wtap * xld + NPL * ld_c0 + p * BK) & wmask[k]);
-                else src = wp[k] ? wp[k] + wtap * xld + NPL * ld_c0 + p * BK : radet_zero_page + lane * 4;
+                if constexpr (BMASK) src = wbase[k] + ((unsigned)(pwt * xld + NPL * pc0 + p * BK) & wmask[k]);
+                else src = wp[k] ? wp[k] + pwt * xld + NPL * pc0 + p * BK : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][p * BN * BK + ins * 256]), 16, 0, 0);
             }
         }
@@ -633,11 +648,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         advance_stage();
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TMA][TNA];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMA; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TNA; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -759,7 +774,67 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    if constexpr (P3) {
+    if constexpr (KW) {
+        const int kg = wave % KD, nh = wave / KD;
+        const unsigned ka = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(li * BK * 4);
+        const unsigned kb = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((nh * TNA * 32 + li) * BK * 4);
+        unsigned kaa[2], kba[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            kaa[h] = ka + 16u * (unsigned)((4 * kg + 2 * h + lh) ^ rswz);
+            kba[h] = kb + 16u * (unsigned)((4 * kg + 2 * h + lh) ^ rswz);
+        }
+        f32x4 fa[2][2][TMA], fb[2][2][TNA];              // [fragment set][k half][block]
+        constexpr int NRD = 2 * (TMA + TNA);
+        // fragment read r of buffer BUF into fragment set PP: A blocks, then B blocks, k half 0 then 1
+        auto read_one = [&](auto bufc, auto ppc, auto rc) {
+            constexpr int BUF = decltype(bufc)::value, PP = decltype(ppc)::value, r = decltype(rc)::value;
+            constexpr int AO = BUF * BM * BK * 4, BO = BUF * BN * BK * 4, RO = 32 * BK * 4;
+            constexpr int h = r / (TMA + TNA), e = r % (TMA + TNA);
+            if constexpr (e < TMA) lds_read128<AO + e * RO>(fa[PP][h][e], kaa[h]);
+            else lds_read128<BO + (e - TMA) * RO>(fb[PP][h][e - TMA], kba[h]);
+        };
+        auto pin = [&](auto ppc) {
+            constexpr int PP = decltype(ppc)::value;
+            (void)fa; (void)fb;            // (named outside the asm operands: clang does not capture through those alone)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < TMA; ++i) asm volatile("" : "+v"(fa[PP][h][i]));
+#pragma unroll
+                for (int j = 0; j < TNA; ++j) asm volatile("" : "+v"(fb[PP][h][j]));
+            }
+        };
+        // two stages, several workgroups per CU: loads of stage it + 1 at the head of stage it, the fragment reads of
+        // stage it + 1 right behind the barrier that publishes it
+        auto stage_kw = [&](auto bufc, auto ppc, int it) {
+            constexpr int BUF = decltype(bufc)::value, PP = decltype(ppc)::value;
+            if (it + 1 < nK) issue_stage(BUF ^ 1);
+            lds_wait<0>();
+            pin(ppc);
+            bf16x8 ah[TMA], am[TMA], al[TMA], bh[TNA], bm[TNA], bl[TNA];
+#pragma unroll
+            for (int i = 0; i < TMA; ++i) split3_bf16(fa[PP][0][i], fa[PP][1][i], ah[i], am[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < TNA; ++j) split3_bf16(fb[PP][0][j], fb[PP][1][j], bh[j], bm[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < TMA; ++i)
+#pragma unroll
+                for (int j = 0; j < TNA; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        if (nK > 0) static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rc); });
+        for (int it = 0; it < nK; it += 2) {
+            stage_kw(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, it);
+            if (it + 1 < nK) {
+                static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, rc); });
+                stage_kw(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, it + 1);
+                if (it + 2 < nK) static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rc); });
+            }
+        }
+    } else if constexpr (P3) {
         // Plane operands: per K = 16 slice 3 (TM + TN) fragment reads (one ds_read_b128 = the 8 bf16 of one plane a lane
         // feeds to v_mfma_f32_32x32x16_bf16) and 6 TM TN MFMAs, nothing else.  Everything that is not an MFMA is spread
         // BETWEEN the MFMAs: a slice is six groups of TM TN MFMAs (one plane product each), and behind each group go a few
@@ -861,13 +936,56 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         if constexpr (NSTG >= 4)
             if (it + 3 < nK) stage(std::integral_constant<int, 3>{}, it + 3);
     }
-    if (streamk) {
+    if constexpr (SK) {
         cur += nK;
         bool fin = nK == KT * cpt;                                // whole tile: plain epilogue
         if (!fin)
             fin = streamk_publish<BM, BN, WM, WN>(epi, acc, sk_tile, nK, KT * cpt, vwg, sk_tile == first_tile ? 0 : 1,
                                                   reinterpret_cast<volatile int*>(&As[0][0]));
         if (fin) igemm_store<BM, BN, WM, WN>(epi, P, acc, m0, n0, 1, 0, 0, wm, wn, li, lh, nullptr);
+    } else if constexpr (KW) {
+        // the KD partial tiles of a column group -> one: wave (kg, nh) keeps its block kg (row block kg / TNA, column block
+        // kg % TNA of the group) and ships its other KD - 1 blocks through LDS (4 KiB each, slot (sender wave, block) in the
+        // stage buffers, which every wave has left behind the closing barrier of the last stage); sum order fixed: own block +
+        // the partners in ascending k-group order
+        constexpr int SLOTS_A = NSTG * BM * BK / 1024, SLOTS_B = NSTG * BN * BK / 1024;
+        static_assert(NW * (KD - 1) <= SLOTS_A + SLOTS_B, "partial blocks fit the stage buffers");
+        const int kg = wave % KD, nh = wave / KD;
+        float* const pa = &As[0][0];
+        float* const pb = &Bs[0][0];
+        auto slot_ptr = [&](int sender_wave, int blk) {
+            const int sk_ = sender_wave % KD;
+            const int slot = sender_wave * (KD - 1) + blk - (blk > sk_ ? 1 : 0);
+            return reinterpret_cast<f32x4*>(slot < SLOTS_A ? pa + slot * 1024 : pb + (slot - SLOTS_A) * 1024) + lane;
+        };
+        f32x16 out[1][1];
+        static_for<0, KD>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const f32x16& v = acc[b / TNA][b % TNA];
+            if (kg == b) {
+                out[0][0] = v;
+            } else {
+                f32x4* d = slot_ptr(wave, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q * 64] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
+        });
+        __syncthreads();
+#pragma unroll
+        for (int sg = 0; sg < KD; ++sg) {
+            if (sg != kg) {
+                const f32x4* d = slot_ptr(nh * KD + sg, kg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = d[q * 64];
+                    out[0][0][4 * q] += t.x; out[0][0][4 * q + 1] += t.y; out[0][0][4 * q + 2] += t.z; out[0][0][4 * q + 3] += t.w;
+                }
+            }
+        }
+        __syncthreads();                                            // (igemm_store reuses the head of As for its ticket)
+        igemm_store<BM, BN, WM, WN>(epi, P, out, m0, n0, nsplit, ctile, zsplit, kg / TNA, nh * TNA + kg % TNA, li, lh,
+                                    reinterpret_cast<volatile int*>(&As[0][0]));
+        cur = end_it;
     } else {
         igemm_store<BM, BN, WM, WN>(epi, P, acc, m0, n0, nsplit, ctile, zsplit, wm, wn, li, lh,
                                     reinterpret_cast<volatile int*>(&As[0][0]));
@@ -1311,10 +1429,18 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
 // One (tap, 64x64 or 128x128 output x input channel tile, pixel split) per workgroup; the dy / x tiles are brought in
 // by global_load_lds (see conv_wgrad9g_kernel): the unpadded
 // [pixel][channel] tiles are lane-linear images of 1-KiB wave loads, so no staging registers and no ds_write pass.
-template <int BM, int BN, int WM, int WN, int MATH, int BP = 16>
+// KD > 1 (MATH 2 only): the waves divide the pixels of a stage as well as the tile -- BP = 16 KD pixels per stage, wave
+// (kg, nh) accumulates ALL BM rows x its BN / (4 / KD) columns over pixel group kg, and the KD partial tiles are added through
+// LDS after the loop (as TAG bit 5 of conv_igemmg_kernel: the operand splits and fragment reads of a wave serve TMA x TNA
+// accumulator blocks instead of one)
+template <int BM, int BN, int WM, int WN, int MATH, int BP = 16, int KD = 1>
 __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     constexpr int NW = 4;                                   // BP = pixels per stage (16 or 32); splits count 16-pixel chunks
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr bool KW = KD > 1;
+    constexpr int WNK = NW / KD;
+    constexpr int TMA = KW ? BM / 32 : TM, TNA = KW ? BN / (32 * WNK) : TN;
+    static_assert(!KW || (MATH == 2 && BP == 16 * KD && TM == 1 && TN == 1 && TMA * TNA == KD), "pixel-divided tile");
     constexpr int A_INSTR = BP * BM * 4 / 1024, B_INSTR = BP * BN * 4 / 1024;
     constexpr int N_INSTR = A_INSTR + B_INSTR;
     constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;
@@ -1398,14 +1524,15 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
         }
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[TMA][TNA];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMA; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TNA; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
     float bsum = 0.f;
+    const int kg = wave % KD, nh = wave / KD;
     const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
 
     // per-lane LDS byte addresses of the operand reads: pixel row lh of a k pair, channel (wave tile) * 32 + li
@@ -1416,7 +1543,43 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
-        if constexpr (MATH == 2) {
+        if constexpr (KW) {
+            // pixel group kg of the stage, all TMA x TNA blocks of this wave's column group
+            const unsigned ab = (unsigned)(size_t)(lptr_t)(&As[0][0]) + 4u * (unsigned)(lh * BM + li) + (unsigned)buf * (BP * BM * 4) +
+                                7u * lh * BM * 4 + (unsigned)(kg * 16 * BM * 4);
+            const unsigned bb = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + 4u * (unsigned)(lh * BN + nh * TNA * 32 + li) +
+                                (unsigned)buf * (BP * BN * 4) + 7u * lh * BN * 4 + (unsigned)(kg * 16 * BN * 4);
+            float a8[TMA][8], b8[TNA][8];
+            static_for<0, TMA>([&](auto ic) {
+                static_for<0, 8>([&](auto ec) {
+                    lds_read32<(decltype(ec)::value * BM + decltype(ic)::value * 32) * 4>(a8[decltype(ic)::value][decltype(ec)::value], ab);
+                });
+            });
+            static_for<0, TNA>([&](auto jc) {
+                static_for<0, 8>([&](auto ec) {
+                    lds_read32<(decltype(ec)::value * BN + decltype(jc)::value * 32) * 4>(b8[decltype(jc)::value][decltype(ec)::value], bb);
+                });
+            });
+            lds_wait<0>();
+            bf16x8 ah[TMA], am[TMA], al[TMA], bh[TNA], bm[TNA], bl[TNA];
+#pragma unroll
+            for (int i = 0; i < TMA; ++i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(a8[i][e]));
+                split3_bf16(a8[i], ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TNA; ++j) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(b8[j][e]));
+                split3_bf16(b8[j], bh[j], bm[j], bl[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TMA; ++i)
+#pragma unroll
+                for (int j = 0; j < TNA; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (MATH == 2) {
             // fp32-accurate products on the bf16 matrix cores (see conv_igemmg_kernel, X3): lane (i, h) holds pixels
             // 8h .. 8h+7 of every 16-pixel group for its channel
             const unsigned ab = a_thr + (unsigned)buf * (BP * BM * 4) + 7u * lh * BM * 4;
@@ -1526,6 +1689,51 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
         }
     }
     float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    if constexpr (KW) {
+        // KD partial tiles of a column group -> one (see conv_igemmg_kernel): wave (kg, nh) keeps block kg, ships the others
+        constexpr int SLOTS_A = 2 * BP * BM / 1024, SLOTS_B = 2 * BP * BN / 1024;
+        static_assert(NW * (KD - 1) <= SLOTS_A + SLOTS_B, "partial blocks fit the stage buffers");
+        float* const pa = &As[0][0];
+        float* const pb = &Bs[0][0];
+        auto slot_ptr = [&](int sender_wave, int blk) {
+            const int sk_ = sender_wave % KD;
+            const int slot = sender_wave * (KD - 1) + blk - (blk > sk_ ? 1 : 0);
+            return reinterpret_cast<f32x4*>(slot < SLOTS_A ? pa + slot * 1024 : pb + (slot - SLOTS_A) * 1024) + lane;
+        };
+        __syncthreads();                                        // (the bias column sums above read As[0])
+        f32x16 res;
+        static_for<0, KD>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const f32x16& v = acc[b / TNA][b % TNA];
+            if (kg == b) {
+                res = v;
+            } else {
+                f32x4* d = slot_ptr(wave, b);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d[q * 64] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            }
+        });
+        __syncthreads();
+#pragma unroll
+        for (int sg = 0; sg < KD; ++sg) {
+            if (sg != kg) {
+                const f32x4* d = slot_ptr(nh * KD + sg, kg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t = d[q * 64];
+                    res[4 * q] += t.x; res[4 * q + 1] += t.y; res[4 * q + 2] += t.z; res[4 * q + 3] += t.w;
+                }
+            }
+        }
+        const int c = c0 + (nh * TNA + kg % TNA) * 32 + li;
+        if (c < a.Cin) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int o = o0 + (kg / TNA) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (o < a.Cout) out[((size_t)o * KT + tap) * a.Cin + c] = res[t];
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1539,11 +1747,12 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
                 out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
             }
         }
+    }
 }
 
-template <int BM, int BN, int WM, int WN, int MATH, int BP = 16>
+template <int BM, int BN, int WM, int WN, int MATH, int BP = 16, int KD = 1>
 __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
-    wgradg_body<BM, BN, WM, WN, MATH, BP>(a, blockIdx.x);
+    wgradg_body<BM, BN, WM, WN, MATH, BP, KD>(a, blockIdx.x);
 }
 
 // Grouped launch: up to WG_MAX independent weight-gradient GEMMs (the convs of one backbone stage / of the neck, all
@@ -2211,6 +2420,16 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         launch_p3<BM, BN, WM, WN>(a, st, tag, bk, stages, tiles);
         return;
     }
+    if (tag & 32) {                       // K-divided 4-wave tile (fp32 operands split in registers): K step 64 / 32
+        if constexpr (BM == 64 && BN == 64 && WM * WN == 4) {
+#define RADET_LAUNCH_KW(BKV) \
+    do { if (tag & 1) hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 41, BKV, 2>), dim3(tiles, a.sk), dim3(256), 0, st, a); \
+         else hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, 40, BKV, 2>), dim3(tiles, a.sk), dim3(256), 0, st, a); } while (0)
+            if (bk == 64) RADET_LAUNCH_KW(64); else RADET_LAUNCH_KW(32);
+#undef RADET_LAUNCH_KW
+        }
+        return;
+    }
 #define RADET_LAUNCH_IGEMM(K, TAGV, BKV) hipLaunchKernelGGL((K<BM, BN, WM, WN, TAGV, BKV>), dim3(tiles, a.sk), dim3(256), 0, st, a)
     if constexpr (!P3ONLY) {
         if (a.sk_wgs > 0) {                                            // stream-K: tag 0, 2 stages
@@ -2248,8 +2467,8 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
 }
 
 static long igemm_tiles(int M, int N, int choice) {
-    const int bm = choice == 3 ? 64 : (choice >= 6 ? 256 : 128);
-    const int bn = (choice == 1 || choice >= 5) ? 128 : (choice == 4 ? 32 : 64);
+    const int bm = (choice == 3 || choice >= 7) ? 64 : (choice == 6 ? 256 : 128);
+    const int bn = (choice == 1 || choice == 5 || choice == 6) ? 128 : (choice == 4 ? 32 : 64);
     return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
@@ -2391,8 +2610,14 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     if (x3) { bk = 32; tag |= 8; }
     if (p3) { tag = 16 | ((tile_override >> 8) & 1); bk = 16; }
     int choice = tile_override & 0xFF;
+    if (choice == 7 || choice == 8) {                          // 64 x 64 tiles whose four waves divide the K step (see TAG bit 5):
+        // 7: four k-groups of a 64-channel stage; 8: two k-groups x two column halves of a 32-channel stage
+        const int kbk = choice == 7 ? 64 : 32;
+        if (!x3 || Cin % kbk != 0 || ((tile_override >> 20) & 7)) return RADET_ERR_ARG;
+        tag |= 32; bk = kbk;
+    } else
     if (choice > 4 && !p3) return RADET_ERR_ARG;               // the 8-wave tiles exist for plane operands only
-    if (choice >= 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
+    if (choice == 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
     if (choice <= 0) {
         if (Cout <= 32) choice = 4;
         else {
@@ -2441,6 +2666,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         case 4: launch_igemm<128, 32, 4, 1>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;
         case 5: launch_igemm<128, 128, 2, 4, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         case 6: launch_igemm<256, 128, 4, 2, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
+        case 7: case 8: launch_igemm<64, 64, 2, 2, true>(a, st, tag, bk, splitk_ws_floats, 2, skw); break;   // K-divided
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();
@@ -2581,6 +2807,13 @@ extern "C" int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs,
     // 128 (output channels) x 64 (input channels): two accumulators per wave -- three operand splits per two MFMA blocks
     // instead of two per block; offered to the tuner with the bf16-plane arithmetic, where the 64 x 64 tile is VALU-bound
     if (bm != 32 && ((flags >> 4) & 3) == 3 && a.math == 2) { bm = 128; bn = 64; }
+    // 0x400 / 0x800 (bf16-plane arithmetic, 64 x 64 tile): the four waves divide a 64-pixel stage four ways / a 32-pixel
+    // stage two ways (x two column halves) and share the operand splits (see wgradg_body, KD)
+    if (bm == 64 && a.math == 2 && (flags & 0xC00)) {
+        const int tiles = ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64) * a.KH * a.KW * a.S;
+        if (flags & 0x400) hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 2, 64, 4>), dim3(tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 2, 32, 2>), dim3(tiles), dim3(256), 0, st, a);
+    } else
     if (bm == 32) launch_wgrad<32, 128, 1, 4>(a, st);
     else if (bm == 64) launch_wgrad<64, 64, 2, 2>(a, st);
     else if (bn == 64) {

@@ -73,7 +73,8 @@ _TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometr
 # the kernel instantiation the launcher dispatches to, `flops` = 2 * rows * Cout * Cin * taps of the launch (x 2 for a
 # grouped pair), `replay()` issues the same launch again (same buffers) for the "alone on the device" timing.
 EVENTS = None
-_TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2"}
+_TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2",
+          7: "64, 64, 2, 2", 8: "64, 64, 2, 2"}
 
 
 def _igemm_key(t, x):
@@ -87,6 +88,9 @@ def _igemm_key(t, x):
         tag, bk = 4 | ((t >> 8) & 1), 32 if t & 0x200 else 16
     elif t & X3:
         tag, bk = 8 | ((t >> 8) & 1), 32
+        if tid >= 7:                        # K-divided 64 x 64 tiles: 7 = four k-groups of a 64-channel stage,
+            tag, bk = tag | 32, 64 if tid == 7 else 32          # 8 = two k-groups x two column halves of 32 channels
+            return f"conv_igemmg_kernel<{_TILES[tid]}, {tag}, {bk}, 2, false>"
     else:
         tag, bk = ((t >> 8) & 1) | (2 if t & MATH_BF16 else 0), 32 if t & 0x200 else 16
     skw = (t >> 20) & 7
@@ -386,16 +390,19 @@ def autotune(g, need_dgrad=True, reps=None):
         if kdim % 32 == 0:
             c += [t | 0x200 for t in tiles]
         # short grids: also try explicit split-K factors (bits 12-15) instead of the launcher's heuristic
+        if getattr(g, "x3", False) and not g.math and not g.h16 and n > 32:
+            # K-divided 64 x 64 tiles (the waves share the operand splits): K steps of 64 / 32 channels
+            c += ([7] if kdim % 64 == 0 else []) + ([8] if kdim % 32 == 0 else [])
         out = list(c)
         for t in c:
-            bm = 64 if (t & 0xFF) == 3 else 128
-            bn = {1: 128, 2: 64, 3: 64, 4: 32}[t & 0xFF]
+            bm = 64 if (t & 0xFF) in (3, 7, 8) else 128
+            bn = {1: 128, 2: 64, 3: 64, 4: 32, 7: 64, 8: 64}[t & 0xFF]
             ntiles = -(-m // bm) * -(-n // bn)
-            nk = taps * kdim // (32 if t & 0x200 else 16)
+            nk = taps * kdim // (64 if (t & 0xFF) == 7 else (32 if (t & 0x200 or (t & 0xFF) == 8) else 16))
             if ntiles < 1024:
                 out += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
                 # stream-K (fp32 tensors, fp32 / bf16-rounded math is decided by the launcher's tag: fp32 only)
-                if not g.math and not g.h16 and (t & 0xFF) in (2, 3, 4) and ntiles % 256:
+                if not g.math and not g.h16 and (t & 0xFF) in (2, 3, 4) and ntiles % 256:      # (not the K-divided tiles)
                     out += [t | (w * STREAMK) for w in (1, 2, 3, 4) if ntiles * nk >= 256 * w]
         return out
 
@@ -410,7 +417,7 @@ def autotune(g, need_dgrad=True, reps=None):
         y = torch.empty(g.lout.rows, g.cout, device=dev, dtype=dt)
         fc = cands(g.cin, g.cout, g.lout.rows, g.k * g.k)
         if not g.math and not g.h16:      # forward launches run alone on the device: 3 LDS stages may pay (0x20000)
-            fc = fc + [t | STAGES3 for t in fc]
+            fc = fc + [t | STAGES3 for t in fc if (t & 0xFF) < 7]
         ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), fc)
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
@@ -570,6 +577,9 @@ def autotune_wgrad(g, reps=None):
                     cands.append((tflag | 0x40, S))
                     if not g.math and not g.h16:
                         cands.append((tflag | 0x40 | 0x80, S))       # 32 pixels per stage
+                    if getattr(g, "x3", False) and t == 64:
+                        # the waves divide the pixels of a stage (64 four ways / 32 two ways) and share the operand splits
+                        cands += [(tflag | 0x40 | 0x400, S), (tflag | 0x40 | 0x800, S)]
         cands = sorted(set(cands))
         dt = torch.bfloat16 if g.h16 else torch.float32
         dy = torch.randn(M, g.cout, device=dev).to(dt)
@@ -655,11 +665,13 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
             if c["zero"] and skip_zero_rows:
                 assert addend is not None and addend.data_ptr() == dx.data_ptr()
                 continue
-            # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table
+            # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table (a K-divided
+            # tile needs 32 / 64 channels per stage: the plain 64 x 64 tile instead, no split-K)
+            ct = ((tile & ~0xF0FF) | 3) if (c["zero"] and (tile & 0xFF) >= 7) else tile
             _lib.call("radet_conv2d_igemm_taps", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
                       _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"],
                       (32 if _is16(dy) else 16) if c["zero"] else kc, g.cin,
-                      tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
+                      ct, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
         return
     _lib.call("radet_conv2d_igemm", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
@@ -674,7 +686,8 @@ def _wgrad_key(g, dy, co):
         return f"conv_wgrad9{'h' if _is16(dy) else 'g'}_kernel ({mode})"
     tf = (g.wgrad_flags >> 4) & 3
     tile = {0: "launcher tile", 1: "128, 128", 2: "64, 64", 3: "128, 64"}[tf] if co > 32 else "32, 128"
-    return f"conv_wgrad{'h' if _is16(dy) else 'g'}_kernel<{tile}> ({mode}{', 32 px' if g.wgrad_flags & 0x80 else ''})"
+    kd = ", 64 px / 4 waves" if g.wgrad_flags & 0x400 else (", 32 px / 2 waves" if g.wgrad_flags & 0x800 else "")
+    return f"conv_wgrad{'h' if _is16(dy) else 'g'}_kernel<{tile}> ({mode}{', 32 px' if g.wgrad_flags & 0x80 else ''}{kd})"
 
 
 def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):

@@ -112,6 +112,70 @@ def test_conv_fwd_dgrad_wgrad(K, case, math):
     assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5
 
 
+KDIV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, split-K
+    (2, 256, 256, 30, 40, 3, 1, 0),          # layer3 3x3
+    (1, 512, 512, 15, 20, 3, 1, 3),          # layer4 3x3, forced split-K = 3
+    (2, 1024, 256, 15, 20, 1, 1, 2),         # 1x1 down, split-K = 2
+    (3, 128, 192, 17, 23, 3, 1, 0),          # ragged M tile, ragged N tile (192 = 3 x 64), K = 128
+    (2, 128, 128, 18, 22, 3, 2, 0),          # strided: the dgrad is a class launch
+    (2, 256, 512, 15, 20, 1, 2, 0),          # 1x1 / 2: dgrad classes with rows that receive no tap
+    (1, 64, 64, 9, 11, 1, 1, 0),             # a single K stage
+]
+
+
+@pytest.mark.parametrize("kd", [7, 8], ids=["4-kgroups", "2-kgroups"])
+@pytest.mark.parametrize("case", KDIV_CASES)
+def test_k_divided_tiles(K, case, kd):
+    """The 64 x 64 tiles whose four waves divide the K step (tile 7: four 16-channel k-groups of a 64-channel stage, every
+    wave accumulates the whole tile; tile 8: two k-groups x two column halves of a 32-channel stage) and add their partial
+    tiles through LDS; and the pixel-divided one-tap wgrad (flags 0x400 / 0x800).  Same fp64 reference and tolerance as
+    every other fp32 path; bit-identical from run to run."""
+    B, Cin, Cout, H, W, k, s, sk = case
+    g = torch.Generator().manual_seed(sum(case) + kd)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    y_ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=pad)
+    Ho, Wo = y_ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g)
+    out_ref = F.relu(y_ref + res.double())
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    gx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride=s, padding=pad)
+    gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride=s, padding=pad)
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
+    geom.x3 = True
+    tile = kd | (sk << 12)
+    xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
+    y = torch.full((B * Ho * Wo, Cout), float("nan"), device=dev)
+    y2 = torch.full_like(y, float("nan"))
+    K.conv_fwd(geom, xr, wf, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)
+    K.conv_fwd(geom, xr, wf, bias.to(dev), y2, addend=to_rows(res).to(dev), relu=True, tile=tile)
+    assert torch.equal(y, y2)
+    assert rel_err(from_rows(y, B, Ho, Wo), out_ref) < 1e-5
+    if Cout % (64 if kd == 7 else 32) == 0:
+        dyr = to_rows(dy).to(dev)
+        wft = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).contiguous().to(dev)
+        dx = torch.full((B * H * W, Cin), float("nan"), device=dev)
+        mask = to_rows(torch.randn(B, Cin, H, W, generator=g)).to(dev)
+        K.conv_dgrad(geom, dyr, wft, dx, mask=mask, tile=tile)
+        gx_m = gx * (from_rows(mask.cpu(), B, H, W) > 0)
+        assert rel_err(from_rows(dx, B, H, W), gx_m) < 1e-5
+    # pixel-divided wgrad, a few split counts (the last split is ragged)
+    dyr = to_rows(dy).to(dev)
+    for S in (1, 3):
+        geom.wgrad_flags, geom.nsplit = (2 << 4) | 0x40 | (0x400 if kd == 7 else 0x800), S
+        slabs = torch.full((S, Cout, k * k, Cin), float("nan"), device=dev)
+        bp = torch.full((S, Cout), float("nan"), device=dev)
+        K.conv_wgrad(geom, dyr, xr, slabs, bp)
+        gw_mine = slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        assert rel_err(gw_mine, gw) < 2e-5, S
+        assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S
+
+
 @pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "fp32x3"])
 @pytest.mark.parametrize("shape", [
     # B, Cin, Cout, H, W, tile

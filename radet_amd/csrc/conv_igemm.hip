@@ -2154,7 +2154,10 @@ __global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
     const int tilesO = (a.Cout + BM - 1) / BM;
     const int tilesC = a.Cin / BC;
     const int tilesPerSplit = tilesO * tilesC;
-    int id = blockIdx.x;
+    // XCD-aware order: the channel tiles of one pixel split run next to each other on ONE XCD, so that its L2 serves the
+    // dy rows to all of them (grid order, tc fastest, put channel tile k of EVERY split on XCD k: each XCD then streamed
+    // the whole dy tensor -- 4.1x the algorithmic bytes at the fabric, profiles/round3_pmc_hbm_traffic*.txt)
+    int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int split = id / tilesPerSplit;
     id -= split * tilesPerSplit;
     const int to = id % tilesO, tc = id / tilesO;

@@ -894,7 +894,7 @@ def test_cabi_error_codes(K):
     with pytest.raises(_lib.RadetHipError):
         K.conv_fwd(g2, torch.zeros(64, 48, device=dev, dtype=torch.bfloat16), torch.zeros(32, 1, 48, device=dev, dtype=torch.bfloat16),
                    None, torch.zeros(64, 32, device=dev, dtype=torch.bfloat16))
-    n = 9000                                                              # NMS capacity is 8192 candidates per image
+    n = 70000                                                             # NMS capacity is 65536 candidates per image
     z = torch.zeros(1, n, device=dev)
     with pytest.raises(_lib.RadetHipError):
         K.nms(torch.zeros(1, n, 4, device=dev), z, z, torch.zeros(1, n, dtype=torch.long, device=dev),

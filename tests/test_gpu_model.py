@@ -132,6 +132,53 @@ def test_native_train_step_matches_autograd(det, golden):
             assert abs(rt.opt_state["grad_norm"].item() - float(golden("model")["total_grad_norm"])) < 1e-3 * 1053
 
 
+_OWN_STREAM_PROBE = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+import radet_amd                                   # (sets GPU_MAX_HW_QUEUES before the first HIP call)
+from radet_amd.runtime import GradReducer
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+g = torch.ones(1 << 20, device="cuda")
+red = GradReducer(g, torch.device("cuda", 0))
+side, probe = torch.cuda.Stream(), torch.cuda.Stream()
+main_ev, side_ev, done_ev = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+with torch.cuda.stream(side):                      # first use: communicator / stream set-up is not part of the probe
+    red.bucket_ready(dict(prefix="warm", arena=(0, g.numel())))
+torch.cuda.synchronize(); red.finish(); torch.cuda.synchronize()
+torch.cuda._sleep(int(2e9))                        # ~1 s on the main stream, BEFORE the hand-over
+main_ev.record()
+with torch.cuda.stream(side):
+    red.bucket_ready(dict(prefix="probe", arena=(0, g.numel())))
+    torch.cuda._sleep(int(2e9))                    # the handing stream parked AFTER the hand-over
+    side_ev.record()
+with torch.cuda.stream(probe):                     # a third stream that only waits for the collective
+    red.works[-1][0].wait()
+    done_ev.record()
+done_ev.synchronize()                              # host waits for the collective only
+print("PARKED", not main_ev.query(), not side_ev.query(), flush=True)
+torch.cuda.synchronize(); red.finish()
+assert float(g[0]) == 1.0
+dist.destroy_process_group()
+"""
+
+
+def test_collectives_run_on_their_own_stream():
+    """The bucket all-reduces neither wait for the main stream nor for what the handing (side) stream does after the
+    hand-over: with the main stream parked in a long spin kernel BEFORE the hand-over and the side stream parked in one AFTER
+    it, the collective still completes at once.  Run in a process of its own: in the test process dozens of streams from the
+    other tests share the device's hardware queues, and a collective queued behind a parked stream's spin kernel in the same
+    hardware queue says nothing about stream dependencies."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _OWN_STREAM_PROBE], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("PARKED")][-1]
+    assert line.split()[1:] == ["True", "True"], line
+
+
 def test_rccl_bucket_exchange_single_rank(det, golden):
     """The data-parallel step with a 1-rank RCCL group: bucketed async all-reduce on the comm stream, unfold on the
     side stream, mean folded into AdamW -- must equal the plain single-GPU step bit for bit."""
@@ -167,28 +214,6 @@ def test_rccl_bucket_exchange_single_rank(det, golden):
         assert all(0.0 <= b["ready_ms"] <= b["done_by_ms"] for b in rep["buckets"]) and rep["exposed_comm_ms"] >= 0.0
         assert rep["steps"] == 1 and rep["backward_ms"] > 0.0
         assert abs(sum(b["mbytes"] for b in rep["buckets"]) - ra.flat.n_train * 4 / 1e6) < 1.0
-        # ... and the collectives run on a stream of their own: with the main stream parked in a long spin kernel BEFORE the
-        # hand-over and the handing (side) stream parked in one AFTER it, the all-reduce still completes at once
-        from radet_amd.runtime import GradReducer
-        g = torch.ones(1 << 20, device="cuda")
-        red = GradReducer(g, torch.device("cuda", 0))
-        side, probe = torch.cuda.Stream(), torch.cuda.Stream()
-        main_ev, side_ev, done_ev = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-        torch.cuda.synchronize()
-        torch.cuda._sleep(int(4e8))                      # ~0.2 s on the main stream
-        main_ev.record()
-        with torch.cuda.stream(side):
-            red.bucket_ready(dict(prefix="probe", arena=(0, g.numel())))
-            torch.cuda._sleep(int(4e8))
-            side_ev.record()
-        with torch.cuda.stream(probe):                   # a third stream that only waits for the collective
-            red.works[-1][0].wait()
-            done_ev.record()
-        done_ev.synchronize()                            # host waits for the collective only
-        parked = (not main_ev.query(), not side_ev.query())
-        torch.cuda.synchronize()
-        red.finish()
-        assert parked == (True, True), parked
     finally:
         os.environ["RADET_FORCE_REDUCER"] = "0"
         dist.destroy_process_group()

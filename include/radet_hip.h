@@ -68,7 +68,10 @@ int radet_build_gather_table(int* table, int B, int KH, int KW, int so, int sr, 
  * plain launch when there is less than one K stage per workgroup; +0x1000000 = fp32 tensors, products formed on the
  * bf16 matrix cores from an exact three-way bf16 split of every fp32 operand (x = hi + mid + lo, 8 significand bits
  * each; 6 of the 9 plane products -- everything above 2^-24 relative -- through v_mfma_f32_32x32x16_bf16, fp32
- * accumulate; Cin % 32 == 0, otherwise the native fp32 MFMA is used); +0x2000000 = the same arithmetic with operands
+ * accumulate; Cin % 32 == 0, otherwise the native fp32 MFMA is used), with two more tiles: 7 / 8 = 64 x 64 tiles whose four
+ * waves divide the K step (four 16-channel k-groups of a 64-channel stage, Cin % 64 == 0 / two k-groups x two column halves of
+ * a 32-channel stage) and add their partial tiles through LDS -- every operand element is split once per workgroup
+ * (-1 for these tiles without 0x1000000, with stream-K bits, or when Cin does not divide); +0x2000000 = the same arithmetic with operands
  * that ARRIVE as bf16 plane triples (x rows [3][Cin] bf16, w [Cout][taps][3][Cin] bf16 -- "planes" below; y, addend, mask,
  * bias fp32; Cin % 32 == 0): no operand split in the K loop; tiles 1..4 as above plus 5 = 128 x 128 and 6 = 256 x 128 with
  * 8 waves; K step 32 channels, or 16 with +0x4000000; +0x20000 = one more LDS stage.  splitk_ws (may be NULL): workspace of splitk_ws_floats floats whose first 16384 words are arrival
@@ -115,7 +118,8 @@ int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntile
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bit 8 (0x100): fp32 products from three bf16
  * planes per operand (as tile_override 0x1000000); bits 4-5: tile override of the one-tap
  * kernel (1 = 128x128, 2 = 64x64; S is then the caller's choice); bit 6: never use the all-taps kernel; bit 7: 32
- * instead of 16 pixels per LDS stage in the one-tap fp32 kernel;
+ * instead of 16 pixels per LDS stage in the one-tap fp32 kernel; bits 10 / 11 (0x400 / 0x800, with 0x100 and the 64x64 tile):
+ * the four waves divide a 64-pixel stage four ways / a 32-pixel stage two ways and share the operand splits;
  * bit 1: bf16 storage -- dy and x are bf16 tensors (ld_dy / Cin in elements, multiples of 8), slabs stay fp32;
  * bit 9 (0x200): dy and x are bf16 plane triples (dy rows [3][ld_dy], x rows [3][Cin]; 3x3 convs with Cin % 32 == 0). */
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);

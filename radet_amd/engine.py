@@ -16,6 +16,7 @@ Reference call sites this replaces: ResNet.forward (radet/models/backbones/resne
 FPN.forward (necks/fpn.py:170-221), ATSSHead.forward / RADetHead.forward_single
 (dense_heads/atss_head.py:100-145, radet_head.py:27-30) and their autograd backward.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -692,6 +693,20 @@ class Engine:
         K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], ws)
         return y
 
+    tower_fwd_streams = os.environ.get("RADET_TOWER_FWD_STREAMS", "1") != "0"
+
+    def _tower_fwd_layer_p(self, t, tower, i, x, ws):
+        """one tower layer with plane operands on the current stream: GEMM (256 x 128 tiles, no split-K) + GroupNorm + ReLU"""
+        b, p = self.buf, self.p
+        c = tower[i]
+        z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
+        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12))
+        gn = f"bbox_head.{t}_convs.{i}.gn"
+        pl = K._isp(y)                  # the last layer's output feeds the predictor convs: fp32
+        K.gn_relu_fwd_p(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], None if pl else y, y if pl else None,
+                        b[f"{t}.stats{i}"], ws)
+        return y
+
     # "streams": cls / reg towers on two HIP streams; "pair": cls+reg layer = one grouped launch (forward and backward);
     # "hybrid" (default): grouped forward launches (they run alone on the device -> clean roofline measurement),
     # two-stream backward (dgrad / wgrad / GroupNorm of the two towers overlap).  bench: 229.5 / 227.7 / 232 img/s
@@ -729,19 +744,37 @@ class Engine:
             if self.p3:
                 K.split_planes(P, b["Pp"])
                 xc = xr = b["Pp"]
-            for i in range(n):
-                xc, xr = self._tower_pair_fwd(i, xc, xr)
+            if self.p3 and self.tower_fwd_streams:
+                # plane operands: a tower GEMM is 200 tiles of 256 x 128 and a tile owns a CU, so the grouped cls + reg launch
+                # is two rounds on 256 CUs with the second 56 % full.  The two towers as two chains on two streams instead:
+                # the tiles of one chain's GEMM take the CUs the other chain's GEMM leaves free (1600 tiles = 6.25 rounds
+                # instead of 8), its GroupNorm runs next to the other chain's GEMM
+                side = self._side()
+                self._fork(side)
+                for i in range(n):
+                    xc = self._tower_fwd_layer_p("cls", self.cls_tower, i, xc, self.gn_ws)
+                    with torch.cuda.stream(side):
+                        xr = self._tower_fwd_layer_p("reg", self.reg_tower, i, xr, self.gn_ws2)
+            else:
+                side = None
+                for i in range(n):
+                    xc, xr = self._tower_pair_fwd(i, xc, xr)
+            reg_stream = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
             if self.x3 and self.feat % 16 == 0 and self.pred_cls.cout <= 32 and self.pred_reg.cout + self.pred_iou.cout <= 32 \
                     and os.environ.get("RADET_PRED_PATCH", "1") != "0":      # (the patch kernel's tile has 32 output columns)
                 # direct convolution from an LDS patch: the tower output is fetched 1.4 times instead of 9, reg + iou
                 # share one launch
                 pc, pr, pi = self.pred_cls, self.pred_reg, self.pred_iou
                 K.pred_conv_patch(self.plv, xc, (pc.wf, pc.bias_f, b["cls"], pc.cout))
-                K.pred_conv_patch(self.plv, xr, (pr.wf, pr.bias_f, b["reg_u"], pr.cout), (pi.wf, pi.bias_f, b["iou"], pi.cout))
+                with reg_stream:
+                    K.pred_conv_patch(self.plv, xr, (pr.wf, pr.bias_f, b["reg_u"], pr.cout), (pi.wf, pi.bias_f, b["iou"], pi.cout))
             else:
                 K.conv_fwd(self.pred_cls.geom, xc, self.pred_cls.wf, self.pred_cls.bias_f, b["cls"])
-                K.conv_fwd(self.pred_reg.geom, xr, self.pred_reg.wf, self.pred_reg.bias_f, b["reg_u"])
-                K.conv_fwd(self.pred_iou.geom, xr, self.pred_iou.wf, self.pred_iou.bias_f, b["iou"])
+                with reg_stream:
+                    K.conv_fwd(self.pred_reg.geom, xr, self.pred_reg.wf, self.pred_reg.bias_f, b["reg_u"])
+                    K.conv_fwd(self.pred_iou.geom, xr, self.pred_iou.wf, self.pred_iou.bias_f, b["iou"])
+            if side is not None:
+                self._join(side)
         elif self.use_streams:
             side = self._side()
             self._fork(side)

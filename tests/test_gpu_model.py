@@ -363,12 +363,17 @@ def test_detect_stream_matches_detect():
     rt = det.runtime()
     with torch.no_grad():
         det.bbox_head.atss_cls.bias += 2.0
-    metas = [dict(img_shape=(160, 192, 3), scale_factor=np.ones(4, np.float32)) for _ in range(2)]
     g = torch.Generator().manual_seed(4)
-    imgs = [torch.randn(2, 3, 160, 192, generator=g).cuda() for _ in range(4)]
-    ref = [rt.detect(im, metas, det.test_cfg, rescale=True) for im in imgs]
-    got = list(rt.detect_stream(((im, metas) for im in imgs), det.test_cfg, rescale=True))
-    assert len(got) == len(ref)
-    for a, b in zip(got, ref):
-        for (da, la), (db, lb) in zip(a, b):
-            assert torch.equal(da, db) and torch.equal(la, lb) and da.shape[0] > 0
+    # two geometries in one stream (two plans, two pairs of head-output sets), an odd number of batches each; decode + NMS of a
+    # batch run next to the forward pass of the next one, on their own stream
+    work = []
+    for (h, w, n) in ((160, 192, 3), (320, 384, 5)):
+        metas = [dict(img_shape=(h, w, 3), scale_factor=np.full(4, 0.5 + 0.25 * i, np.float32)) for i in range(2)]
+        work += [(torch.randn(2, 3, h, w, generator=g).cuda(), metas) for _ in range(n)]
+    ref = [rt.detect(im, metas, det.test_cfg, rescale=True) for im, metas in work]
+    for _ in range(2):
+        got = list(rt.detect_stream(iter(work), det.test_cfg, rescale=True))
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            for (da, la), (db, lb) in zip(a, b):
+                assert torch.equal(da, db) and torch.equal(la, lb) and da.shape[0] > 0

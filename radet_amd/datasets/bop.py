@@ -16,7 +16,7 @@ import tempfile
 import numpy as np
 
 from ..utils import Registry, build_from_cfg
-from .cocoeval import COCO, COCOeval
+from .cocoeval import COCO, COCOeval, eval_recalls
 from .pipelines import PIPELINES
 
 osp = os.path
@@ -256,9 +256,9 @@ class BOPDataset:
     def _check_metrics(metric, metric_items):
         metrics = list(metric) if isinstance(metric, (list, tuple)) else [metric]
         for m in metrics:
-            if m in ("segm", "proposal_fast"):
-                raise NotImplementedError(f"metric {m} is outside the detector hot-path scope (boxes only)")
-            if m not in ("bbox", "proposal"):
+            if m == "segm":
+                raise NotImplementedError("metric segm is outside the detector hot-path scope (the detector outputs boxes only)")
+            if m not in ("bbox", "proposal", "proposal_fast"):
                 raise KeyError(f"metric {m} is not supported")
         items = None if metric_items is None else (list(metric_items) if isinstance(metric_items, (list, tuple))
                                                    else [metric_items])
@@ -281,6 +281,21 @@ class BOPDataset:
         _log("\n" + "\n".join(lines), logger)
         return rows
 
+    def fast_eval_recall(self, results, proposal_nums, iou_thrs, logger=None):
+        """Average recall (over `iou_thrs`) of the non-crowd, non-ignored ground-truth boxes by the top-N boxes of every image,
+        straight from the result arrays (coco.py:311-333).  An image's result is an (k, 5) / (k, 4) array, or the detector's
+        per-class list, whose classes are pooled."""
+        gts = []
+        for img_id in self.img_ids:
+            anns = self.coco.load_anns(self.coco.get_ann_ids(img_ids=[img_id]))
+            keep = [a["bbox"] for a in anns if not a.get("ignore", False) and not a["iscrowd"]]
+            xywh = np.asarray(keep, np.float64).reshape(-1, 4)          # (corners formed in double, then stored as fp32)
+            gts.append(np.concatenate([xywh[:, :2], xywh[:, :2] + xywh[:, 2:]], axis=1).astype(np.float32) if len(keep)
+                       else np.zeros((0, 4)))
+        pooled = [np.concatenate([np.asarray(c).reshape(-1, 5) for c in r], axis=0) if isinstance(r, (list, tuple)) else np.asarray(r)
+                  for r in results]
+        return eval_recalls(gts, pooled, proposal_nums, iou_thrs).mean(axis=1)
+
     def evaluate(self, results, metric="bbox", logger=None, jsonfile_prefix=None, classwise=False,
                  proposal_nums=(1, 10, 100), iou_thrs=None, metric_items=None):
         """COCO-protocol evaluation of per-class box lists; returns e.g. {'bbox_mAP': .., 'bbox_mAP_50': .., ...,
@@ -291,11 +306,16 @@ class BOPDataset:
                                "evaluate with bop_submission=False")
         if iou_thrs is None:
             iou_thrs = np.linspace(0.5, 0.95, 10)
-        files, scratch = self.format_results(results, jsonfile_prefix)
+        files, scratch = (None, None) if all(m == "proposal_fast" for m in metrics) else self.format_results(results, jsonfile_prefix)
         out = {}
         try:
             for m in metrics:
                 _log(("\n" if logger is None else "") + f"Evaluating {m}...", logger)
+                if m == "proposal_fast":
+                    ar = self.fast_eval_recall(results, proposal_nums, iou_thrs)
+                    out.update((f"AR@{n}", ar[i]) for i, n in enumerate(proposal_nums))
+                    _log("".join(f"\nAR@{n}\t{ar[i]:.4f}" for i, n in enumerate(proposal_nums)), logger)
+                    continue
                 try:
                     detections = self.coco.loadRes(files[m])
                 except IndexError:

@@ -270,3 +270,56 @@ class COCOeval:
             self._summarize(0, area="small", max_dets=md[2]), self._summarize(0, area="medium", max_dets=md[2]),
             self._summarize(0, area="large", max_dets=md[2])])
         return self.stats
+
+
+# ----------------------------------------------------------------------------- class-agnostic recall ('proposal_fast')
+def box_iou_matrix(a, b, eps=1e-6):
+    """IoU of every box of a (n, 4) with every box of b (k, 4), fp32, the arithmetic of the reference's NumPy
+    `bbox_overlaps` (radet/core/evaluation/bbox_overlaps.py:4-50: plain x2 - x1 extents, union clamped at eps)."""
+    a, b = np.asarray(a, np.float32).reshape(-1, 4), np.asarray(b, np.float32).reshape(-1, 4)
+    if a.shape[0] == 0 or b.shape[0] == 0:
+        return np.zeros((a.shape[0], b.shape[0]), np.float32)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    w = np.maximum(np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]), 0)
+    h = np.maximum(np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]), 0)
+    inter = w * h
+    union = np.maximum(area_a[:, None] + area_b[None, :] - inter, eps)
+    return (inter / union).astype(np.float32)
+
+
+def eval_recalls(gts, proposals, proposal_nums=(100, 300, 1000), iou_thrs=0.5):
+    """Recall of ground-truth boxes by the top-N proposals per image -> array [len(proposal_nums), len(iou_thrs)]
+    (radet/core/evaluation/recall.py:10-106).  Per image the proposals are ranked by score (column 4, when present), cut
+    at the largest N, and ground truths and proposals are matched one to one greedily by IoU: the best remaining pair is
+    taken (first in row-major order among equals), its row and column leave the pool, until every ground truth has had a
+    turn -- a ground truth left without a proposal scores -1 (0 when the image has no proposal at all).  A ground truth
+    counts as recalled at threshold t when its matched IoU >= t."""
+    nums = np.atleast_1d(np.asarray(proposal_nums)).astype(np.int64)
+    thrs = np.atleast_1d(np.asarray(iou_thrs, dtype=np.float64))
+    assert len(gts) == len(proposals)
+    mats = []
+    for gt, pr in zip(gts, proposals):
+        pr = np.asarray(pr)
+        if pr.ndim == 2 and pr.shape[1] == 5:
+            pr = pr[np.argsort(pr[:, 4])[::-1]]
+        pr = pr[:min(pr.shape[0], int(nums[-1]))]
+        n_gt = 0 if gt is None else np.asarray(gt).shape[0]
+        mats.append(box_iou_matrix(gt, pr[:, :4]) if n_gt else np.zeros((0, pr.shape[0]), np.float32))
+    total = sum(m.shape[0] for m in mats)
+    matched = np.zeros((nums.size, total), np.float32)
+    for k, n in enumerate(nums):
+        col = 0
+        for m in mats:
+            pool = m[:, :n].copy()
+            g = pool.shape[0]
+            if pool.size:
+                for j in range(g):
+                    r, c = np.unravel_index(np.argmax(pool), pool.shape)
+                    matched[k, col + j] = pool[r, c]
+                    pool[r, :] = -1
+                    pool[:, c] = -1
+            col += g
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.stack([(matched >= t).sum(axis=1) / float(total) for t in thrs], axis=1)
+

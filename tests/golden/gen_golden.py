@@ -431,6 +431,59 @@ def gen_model(det, assign):
     save("model", **out)
 
 
+def gen_recall():
+    """eval_recalls (radet/core/evaluation/recall.py) on seeded boxes: ragged images (no ground truth, no proposals, more
+    ground truths than proposals), tied scores and exact-threshold IoUs."""
+    import types
+    from radet.core.evaluation import recall as ref_recall
+    from radet.core.evaluation.recall import eval_recalls
+
+    # the reference builds a ragged array with np.array(list of matrices), which NumPy >= 1.24 only does with dtype=object
+    # (older NumPy did it implicitly): run it with that one call made explicit
+    class _Np(types.ModuleType):
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def array(x, *a, **kw):
+            try:
+                return np.array(x, *a, **kw)
+            except ValueError:
+                out = np.empty(len(x), dtype=object)
+                for i, v in enumerate(x):
+                    out[i] = v
+                return out
+    ref_recall.np = _Np("np_compat")
+    ref_recall.print_recall_summary = lambda *a, **k: None        # (the table printer needs terminaltables; not data)
+    rng = np.random.RandomState(7)
+    gts, props = [], []
+    for i in range(12):
+        g = rng.randint(0, 7) if i not in (3, 9) else (0 if i == 3 else 5)
+        k = rng.randint(0, 40) if i not in (5, 9) else (0 if i == 5 else 2)
+        xy = rng.uniform(0, 200, (g, 2))
+        gt = np.concatenate([xy, xy + rng.uniform(10, 120, (g, 2))], 1).astype(np.float32)
+        pxy = rng.uniform(0, 200, (k, 2))
+        pr = np.concatenate([pxy, pxy + rng.uniform(10, 120, (k, 2)), rng.uniform(0, 1, (k, 1))], 1).astype(np.float32)
+        for j in range(min(g, k) // 2):                     # some proposals are jittered copies of ground truths
+            pr[j, :4] = gt[j] + rng.uniform(-6, 6, 4).astype(np.float32)
+        if k > 3:
+            pr[1, 4] = pr[2, 4]                             # tied scores
+        if g and k:
+            pr[-1, :4] = gt[-1] * np.float32(1.0)           # IoU exactly 1
+        gts.append(gt)
+        props.append(pr)
+    gts[0] = np.array([[0, 0, 10, 10]], np.float32)
+    props[0] = np.array([[0, 0, 10, 5, 0.9], [0, 0, 10, 7.5, 0.8]], np.float32)      # IoU exactly 0.5 and 0.75
+    nums = np.array([1, 5, 20, 100])
+    thrs = np.linspace(0.5, 0.95, 10)
+    rec = eval_recalls(gts, props, nums, thrs, logger="silent")
+    out = dict(nums=nums, thrs=thrs, recalls=rec, n=np.int64(len(gts)),
+               recalls_single=eval_recalls(gts, props, 10, 0.5, logger="silent"))
+    for i, (g, p) in enumerate(zip(gts, props)):
+        out[f"gt{i}"], out[f"pr{i}"] = g, p
+    save("recall", **out)
+
+
 def gen_model_grads(det, assign):
     """Sampled gradient ELEMENTS of every trainable parameter (model.npz holds only their norms, which a tap transposition
     or a sign error inside a tensor would preserve): same weights / batch as gen_model."""
@@ -466,6 +519,9 @@ def gen_model_grads(det, assign):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ops2":       # only the second op set (the other fixtures stay as committed)
         gen_ops2()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "recall":     # only recall.npz
+        gen_recall()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "grads":      # only model_grads.npz (inputs from the committed assigner.npz)
         torch.manual_seed(0)

@@ -131,6 +131,35 @@ def test_evaluate_perfect_and_degraded(bop):
     assert set(saved) == {"0", "7"} and saved["0"][0].keys() == {"bbox_obj", "obj_id", "score"} and 1 in conv
 
 
+def test_eval_recalls_vs_reference_golden():
+    """radet_amd.datasets.cocoeval.eval_recalls against the reference's eval_recalls (tests/golden/recall.npz, written by
+    tests/golden/gen_golden.py recall): ragged images, tied scores, exact-threshold IoUs; bit-equal recalls."""
+    from radet_amd.datasets.cocoeval import eval_recalls, box_iou_matrix
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "recall.npz"))
+    gts = [g[f"gt{i}"] for i in range(int(g["n"]))]
+    prs = [g[f"pr{i}"] for i in range(int(g["n"]))]
+    rec = eval_recalls(gts, prs, g["nums"], g["thrs"])
+    assert rec.shape == g["recalls"].shape and np.array_equal(rec, g["recalls"])
+    assert np.array_equal(eval_recalls(gts, prs, 10, 0.5), g["recalls_single"])
+    assert box_iou_matrix(np.zeros((0, 4)), prs[1][:, :4]).shape == (0, prs[1].shape[0])
+    iou = box_iou_matrix(gts[0], prs[0][:, :4])
+    assert iou.dtype == np.float32 and iou[0, 0] == np.float32(0.5) and iou[0, 1] == np.float32(0.75)
+
+
+def test_proposal_fast_metric(bop):
+    from radet_amd.datasets import BOPDataset
+    root, ann, coco = bop
+    ds = BOPDataset(ann, pipeline=[], test_mode=True)
+    ev = ds.evaluate(gt_as_results(ds, coco), metric="proposal_fast", logger="silent", proposal_nums=(1, 10, 100))
+    assert set(ev) == {"AR@1", "AR@10", "AR@100"} and ev["AR@100"] == 1.0 and 0.0 < ev["AR@1"] < 1.0
+    # pooled (k, 5) arrays per image are accepted as well (what the reference's RPN-style results look like)
+    pooled = [np.concatenate(r, axis=0) for r in gt_as_results(ds, coco, jitter=6.0)]
+    ev2 = ds.evaluate(pooled, metric=["proposal_fast"], logger="silent", proposal_nums=(100,), iou_thrs=[0.5, 0.95])
+    assert 0.5 <= ev2["AR@100"] < 1.0
+    with pytest.raises(NotImplementedError):
+        ds.evaluate(pooled, metric="segm")
+
+
 def test_cocoeval_hand_worked_case():
     """One image, one class, 2 gts, 3 detections in score order [TP (IoU 1.0), FP, TP (IoU 0.6)]:
     at IoU thresholds <= 0.6 the precision / recall points are (1, .5), (.5, .5), (2/3, 1): the envelope gives precision 1

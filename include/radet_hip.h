@@ -144,6 +144,16 @@ int radet_unfold_grads(const RadetConvDesc* table_dev, int nconv, int max_cout, 
 int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc, int B,
                             int H, int W, void* stream);
 int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* resnet.py:570,630 */
+/* Trainable stem (ResNet(frozen_stages=-1): conv1 / bn1 get gradients, resnet.py:572-588).  Backward of the max-pool fused with
+ * the stem's ReLU: ds = [s > 0] * (dpool routed to the first maximum of each 3x3 / 2 window in row-major order -- the element
+ * torch's MaxPool2d backward picks); s = stem output [B,H,W,C], dpool [B,Ho,Wo,C], fp32, C % 4 == 0. */
+int radet_maxpool3x3s2_bwd_relu(const float* s, const float* dpool, float* ds, int B, int H, int W, int C, void* stream);
+/* Weight gradient of the 7x7 / 2 stem conv from the NCHW image: slabs[S][64][49][3] (pixel splits, the layout radet_unfold_grads
+ * reduces) and dbias_partials[S][64] (column sums of ds, may be NULL); ds = gradient w.r.t. the stem's pre-activation
+ * [B*Ho*Wo, 64].  S from radet_stem_wgrad_splits (or any S >= 1). */
+int radet_stem_wgrad_splits(int B, int H, int W);
+int radet_stem_wgrad(const float* img_nchw, const float* ds, float* slabs, float* dbias_partials, int B, int H, int W, int S,
+                     void* stream);
 
 /* ---- GroupNorm(32, 256) + ReLU over a multi-level buffer (atss_head.py:32,60-76 via mmcv ConvModule) */
 int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg);

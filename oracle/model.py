@@ -399,14 +399,14 @@ def get_bboxes(cls_scores, bbox_preds, iou_preds, img_metas, test_cfg, rescale=T
 class OracleDetector:
     """State-dict-driven detector. `sd` tensors that are trainable get requires_grad=True."""
 
-    def __init__(self, depth=50, seed=None, test_cfg=None, math="fp32", num_classes=NUM_CLASSES):
+    def __init__(self, depth=50, seed=None, test_cfg=None, math="fp32", num_classes=NUM_CLASSES, frozen_stages=1):
         from . import synth
         self.depth, self.math, self.num_classes = depth, math, num_classes
         self.sd = make_state_dict(depth, num_classes)
         if seed is not None:
             synth.fill_state_dict(self.sd, seed)
         for n, t in self.sd.items():
-            if t.is_floating_point() and is_trainable(n):
+            if t.is_floating_point() and is_trainable(n, frozen_stages):
                 t.requires_grad_(True)
         self.test_cfg = test_cfg or dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, max_per_img=100,
                                          nms=dict(type="vote", iou_threshold=0.65, cluster_score=["cls", "iou"],

@@ -47,6 +47,9 @@ SIGNATURES = {
     "radet_unfold_grads": (_i, [_p, _i, _i, _p]),
     "radet_stem_conv_bn_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "radet_maxpool3x3s2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "radet_maxpool3x3s2_bwd_relu": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "radet_stem_wgrad_splits": (_i, [_i, _i, _i]),
+    "radet_stem_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "radet_gn_workspace_floats": (_i, [_i, _p, _i]),
     "radet_gn_relu_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
     "radet_gn_relu_fwd_pair": (_i, [_p] * 12 + [_i, _i, _i, _f, _i, _p, _i, _p]),

@@ -210,6 +210,139 @@ extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W,
     return radet_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------ trainable stem (frozen_stages = -1)
+// Backward of max-pool 3x3 / 2 (pad 1) fused with the stem's ReLU: ds[n, y, x, c] = [s > 0] * the sum of dpool over the (at
+// most four) windows that contain (y, x) and whose FIRST maximum in row-major scan order over their in-range positions is
+// (y, x) -- the element torch.nn.MaxPool2d routes the gradient to (resnet.py:570,630 + autograd).  Gather form: no atomics, one
+// writer per element.
+__global__ void maxpool_bwd_relu_kernel(const float* __restrict__ s, const float* __restrict__ dpool, float* __restrict__ ds,
+                                        int B, int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        size_t p = i / C4;
+        const int x = (int)(p % W);
+        p /= W;
+        const int y = (int)(p % H);
+        const int n = (int)(p / H);
+        const float4 v = ld4(s, i);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = y >> 1; oy <= min((y + 1) >> 1, Ho - 1); ++oy)
+            for (int ox = x >> 1; ox <= min((x + 1) >> 1, Wo - 1); ++ox) {
+                bool seen = false;
+                bool fx = true, fy = true, fz = true, fw = true;          // (y, x) is the first maximum of this window, per channel
+                for (int r = 0; r < 3; ++r) {
+                    const int iy = oy * 2 - 1 + r;
+                    if (iy < 0 || iy >= H) continue;
+                    for (int q = 0; q < 3; ++q) {
+                        const int ix = ox * 2 - 1 + q;
+                        if (ix < 0 || ix >= W) continue;
+                        if (iy == y && ix == x) { seen = true; continue; }
+                        const float4 u = ld4(s, ((size_t)(n * H + iy) * W + ix) * C4 + c);
+                        if (!seen) { fx &= u.x < v.x; fy &= u.y < v.y; fz &= u.z < v.z; fw &= u.w < v.w; }   // earlier: strictly less
+                        else       { fx &= u.x <= v.x; fy &= u.y <= v.y; fz &= u.z <= v.z; fw &= u.w <= v.w; }
+                    }
+                }
+                const float4 d = ld4(dpool, ((size_t)(n * Ho + oy) * Wo + ox) * C4 + c);
+                if (fx) g.x += d.x;
+                if (fy) g.y += d.y;
+                if (fz) g.z += d.z;
+                if (fw) g.w += d.w;
+            }
+        st4(ds, i, make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f));
+    }
+}
+
+extern "C" int radet_maxpool3x3s2_bwd_relu(const float* s, const float* dpool, float* ds, int B, int H, int W, int C, void* stream) {
+    if (C % 4 || B <= 0 || H <= 0 || W <= 0) return RADET_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool_bwd_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, dpool, ds, B, H, W, C / 4, Ho, Wo);
+    return radet_check_launch();
+}
+
+// Weight gradient of the 7x7 / 2 stem conv (3 -> 64) straight from the NCHW image: slabs[split][o][tap][c] = sum over the
+// split's output pixels of ds[pixel][o] * img[n, c, 2 y - 3 + ky, 2 x - 3 + kx] (zero outside the image), and the column sums of
+// ds (the folded BN's shift gradient) -- the layout `radet_unfold_grads` reduces.  5.8 GFLOP per step at bs 4 and off every
+// BOP config's path (they freeze the stem), so a plain VALU kernel: a workgroup walks its pixels 16 at a time (ds rows and
+// the 147-element input patches in LDS), thread (o, kg) keeps 40 of the 147 products of output channel o in registers and
+// reads the patch as broadcast float4s.  One writer per slab element, pixels in ascending order: deterministic.
+#define SW_PIX 16
+#define SW_K 160            // 147 patch elements padded to four groups of 40
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const float* __restrict__ ds,
+                                                         float* __restrict__ slabs, float* __restrict__ dbias_partials, int B, int H,
+                                                         int W, int Ho, int Wo, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) float sds[SW_PIX][64];
+    __shared__ __attribute__((aligned(16))) float sp[SW_PIX][SW_K];
+    const int t = threadIdx.x, o = t & 63, kg = t >> 6;
+    const long npix = (long)B * Ho * Wo;
+    const long p0 = (long)blockIdx.x * chunks_per_split * SW_PIX;
+    const long p1 = p0 + (long)chunks_per_split * SW_PIX < npix ? p0 + (long)chunks_per_split * SW_PIX : npix;
+    float acc[40];
+#pragma unroll
+    for (int j = 0; j < 40; ++j) acc[j] = 0.f;
+    float bsum = 0.f;
+    for (long base = p0; base < p1; base += SW_PIX) {
+        {   // ds tile: 16 pixels x 64 channels, one float4 per thread
+            const int px = t >> 4, c4 = t & 15;
+            const long pix = base + px;
+            const float4 v = pix < p1 ? ld4(ds, (size_t)pix * 16 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&sds[px][4 * c4]) = v;
+        }
+        for (int e = t; e < SW_PIX * SW_K; e += 256) {      // input patches: element k = tap * 3 + c
+            const int px = e / SW_K, k = e - px * SW_K;
+            const long pix = base + px;
+            float v = 0.f;
+            if (k < 147 && pix < p1) {
+                const int tap = k / 3, c = k - 3 * tap, ky = tap / 7, kx = tap - 7 * ky;
+                const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), n = (int)(pix / ((long)Wo * Ho));
+                const int iy = 2 * y - 3 + ky, ix = 2 * x - 3 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[((size_t)(n * 3 + c) * H + iy) * W + ix];
+            }
+            sp[px][k] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int px = 0; px < SW_PIX; ++px) {
+            const float d = sds[px][o];
+            if (kg == 0) bsum += d;
+            const float4* pp = reinterpret_cast<const float4*>(&sp[px][40 * kg]);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float4 u = pp[j];
+                acc[4 * j] += d * u.x; acc[4 * j + 1] += d * u.y; acc[4 * j + 2] += d * u.z; acc[4 * j + 3] += d * u.w;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = slabs + ((size_t)blockIdx.x * 64 + o) * 147;
+#pragma unroll
+    for (int j = 0; j < 40; ++j)
+        if (40 * kg + j < 147) out[40 * kg + j] = acc[j];
+    if (kg == 0 && dbias_partials != nullptr) dbias_partials[(size_t)blockIdx.x * 64 + o] = bsum;
+}
+
+extern "C" int radet_stem_wgrad_splits(int B, int H, int W) {
+    const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
+    const long chunks = ((long)B * Ho * Wo + SW_PIX - 1) / SW_PIX;
+    long S = (chunks + 31) / 32;
+    if (S < 1) S = 1;
+    if (S > 1024) S = 1024;
+    return (int)S;
+}
+
+extern "C" int radet_stem_wgrad(const float* img_nchw, const float* ds, float* slabs, float* dbias_partials, int B, int H, int W,
+                                int S, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || S < 1) return RADET_ERR_ARG;
+    const int Ho = (H + 2 * 3 - 7) / 2 + 1, Wo = (W + 2 * 3 - 7) / 2 + 1;
+    const long chunks = ((long)B * Ho * Wo + SW_PIX - 1) / SW_PIX;
+    const int cps = (int)((chunks + S - 1) / S);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, img_nchw, ds, slabs, dbias_partials, B, H, W,
+                       Ho, Wo, cps);
+    return radet_check_launch();
+}
+
 // ------------------------------------------------------------------------------------------ fold / unfold
 // fold: for every conv in the table, s[o] = gamma*rsqrt(var+eps) (1 without BN):
 //   wf[o][t][c] = s[o] * w[o][c][t] ; wft[c][t][o] = same value ; bias_f[o] = beta - mean*s | conv bias | 0

@@ -33,6 +33,13 @@ def conv_out_hw(h, w, k, s, p):
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
+class _StemSplits:
+    """What the slab / descriptor bookkeeping needs from a conv geometry, for the stem (which has its own kernels)"""
+
+    def __init__(self, nsplit):
+        self.nsplit = nsplit
+
+
 class Conv:
     """One convolution layer: parameters by name, folded buffers, geometry-bound slabs."""
 
@@ -143,12 +150,12 @@ class Engine:
 
     def _build_layers(self):
         fs = self.frozen_stages
-        if fs < 0:
-            # the reference trains conv1 / bn1 when frozen_stages = -1 (resnet.py:572-588); the stem has no
-            # weight-gradient / max-pool backward kernels here, and silently leaving its gradients at zero would let
-            # AdamW's weight decay shrink the stem
-            raise NotImplementedError("ResNet(frozen_stages=-1) (trainable stem) is not implemented on MI355X: every "
-                                      "RADet config freezes the stem (frozen_stages >= 0; the BOP configs use 1)")
+        if fs < 0 and self.h16:
+            # the reference trains conv1 / bn1 when frozen_stages = -1 (resnet.py:572-588): built for the fp32-tensor modes
+            # (max-pool backward + stem weight gradient read fp32 activations); silently leaving the stem's gradients at zero
+            # would let AdamW's weight decay shrink it
+            raise NotImplementedError("ResNet(frozen_stages=-1) (trainable stem) with bf16 storage is not implemented on MI355X: "
+                                      "every RADet config freezes the stem (frozen_stages >= 0; the BOP configs use 1)")
         self.stem = self._add(Conv("backbone.conv1", 3, 64, 7, 2, 3, bn="backbone.bn1", trainable=fs < 0, dgrad=False))
         self.stages = []
         inpl = 64
@@ -280,6 +287,10 @@ class Engine:
 
         new("stem", B * h1 * w1, 64)
         new("pool", B * h2 * w2, 64)
+        if self.stem.trainable:           # frozen_stages = -1: gradients w.r.t. the pooled map and the stem's pre-activation
+            new("d_pool", B * h2 * w2, 64)
+            new("d_stem", B * h1 * w1, 64)
+            self.stem.geom = _StemSplits(K.stem_wgrad_splits(B, H, W))
         lv = Levels([(h2, w2)], B)
         for li, blocks in enumerate(self.stages):
             for b, blk in enumerate(blocks):
@@ -565,6 +576,7 @@ class Engine:
     def backbone_forward(self, img):
         B, H, W = self.B, self.H, self.W
         b = self.buf
+        self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
         K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
         x = b["pool"]
@@ -1047,5 +1059,16 @@ class Engine:
             self.flush_wgrads()
             if after_stage is not None:
                 after_stage(li)
+        if self.stem.trainable and nxt is not None and nxt is self.stages[0][0]:
+            # frozen_stages = -1: through layer1.0's conv1 + projection shortcut to the pooled map, through the max-pool and
+            # the stem's ReLU, into conv1 / bn1 (resnet.py:572-588 leaves them trainable)
+            d_pool, d_stem = b["d_pool"], b["d_stem"]
+            K.conv_dgrad(nxt["c1"].geom, nxt["d_o1"], nxt["c1"].wft, d_pool)
+            K.conv_dgrad(nxt["ds"].geom, nxt["d_pre"], nxt["ds"].wft, d_pool, addend=d_pool)
+            K.maxpool_bwd_relu(b["stem"], d_pool, d_stem, self.B, self.stem_hw[0], self.stem_hw[1], 64)
+            K.stem_wgrad(self._img, d_stem, self.stem.slabs, self.stem.dbias_partials, self.B, self.H, self.W,
+                         self.stem.geom.nsplit)
+            if after_stage is not None:
+                after_stage("stem")
         return None
 

@@ -769,6 +769,20 @@ def maxpool(x, y, B, H, W, Cch):
     _lib.call(_h("radet_maxpool3x3s2", x), _ptr(x), _ptr(y), B, H, W, Cch, _stream())
 
 
+def maxpool_bwd_relu(s, dpool, ds, B, H, W, Cch):
+    """ds = [s > 0] * max-pool backward of dpool (s = the stem's ReLU output [B*H*W, C], fp32)"""
+    _lib.call("radet_maxpool3x3s2_bwd_relu", _ptr(s), _ptr(dpool), _ptr(ds), B, H, W, Cch, _stream())
+
+
+def stem_wgrad_splits(B, H, W):
+    return _lib.load().radet_stem_wgrad_splits(B, H, W)
+
+
+def stem_wgrad(img, ds, slabs, dbias_partials, B, H, W, S):
+    """slabs[S][64][49][3], dbias_partials[S][64] from the NCHW image and the stem's pre-activation gradient"""
+    _lib.call("radet_stem_wgrad", _ptr(img), _ptr(ds), _ptr(slabs), _ptr(dbias_partials), B, H, W, S, _stream())
+
+
 def gn_ws_floats(levels):
     d, n = _desc([(h, w, h, w, o, o) for (h, w), o in zip(levels.hw, levels.offsets)])
     return _lib.load().radet_gn_workspace_floats(levels.B, d, n)

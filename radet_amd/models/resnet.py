@@ -1,5 +1,5 @@
 """ResNet-50/101 backbone, parameter-compatible with radet/models/backbones/resnet.py:303-648
-(Bottleneck style='pytorch', BN in eval mode, frozen stem + stages <= frozen_stages).
+(Bottleneck style='pytorch', BN in eval mode, stem + stages <= frozen_stages frozen; frozen_stages=-1 trains the stem too).
 Arithmetic runs in the HIP engine; this class owns parameters, init and the config surface."""
 from torch import nn
 

@@ -276,7 +276,7 @@ class DetectorRuntime:
         unfold(bk["bbox_head."])
         d_feats = e.neck_backward(dP)
         unfold(bk["neck."])
-        e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk[f"backbone.layer{li + 1}."]))
+        e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk["backbone.conv1" if li == "stem" else f"backbone.layer{li + 1}."]))
         e.join_side()                           # gradients complete on the current stream from here on
 
     def _unfold_bucket(self, bucket, bucket_hook=None):

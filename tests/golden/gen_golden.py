@@ -484,7 +484,7 @@ def gen_recall():
     save("recall", **out)
 
 
-def gen_model_grads(det, assign):
+def gen_model_grads(det, assign, out_name="model_grads"):
     """Sampled gradient ELEMENTS of every trainable parameter (model.npz holds only their norms, which a tap transposition
     or a sign error inside a tensor would preserve): same weights / batch as gen_model."""
     B = 2
@@ -512,8 +512,10 @@ def gen_model_grads(det, assign):
         val.append(p.grad.reshape(-1)[i].numpy())
         rms.append(float(p.grad.double().pow(2).mean().sqrt()))
         off.append(off[-1] + k)
-    save("model_grads", names=np.asarray(names), offsets=np.asarray(off, np.int64), idx=np.concatenate(idx),
-         val=np.concatenate(val), rms=np.asarray(rms, np.float64))
+    total = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in det.parameters() if p.grad is not None)))
+    save(out_name, names=np.asarray(names), offsets=np.asarray(off, np.int64), idx=np.concatenate(idx),
+         val=np.concatenate(val), rms=np.asarray(rms, np.float64), total_grad_norm=np.float64(total),
+         losses=np.asarray([float(losses[k]) for k in ("loss_cls", "loss_bbox", "loss_iou")], np.float64))
 
 
 def main():
@@ -522,6 +524,14 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "recall":     # only recall.npz
         gen_recall()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "stem":       # only model_grads_stem.npz: ResNet(frozen_stages=-1), trainable stem
+        torch.manual_seed(0)
+        model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
+        model_cfg["backbone"] = dict(model_cfg["backbone"], frozen_stages=-1)
+        det = build_detector(model_cfg, train_cfg=train_cfg, test_cfg=test_cfg)
+        synth.fill_state_dict(det.state_dict(), seed=0)
+        gen_model_grads(det, dict(np.load(os.path.join(HERE, "assigner.npz"))), out_name="model_grads_stem")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "grads":      # only model_grads.npz (inputs from the committed assigner.npz)
         torch.manual_seed(0)

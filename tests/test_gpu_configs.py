@@ -322,6 +322,79 @@ def test_head_with_more_than_32_classes():
     assert det.runtime().engine.pred_cls.cout == 40
 
 
+@pytest.mark.parametrize("fs", [-1, 0])
+def test_trainable_stem_and_layer1_vs_oracle(fs):
+    """ResNet(frozen_stages=-1): conv1 / bn1 and layer1 train (resnet.py:572-588) -- dgrad through layer1.0's conv1 and
+    projection shortcut, max-pool backward (first maximum of a window in scan order, ties among the ReLU's zeros included),
+    the stem's ReLU, the stem weight gradient from the NCHW image; frozen_stages=0: stem frozen, layer1 trainable.  Losses
+    and every gradient tensor against the oracle; one optimizer step moves the stem."""
+    from oracle import model as om, synth
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    cfg.model["backbone"]["frozen_stages"] = fs
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(det.state_dict(), seed=5)
+    det = det.cuda().train()
+    H, W = 150, 202                                        # odd sizes: ragged max-pool windows at the right / bottom edge
+    img, gt_b, gt_l, p2g, pw = batch(H, W, 2, G=(3, 2))
+    losses = det(img=img.cuda(), img_metas=synth.img_metas(2, H, W), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    sum(losses.values()).backward()
+    odet = om.OracleDetector(50, seed=5, frozen_stages=fs)
+    ol = odet.forward_train(img, gt_b, gt_l, p2g, pw)
+    om.parse_losses(ol).backward()
+    for k in ("loss_cls", "loss_bbox", "loss_iou"):
+        assert abs(losses[k].item() - ol[k].item()) <= 1e-4 * max(1.0, abs(ol[k].item())), k
+    mine = {n: p.grad for n, p in det.named_parameters() if p.requires_grad}
+    ref = odet.named_grads()
+    assert ("backbone.conv1.weight" in mine) == (fs < 0) and "backbone.layer1.0.conv1.weight" in mine
+    assert set(mine) == set(ref)
+    from _grads import assert_grads_close
+    assert_grads_close(mine, ref)
+    if fs < 0:
+        rt = det.runtime()
+        rt.init_optimizer()
+        tg = rt.pack_targets(gt_b, gt_l, p2g, pw)
+        w0 = det.backbone.conv1.weight.detach().clone()
+        rt.train_step(img.cuda(), tg)
+        torch.cuda.synchronize()
+        assert not torch.equal(w0, det.backbone.conv1.weight.detach())
+
+
+def test_trainable_stem_vs_reference_golden():
+    """frozen_stages=-1 on the reference's own batch: losses and sampled elements of all 210 gradient tensors (conv1, bn1 and
+    layer1 included) as written by the reference (tests/golden/model_grads_stem.npz)."""
+    from oracle import synth
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    g = np.load(os.path.join(REPO, "tests", "golden", "model_grads_stem.npz"))
+    a = np.load(os.path.join(REPO, "tests", "golden", "assigner.npz"))
+    tags = ("g8", "g3")
+    gt_b = [torch.from_numpy(a[t + "_boxes"]) for t in tags]
+    gt_l = [torch.from_numpy(a[t + "_labels"]) for t in tags]
+    p2g = [torch.from_numpy(a[t + "_p2g"].astype(np.int64)) for t in tags]
+    pw = [torch.from_numpy(a[t + "_w"]) for t in tags]
+    cfg = Config.fromfile(os.path.join(REPO, "configs", "bop", "r50_ycbv_pbr.py"))
+    cfg.model["pretrained"] = None
+    cfg.model["backbone"]["frozen_stages"] = -1
+    det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
+    synth.fill_state_dict(det.state_dict(), seed=0)
+    det = det.cuda().train()
+    img = synth.synth_images(0, 2).cuda()
+    losses = det(img=img, img_metas=synth.img_metas(2), return_loss=True, gt_bboxes=gt_b, gt_labels=gt_l,
+                 points_to_gt_index=p2g, points_weight=pw)
+    for k, ref in zip(("loss_cls", "loss_bbox", "loss_iou"), g["losses"]):
+        assert abs(losses[k].item() - float(ref)) <= 1e-4 * max(1.0, abs(float(ref))), k
+    sum(losses.values()).backward()
+    named = dict(det.named_parameters())
+    names = [str(n) for n in g["names"]]
+    assert sorted(names) == sorted(n for n, p in named.items() if p.requires_grad)
+    from _grads import assert_sampled_grads
+    assert_sampled_grads({n: named[n].grad for n in names}, g, atol_total=2e-6, total=float(g["total_grad_norm"]))
+
+
 def test_stale_data_write_is_refolded():
     """A parameter written through `.data` (its own version counter: the engine cannot see it) is picked up after
     `invalidate_folded_weights()` / a train()-eval() switch; a tracked write (copy_ on the Parameter) by itself."""

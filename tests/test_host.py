@@ -106,9 +106,9 @@ def test_reference_config_file_loads_unchanged(tmp_path, monkeypatch):
         build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
 
 
-def test_trainable_stem_is_refused():
-    """frozen_stages=-1 would train conv1 / bn1 in the reference; there is no stem backward here, so it must not be
-    accepted silently (zero gradients + weight decay would shrink the stem)."""
+def test_trainable_stem_in_bf16_storage_is_refused():
+    """frozen_stages=-1 trains conv1 / bn1 (built for the fp32-tensor modes, tests/test_gpu_configs.py); with bf16 storage there
+    is no stem backward, so it must not be accepted silently (zero gradients + weight decay would shrink the stem)."""
     from radet_amd.engine import Engine
     from radet_amd.models import build_detector
     from radet_amd.runtime import FlatParams
@@ -118,8 +118,9 @@ def test_trainable_stem_is_refused():
     cfg.model["backbone"]["frozen_stages"] = -1
     det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg)
     flat = FlatParams(det, torch.device("cpu"))
+    assert "backbone.conv1.weight" in flat.train_names and "backbone.bn1.bias" in flat.train_names
     with pytest.raises(NotImplementedError):
-        Engine(flat.p, flat.g, depth=50, frozen_stages=-1)
+        Engine(flat.p, flat.g, depth=50, frozen_stages=-1, math="bf16-storage")
 
 
 def build(depth=50):

@@ -201,6 +201,25 @@ def test_get_bboxes(golden, nms_type):
         assert np.array_equal(db, g[f"{nms_type}_{i}_b"])
 
 
+@pytest.mark.timeout(600)
+def test_trainable_stem_against_reference(golden):
+    """ResNet(frozen_stages=-1) (conv1 / bn1 / layer1 trainable, resnet.py:572-588): losses and sampled gradient elements of
+    all 210 trainable tensors as written by the reference (tests/golden/model_grads_stem.npz, gen_golden.py stem)."""
+    g = golden("model_grads_stem")
+    torch.set_num_threads(8)
+    det = om.OracleDetector(50, seed=0, frozen_stages=-1)
+    img = synth.synth_images(0, 2)
+    gt_b, gt_l, p2g, pw = assign_inputs(golden)
+    losses = det.forward_train(img, gt_b, gt_l, p2g, pw)
+    for k, ref in zip(("loss_cls", "loss_bbox", "loss_iou"), g["losses"]):
+        assert np.isclose(losses[k].item(), float(ref), rtol=1e-4), k
+    om.parse_losses(losses).backward()
+    grads = det.named_grads()
+    assert sorted(grads) == sorted(str(n) for n in g["names"]) and "backbone.conv1.weight" in grads
+    from _grads import assert_sampled_grads
+    assert_sampled_grads(grads, g, atol_total=1e-7, total=float(g["total_grad_norm"]))
+
+
 def test_state_dict_inventory():
     sd = om.make_state_dict(50)
     n_all = sum(t.numel() for n, t in sd.items() if t.is_floating_point() and "running" not in n)

@@ -40,8 +40,10 @@ DOM=$(python3 -c "import json; d=json.loads([l for l in open('$OUT/bench_default
 DOM_K=$(echo "$DOM" | head -1); DOM_B=$(echo "$DOM" | tail -1)
 python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "$DOM_K" \
     $OUT/pmc_hbm_traffic_fp32.txt $OUT/roofline_traffic.json $DOM_B > /dev/null 2>> $OUT/bench_default.err
-python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "conv_igemmg_kernel<256, 128, 4, 2, 17, 16, 2, false>" \
-    $OUT/pmc_hbm_traffic_tower.txt $OUT/roofline_traffic_tower.json 103022592 > /dev/null 2>> $OUT/bench_default.err
+TOW=$(python3 -c "import json; d=json.loads([l for l in open('$OUT/bench_default.json') if l.startswith('{')][-1]); t=d['roofline_tower_forward']; print(t['kernel']); print(t['algorithmic_bytes_per_launch'])")
+TOW_K=$(echo "$TOW" | head -1); TOW_B=$(echo "$TOW" | tail -1)
+python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "$TOW_K" \
+    $OUT/pmc_hbm_traffic_tower.txt $OUT/roofline_traffic_tower.json $TOW_B > /dev/null 2>> $OUT/bench_default.err
 # 4. inference (config 4) kernel stats, R101 (config 5) log, fill-path micro-benchmark
 db=$(prof infer $R/tools/bench_configs.py infer)
 python3 $R/tools/bench_configs.py r101 > $OUT/r101.log 2>&1

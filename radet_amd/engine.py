@@ -634,6 +634,12 @@ class Engine:
             self._ev_i = 0
         return self._side_stream
 
+    def _chain_stream(self):
+        if getattr(self, "_chain", None) is None:
+            self._side()
+            self._chain = torch.cuda.Stream(device=self.dev)
+        return self._chain
+
     def _event(self):
         self._ev_i = (self._ev_i + 1) % len(self._events)
         return self._events[self._ev_i]
@@ -906,7 +912,42 @@ class Engine:
         b = self.buf
         n = self.stacked_convs
         dP = b["dP"]
-        if self.tower_mode in ("pair", "pairbwd"):
+        if self.p3 and self.tower_mode == "pairbwd" and os.environ.get("RADET_TOWER_BWD_CHAINS", "1") != "0":
+            # plane operands: the two towers' backward as two CHAINS (cls on this stream, reg on the chain stream), each layer
+            # GroupNorm backward -> weight gradient (on the side streams, as before) -> dgrad as ONE 200-tile launch.  The
+            # grouped cls + reg dgrad (400 tiles of 256 x 128 that own a CU each = two rounds, the second 56 % full) held
+            # every CU while both chains' next GroupNorms waited for it; as single launches the tiles of one chain's dgrad, the
+            # other's and the weight gradients interleave CU by CU: step -2.5 % (same box, same run)
+            p, g = self.p, self.g
+            cs = self._chain_stream()
+            wg_done = {}
+
+            def layer(t, tower, ws, i):
+                gn = f"bbox_head.{t}_convs.{i}.gn"
+                ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
+                if ev is not None:
+                    torch.cuda.current_stream().wait_event(ev)
+                K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], ws)
+                x = b[f"{t}.y{i - 1}"] if i > 0 else b["Pp"]
+                wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
+                if i > 0:
+                    K.conv_dgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], tower[i].wft, b[f"{t}.dy"], tile=6 | (1 << 12))
+            self._tower_bwd_head_async("cls")
+            self._fork(cs)
+            with torch.cuda.stream(cs):
+                self._tower_bwd_head_async("reg")
+            for i in range(n - 1, -1, -1):
+                layer("cls", self.cls_tower, self.gn_ws, i)
+                with torch.cuda.stream(cs):
+                    layer("reg", self.reg_tower, self.gn_ws2, i)
+            # both first layers write dL/dP: cls on this stream, then reg accumulates onto it on the chain stream
+            K.conv_dgrad(self.cls_tower[0].geom, b["cls.dz0"], self.cls_tower[0].wft, dP, tile=6 | (1 << 12))
+            self._fork(cs)
+            with torch.cuda.stream(cs):
+                K.conv_dgrad(self.reg_tower[0].geom, b["reg.dz0"], self.reg_tower[0].wft, dP, addend=dP, tile=6 | (1 << 12))
+            self._join(cs)
+        elif self.tower_mode in ("pair", "pairbwd"):
             p, g = self.p, self.g
             tagged = self.tower_mode == "pair"        # "pairbwd": only the forward launches are tagged / timed (like hybrid)
             launch = self._tower_launch if tagged else (lambda fn, *a, **k: fn(*a, **k))

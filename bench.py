@@ -379,8 +379,9 @@ def main():
         x3 = bool(rt.engine.x3)
         if args.math.startswith("fp32"):
             out["config"]["arithmetic"] = (
-                "f32 tensors, f32-accurate conv GEMMs: every f32 operand is split exactly into three bf16 planes in "
-                "registers, 6 of the 9 plane products go through v_mfma_f32_32x32x16_bf16 with f32 accumulation "
+                "f32 tensors, f32-accurate conv GEMMs: every f32 operand is split exactly into three bf16 planes (in "
+                "registers; the head towers' activations / gradients / weights once, by the kernel that produces them), "
+                "6 of the 9 plane products go through v_mfma_f32_32x32x16_bf16 with f32 accumulation "
                 "(measured error vs f64 <= that of v_mfma_f32_32x32x2_f32: tools/x3_probe.py, DESIGN.md 6); "
                 "`--math fp32-mfma` / RADET_X3=0 = native f32 MFMA") if x3 else "f32 tensors, v_mfma_f32_32x32x2_f32"
         else:

@@ -40,6 +40,9 @@ def infer(n_images=1000, B=8):
     for _ in range(3):
         out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
     passed = float((torch.sigmoid(rt.engine.buf["cls"]) > 0.05).float().mean())
+    if os.environ.get("RADET_INFER_SYNC") != "1":           # warm the streamed path (its streams, second set of head buffers)
+        for _ in rt.detect_stream(((imgs, metas) for _ in range(3)), det.test_cfg, rescale=True):
+            pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ndet = 0

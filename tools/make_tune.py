@@ -31,7 +31,7 @@ elif os.path.exists(K._PACKAGED_TUNE) and "--keep" not in sys.argv:
     K._TUNE_LOADED = True                                       # ignore the shipped file too
 out = [a for a in sys.argv[1:] if not a.startswith("--")][0]
 JOBS = [  # depth, math, (B, H, W) list
-    (50, "fp32", [(4, 480, 640), (1, 480, 640), (2, 480, 640), (8, 480, 640)]),          # products from bf16 planes
+    (50, "fp32", [(4, 480, 640), (1, 480, 640), (2, 480, 640), (8, 480, 640), (16, 480, 640)]),   # products from bf16 planes
     (50, "fp32-mfma", [(4, 480, 640), (1, 480, 640), (2, 480, 640), (8, 480, 640)]),     # native fp32 MFMA
     (50, "bf16-storage", [(4, 480, 640), (8, 480, 640), (1, 480, 640)]),
     (50, "bf16", [(4, 480, 640), (8, 480, 640)]),
@@ -39,7 +39,7 @@ JOBS = [  # depth, math, (B, H, W) list
     (101, "fp32-mfma", [(2, 800, 800)]),
     (101, "bf16-storage", [(2, 800, 800)]),
 ]
-if "--retune-x3" in sys.argv:
+if "--retune-x3" in sys.argv or "--fp32-only" in sys.argv:
     JOBS = [j for j in JOBS if j[1] == "fp32"]
 for depth, math, geos in JOBS:
     cfg = Config.fromfile(os.path.join(ROOT, "configs", "bop", "r50_ycbv_pbr.py"))

@@ -492,26 +492,26 @@ def _detect_stream(self, batches, test_cfg, rescale=False):
     device program (forward, decode, NMS) is enqueued BEFORE the host waits for batch k's detection counts, so the GPU
     never idles on the per-batch hand-over (what the reference's `single_gpu_test` loop -- apis/test.py -- pays per batch
     as a device synchronisation).  Yields exactly what `detect` returns, in order.  The small per-batch uploads (image
-    sizes, scale factors) go through pinned memory and the counts come back on a copy stream behind an event: nothing in
-    the loop synchronises the main stream.  Decode + NMS of batch k (a dozen launches of a few workgroups each, ~0.3 ms at
+    sizes, scale factors) go through pinned memory and the counts come back behind an event on the stream that produced
+    them: nothing in the loop synchronises the main stream.  Decode + NMS of batch k (a dozen launches of a few workgroups each, ~0.3 ms at
     batch 8) run on a stream of their own NEXT TO the forward pass of batch k + 1: the head outputs alternate between two
     sets of buffers, and the forward pass that reuses a set first waits for the post-processing that read it."""
-    copy = self.__dict__.setdefault("_copy_stream", None) or torch.cuda.Stream(device=self.dev)
-    self._copy_stream = copy
-    post = self.__dict__.setdefault("_post_stream", None) or torch.cuda.Stream(device=self.dev)
-    self._post_stream = post
+    # (no stream of its own: a process should not create more than four HIP streams on this device -- engine.py, "stream
+    # budget" -- and the training step's tower-chain stream is idle here: the inference pass runs its reg chain on `side`)
+    post = self.engine._chain_stream()
     overlap = os.environ.get("RADET_POST_OVERLAP", "1") != "0"
     HEAD_OUT = ("cls", "reg_u", "iou")
     alts = {}                    # id(plan) -> (plan, the other set of head-output buffers)
     post_ev = [None, None]       # events "decode / NMS done" of the batch before last and of the last batch
 
+    def fetch_counts(outs, pinned):     # on the current stream: the detection counts into pinned memory + "arrived" event
+        pinned.copy_(outs[3], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return done
+
     def collect(rec):
-        outs, ev, pinned = rec[:3]      # (rec[3] keeps the batch's size / scale tensors alive until its decode has run)
-        with torch.cuda.stream(copy):
-            copy.wait_event(ev)
-            pinned.copy_(outs[3], non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
+        outs, done, pinned = rec[:3]    # (rec[3] keeps the batch's size / scale tensors alive until its decode has run)
         done.synchronize()                                      # the host waits for THIS batch only
         counts = pinned.numpy()
         ob, osc, ol, _ = outs
@@ -546,13 +546,19 @@ def _detect_stream(self, batches, test_cfg, rescale=False):
                     outs = _post_launch(self, hw, sf, test_cfg)
                     ev = torch.cuda.Event()
                     ev.record()
+                    pinned = torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory()
+                    done = fetch_counts(outs, pinned)
                 post_ev[0], post_ev[1] = post_ev[1], ev
             else:
                 self.forward(img)
                 outs = _post_launch(self, hw, sf, test_cfg)
                 ev = torch.cuda.Event()
                 ev.record()
-            rec = (outs, ev, torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory(), (hw, sf))
+                pinned = torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory()
+                with torch.cuda.stream(post):                   # (the copy must not queue behind the next batch's forward pass)
+                    post.wait_event(ev)
+                    done = fetch_counts(outs, pinned)
+            rec = (outs, done, pinned, (hw, sf))
             if prev is not None:
                 yield collect(prev)
             prev = rec
@@ -661,7 +667,7 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
                 _post_launch(self, hw, sf, test_cfg)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            cap_stream = torch.cuda.Stream(device=self.dev)
+            cap_stream = self.engine._chain_stream()            # (an existing stream: see engine.py, "stream budget")
             K.splitk_ws_for(cap_stream)                         # allocate the stream's split-K workspace outside capture
             self.engine.invalidate_fold()                       # the weight fold is part of the graph: replays see
             with torch.cuda.graph(graph, stream=cap_stream):    # the parameters of the moment, like the eager path

@@ -632,9 +632,20 @@ class Engine:
     # GEMM pair, tools/bench_streams.py).  Weight-gradient GEMMs are likewise issued on the side stream.
     use_streams = True
 
+    # The three extra streams are shared by every engine of the process on a device (one detector for training and another
+    # one for validation must not add up to more than four streams: "stream budget" in __init__)
+    _SHARED_STREAMS = {}
+
+    def _shared_stream(self, role):
+        key = (torch.device(self.dev).index if torch.device(self.dev).index is not None else torch.cuda.current_device(), role)
+        st = Engine._SHARED_STREAMS.get(key)
+        if st is None:
+            st = Engine._SHARED_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+        return st
+
     def _side(self):
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.dev)
+            self._side_stream = self._shared_stream("side")
             # ring of reusable events; an event handed out here is consumed (waited on) at most a few layers later, so
             # the ring only has to be longer than the events of ONE step (R101: ~2 per conv + forks/joins, < 600)
             self._events = [torch.cuda.Event() for _ in range(2048)]
@@ -644,7 +655,7 @@ class Engine:
     def _chain_stream(self):
         if getattr(self, "_chain", None) is None:
             self._side()
-            self._chain = torch.cuda.Stream(device=self.dev)
+            self._chain = self._shared_stream("chain")
         return self._chain
 
     def _event(self):
@@ -692,7 +703,7 @@ class Engine:
     def _side2(self):
         if getattr(self, "_side2_stream", None) is None:
             self._side()
-            self._side2_stream = torch.cuda.Stream(device=self.dev)
+            self._side2_stream = self._shared_stream("side2")
         return self._side2_stream
 
     def side_collect(self):

@@ -90,13 +90,12 @@ class Engine:
         self.act_dtype = torch.bfloat16 if self.h16 else torch.float32
         self.p, self.g = params, grads
         self.depth, self.num_classes, self.frozen_stages = depth, num_classes, frozen_stages
-        # Stream budget.  This device runs FOUR HIP streams of one process well; with a fifth one CREATED (busy or not) the step
-        # falls off a cliff: 9.98 -> 13.8 ms with main + side + second weight-gradient stream + tower chain + the collectives'
-        # stream (`tools/bench_dp1.py`; GPU_MAX_HW_QUEUES does not move it; three weight-gradient streams without any
-        # collective: 13.2 ms).  A data-parallel process needs one for RCCL, so it never creates the second weight-gradient
-        # stream (10.5 ms with a 1-rank exchange on, against 10.0 for the single-GPU step with it).
-        if "RADET_WGRAD_STREAMS" not in os.environ and torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.wgrad_streams = 1
+        # Stream budget.  This device runs FOUR HIP streams of one process well; with a fifth one IN USE during the step it falls
+        # off a cliff: 9.98 -> 13.8 ms with main + side + second weight-gradient stream + tower chain + the process group's
+        # internal stream (`tools/bench_dp1.py`; GPU_MAX_HW_QUEUES does not move it; three weight-gradient streams without
+        # any collective: 13.2 ms).  Hence: the three extra streams are shared by all engines of a process, decode / NMS and
+        # graph capture borrow the tower-chain stream (idle at inference), and the gradient exchange runs as synchronous
+        # collectives ON the tower-chain stream (idle from the head's backward pass to the next step), runtime.GradReducer.
         self.strides, self.stacked_convs, self.feat = tuple(strides), stacked_convs, feat
         self.dev = next(iter(params.values())).device
         self.convs = []

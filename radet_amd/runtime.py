@@ -114,20 +114,40 @@ def compute_buckets(flat, conv_names, conv_trainable):
     return buckets
 
 
+class _StreamWork:
+    """What GradReducer needs of a c10d Work, for a collective issued synchronously on a stream of ours: an event behind it"""
+
+    def __init__(self, timed, t0):
+        self.t0 = t0
+        self.done = torch.cuda.Event(enable_timing=timed)
+        self.done.record()
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
+
+    def _get_duration(self):                                   # ms, valid once `done` has completed
+        return self.t0.elapsed_time(self.done)
+
+
 class GradReducer:
     """Sum-all-reduce of gradient-arena buckets as they become ready (RCCL over xGMI on the GPU box,
     gloo in the CPU tests).  `bucket_ready` is called on the stream that produced the bucket (the engine's side
-    stream, right after the bucket's slab reduction); the process group runs the collective on its own internal
-    stream behind an event, so neither the side stream nor the main stream waits for it, and `finish()` makes the
-    current stream wait for all of them.  No extra stream of our own: HIP multiplexes streams onto 4 hardware
-    queues by default, and a 4th busy stream aliased with the main one and serialised the backward (measured:
-    -12 % with a dedicated comm stream, recovered with GPU_MAX_HW_QUEUES=8 or without the stream).  The mean
-    (1/world) is applied later, inside the fused clip+AdamW kernel."""
+    stream, right after the bucket's slab reduction); the collective runs behind an event of that stream on the
+    communication stream (`comm_stream`: see __init__; without one, asynchronously on the process group's internal
+    stream), so neither the side stream nor the main stream waits for it, and `finish()` makes the current stream wait
+    for all of them.  The mean (1/world) is applied later, inside the fused clip+AdamW kernel."""
 
-    def __init__(self, grads, device, bf16=False):
+    def __init__(self, grads, device, bf16=False, comm_stream=None):
         """bf16=True: each bucket is exchanged as bf16 (half the bytes on xGMI; the reference's fp16 training also
-        all-reduces half-precision gradients): fp32 -> bf16 staging buffer -> all-reduce -> back into the fp32 arena."""
+        all-reduces half-precision gradients): fp32 -> bf16 staging buffer -> all-reduce -> back into the fp32 arena.
+        comm_stream: a HIP stream of the caller on which the collectives run, as SYNCHRONOUS `all_reduce` calls (which
+        c10d issues on the current stream) behind an event of the producing stream -- instead of asynchronous ones on the
+        process group's internal stream.  The detector passes its tower-chain stream, idle from the end of the head's
+        backward pass to the next step: a process may not USE more than four HIP streams on this device ("stream budget",
+        engine.py), and main + side + second weight-gradient stream + chain are four already (with RCCL's own stream as the
+        fifth the step took 13.8-14.1 instead of 10.2-10.3 ms, tools/bench_dp1.py)."""
         self.grads, self.device, self.bf16 = grads, device, bf16
+        self.comm_stream = comm_stream if grads.is_cuda else None
         self.works = []
         self.staging = torch.empty(grads.numel(), dtype=torch.bfloat16, device=device) if bf16 else None
         # diagnostics (enable_trace()): per bucket an event on the producing stream when the bucket is handed over, an event
@@ -152,7 +172,24 @@ class GradReducer:
         if self.trace is not None and self.grads.is_cuda:
             ready = torch.cuda.Event(enable_timing=True)
             ready.record()
-        if self.bf16:
+        if self.comm_stream is not None:
+            cs = self.comm_stream
+            handed = torch.cuda.Event()
+            handed.record()                                    # on the stream that produced the bucket
+            timed = self.trace is not None
+            with torch.cuda.stream(cs):
+                cs.wait_event(handed)
+                t0 = torch.cuda.Event(enable_timing=True) if timed else None
+                if timed:
+                    t0.record()
+                if self.bf16:
+                    st = self.staging[b:e]
+                    self._convert(self.grads[b:e], st)
+                    dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=False)
+                else:
+                    dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, async_op=False)
+                w = _StreamWork(timed, t0)
+        elif self.bf16:
             st = self.staging[b:e]
             self._convert(self.grads[b:e], st)
             w = dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True)
@@ -336,7 +373,8 @@ class DetectorRuntime:
     def comm_report(self):
         """Diagnostics of the traced steps since reducer.enable_trace() (averaged), times in ms after the start of the
         backward pass: per bucket `ready` (handed to RCCL: its slab reduction finished on the side stream), `allreduce_ms`
-        (RCCL's own start-to-end time, with TORCH_NCCL_ENABLE_TIMING=1) and `done_by` (the main stream saw it complete in
+        (start-to-end time of the collective: HIP events around it on the communication stream, or RCCL's own timing with
+        TORCH_NCCL_ENABLE_TIMING=1 when the process group's internal stream is used) and `done_by` (the main stream saw it complete in
         finish(): an upper bound, exact for the bucket that is waited for); `exposed_comm_ms` = how long the main stream
         waits for the exchange after its last backward kernel -- what clip + AdamW pays.  Host-synchronising: call it after
         the steps, not between them."""
@@ -385,7 +423,8 @@ class DetectorRuntime:
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
         if use_reducer:
             if self.reducer is None:
-                self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets())
+                self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets(),
+                                           comm_stream=self.engine._chain_stream() if self.engine.use_streams else None)
             tr = self.reducer.trace is not None
             if tr:
                 ev0 = torch.cuda.Event(enable_timing=True)

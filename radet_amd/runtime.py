@@ -424,7 +424,8 @@ class DetectorRuntime:
         if use_reducer:
             if self.reducer is None:
                 self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets(),
-                                           comm_stream=self.engine._chain_stream() if self.engine.use_streams else None)
+                                           comm_stream=self.engine._chain_stream()
+                                           if (self.engine.use_streams and self.flat.grads.is_cuda) else None)
             tr = self.reducer.trace is not None
             if tr:
                 ev0 = torch.cuda.Event(enable_timing=True)

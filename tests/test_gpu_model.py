@@ -141,7 +141,8 @@ from radet_amd.runtime import GradReducer
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 g = torch.ones(1 << 20, device="cuda")
-red = GradReducer(g, torch.device("cuda", 0))
+comm = torch.cuda.Stream() if os.environ.get("PROBE_COMM_STREAM") == "1" else None      # the detector passes its chain stream
+red = GradReducer(g, torch.device("cuda", 0), comm_stream=comm)
 side, probe = torch.cuda.Stream(), torch.cuda.Stream()
 main_ev, side_ev, done_ev = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 with torch.cuda.stream(side):                      # first use: communicator / stream set-up is not part of the probe
@@ -164,16 +165,19 @@ dist.destroy_process_group()
 """
 
 
-def test_collectives_run_on_their_own_stream():
-    """The bucket all-reduces neither wait for the main stream nor for what the handing (side) stream does after the
-    hand-over: with the main stream parked in a long spin kernel BEFORE the hand-over and the side stream parked in one AFTER
+@pytest.mark.parametrize("comm_stream", ["1", "0"], ids=["on-a-stream-of-ours", "process-group-stream"])
+def test_collectives_run_on_their_own_stream(comm_stream):
+    """The bucket all-reduces -- synchronous collectives on a stream the caller names (what the detector does: its
+    tower-chain stream), or asynchronous ones on the process group's internal stream -- neither wait for the main stream nor
+    for what the handing (side) stream does after the hand-over: with the main stream parked in a long spin kernel BEFORE the hand-over and the side stream parked in one AFTER
     it, the collective still completes at once.  Run in a process of its own: in the test process dozens of streams from the
     other tests share the device's hardware queues, and a collective queued behind a parked stream's spin kernel in the same
     hardware queue says nothing about stream dependencies."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _OWN_STREAM_PROBE], cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _OWN_STREAM_PROBE], cwd=root, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PROBE_COMM_STREAM=comm_stream))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("PARKED")][-1]
     assert line.split()[1:] == ["True", "True"], line

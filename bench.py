@@ -93,8 +93,9 @@ def cpu_model():
 
 
 def cpu_baseline(steps=3):
-    """The oracle (CPU restatement pinned to the reference) timed on this host on the SAME work as one GPU step:
-    forward + loss + backward + global-norm clip + AdamW at the per-GPU batch (B = 4, 640x480)."""
+    """The oracle (CPU restatement pinned to the reference) timed on this host on the same conv work as one GPU step:
+    forward + loss + backward + global-norm clip + AdamW at the per-GPU batch (B = 4, 640x480; its own seeded batch of 6
+    objects per image -- the GPU step's has 1-8 -- which only moves the loss kernels' share)."""
     from oracle import assigner as oa, model as om, synth
     nthreads = effective_cores()
     torch.set_num_threads(nthreads)
@@ -124,8 +125,8 @@ def cpu_baseline(steps=3):
         if time.perf_counter() - t_start > 30.0:   # bounded sample (~10-30 s of CPU work)
             break
     return dict(value=round(B / best, 3), unit="images/sec", cores=nthreads, kind="port", cpu=cpu_model(),
-                sample=f"oracle (PyTorch-CPU fp32 restatement) forward+loss+backward+clip+AdamW, B={B} 640x480 (one GPU "
-                       f"step's work), best of {n_timed} timed step(s), {nthreads} threads")
+                sample=f"oracle (PyTorch-CPU fp32 restatement) forward+loss+backward+clip+AdamW, B={B} 640x480 (the conv work "
+                       f"of one GPU step; 6 objects per image), best of {n_timed} timed step(s), {nthreads} threads")
 
 
 def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):

@@ -132,6 +132,37 @@ def test_native_train_step_matches_autograd(det, golden):
             assert abs(rt.opt_state["grad_norm"].item() - float(golden("model")["total_grad_norm"])) < 1e-3 * 1053
 
 
+def test_stream_budget(det, golden):
+    """Training, streamed inference, a captured detect graph and the data-parallel exchange together use the main stream and
+    at most three more (shared by every engine of the process): a fifth HIP stream in use costs the step a third of its
+    speed on this device ("stream budget")."""
+    import numpy as np
+    from oracle import synth
+    from radet_amd.engine import Engine
+    from radet_amd.runtime import GradReducer
+    img = synth.synth_images(0, 2).cuda()
+    gt_b, gt_l, p2g, pw = targets(golden)
+    d = make_det()
+    d.train()
+    rt = d.runtime()
+    rt.init_optimizer()
+    rt.train_step(img, rt.pack_targets(gt_b, gt_l, p2g, pw))
+    d.eval()
+    metas = synth.img_metas(2, img.shape[2], img.shape[3])
+    list(rt.detect_stream(((img, metas) for _ in range(3)), d.test_cfg))
+    rt.detect_graph(img[:1], metas[:1], d.test_cfg)
+    torch.cuda.synchronize()
+    dev = torch.cuda.current_device()
+    roles = {r for (i, r) in Engine._SHARED_STREAMS if i == dev}
+    assert roles <= {"side", "side2", "chain"}, roles
+    assert not hasattr(rt, "_post_stream") and not hasattr(rt, "_copy_stream")
+    e = rt.engine
+    assert e._side() is det.runtime().engine._side() and e._chain_stream() is det.runtime().engine._chain_stream()
+    # the exchange runs on the chain stream the detector hands it, not on a stream of its own
+    red = GradReducer(torch.ones(8, device="cuda"), torch.device("cuda", dev), comm_stream=e._chain_stream())
+    assert red.comm_stream is e._chain_stream()
+
+
 _OWN_STREAM_PROBE = r"""
 import os, sys
 sys.path.insert(0, os.getcwd())

@@ -561,49 +561,64 @@ def _detect_stream(self, batches, test_cfg, rescale=False):
     def upload(a):
         return torch.from_numpy(a).pin_memory().to(self.dev, non_blocking=True)
 
-    prev = None
-    with torch.no_grad():
-        for img, img_metas in batches:
-            hw = upload(np.asarray([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], np.float32))
-            sf = upload(np.stack([np.asarray(m["scale_factor"], np.float32).reshape(4) for m in img_metas])) if rescale else None
-            img = img.to(self.dev, non_blocking=True)
-            if overlap:
-                e = self.engine
-                e.prepare(img.shape[0], img.shape[2], img.shape[3])
-                plan = e.buf
-                if id(plan) not in alts or alts[id(plan)][0] is not plan:
-                    alts[id(plan)] = (plan, {k: torch.empty_like(plan[k]) for k in HEAD_OUT})
-                other = alts[id(plan)][1]
-                for k in HEAD_OUT:                               # this batch writes the set the batch before last wrote
-                    plan[k], other[k] = other[k], plan[k]
-                if post_ev[0] is not None:
-                    torch.cuda.current_stream().wait_event(post_ev[0])   # ... once that batch's decode / NMS have read it
-                self.forward(img)
-                fwd = torch.cuda.Event()
-                fwd.record()
-                with torch.cuda.stream(post):
-                    post.wait_event(fwd)
+    swapped = {}                 # id(plan) -> the plan currently holds its second set
+
+    def run():
+        prev = None
+        with torch.no_grad():
+            for img, img_metas in batches:
+                hw = upload(np.asarray([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], np.float32))
+                sf = upload(np.stack([np.asarray(m["scale_factor"], np.float32).reshape(4) for m in img_metas])) if rescale else None
+                img = img.to(self.dev, non_blocking=True)
+                if overlap:
+                    e = self.engine
+                    e.prepare(img.shape[0], img.shape[2], img.shape[3])
+                    plan = e.buf
+                    if id(plan) not in alts or alts[id(plan)][0] is not plan:
+                        alts[id(plan)] = (plan, {k: torch.empty_like(plan[k]) for k in HEAD_OUT})
+                    other = alts[id(plan)][1]
+                    for k in HEAD_OUT:                               # this batch writes the set the batch before last wrote
+                        plan[k], other[k] = other[k], plan[k]
+                    swapped[id(plan)] = not swapped.get(id(plan), False)
+                    if post_ev[0] is not None:
+                        torch.cuda.current_stream().wait_event(post_ev[0])   # ... once that batch's decode / NMS have read it
+                    self.forward(img)
+                    fwd = torch.cuda.Event()
+                    fwd.record()
+                    with torch.cuda.stream(post):
+                        post.wait_event(fwd)
+                        outs = _post_launch(self, hw, sf, test_cfg)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        pinned = torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory()
+                        done = fetch_counts(outs, pinned)
+                    post_ev[0], post_ev[1] = post_ev[1], ev
+                else:
+                    self.forward(img)
                     outs = _post_launch(self, hw, sf, test_cfg)
                     ev = torch.cuda.Event()
                     ev.record()
                     pinned = torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory()
-                    done = fetch_counts(outs, pinned)
-                post_ev[0], post_ev[1] = post_ev[1], ev
-            else:
-                self.forward(img)
-                outs = _post_launch(self, hw, sf, test_cfg)
-                ev = torch.cuda.Event()
-                ev.record()
-                pinned = torch.empty(outs[3].shape, dtype=outs[3].dtype).pin_memory()
-                with torch.cuda.stream(post):                   # (the copy must not queue behind the next batch's forward pass)
-                    post.wait_event(ev)
-                    done = fetch_counts(outs, pinned)
-            rec = (outs, done, pinned, (hw, sf))
+                    with torch.cuda.stream(post):                   # (the copy must not queue behind the next batch's forward pass)
+                        post.wait_event(ev)
+                        done = fetch_counts(outs, pinned)
+                rec = (outs, done, pinned, (hw, sf))
+                if prev is not None:
+                    yield collect(prev)
+                prev = rec
             if prev is not None:
                 yield collect(prev)
-            prev = rec
-        if prev is not None:
-            yield collect(prev)
+
+    try:
+        yield from run()
+    finally:
+        # leave every plan with its own set (captured graphs and the training step hold pointers to it); the last batch's
+        # decode has been waited for by collect(), or the caller abandoned the stream and nobody reads its results
+        for pid, odd in swapped.items():
+            if odd and pid in alts:
+                plan, other = alts[pid]
+                for k in HEAD_OUT:
+                    plan[k], other[k] = other[k], plan[k]
 
 
 def _meta_tensors(self, img_metas, rescale):
@@ -715,8 +730,10 @@ def _detect_graph(self, img, img_metas, test_cfg, rescale=False):
                 outs = _post_launch(self, hw, sf, test_cfg)
             # the captured launches hold raw pointers into the decode / NMS workspaces: the record keeps them alive when
             # the `_posts` cache drops its reference
+            # (... as do the head-output buffers: detect_stream alternates the plan's entries between two sets)
             g = cache[key] = dict(graph=graph, img=static_img, hw=hw, sf=sf, outs=outs, plan=self.engine.buf,
-                                  keep=list(self.__dict__.get("_posts", {}).values()))
+                                  keep=list(self.__dict__.get("_posts", {}).values())
+                                  + [self.engine.buf[k] for k in ("cls", "reg_u", "iou")])
         else:
             hw, sf = _meta_tensors(self, img_metas, rescale)
             g["hw"].copy_(hw)

@@ -406,9 +406,18 @@ def test_detect_stream_matches_detect():
         metas = [dict(img_shape=(h, w, 3), scale_factor=np.full(4, 0.5 + 0.25 * i, np.float32)) for i in range(2)]
         work += [(torch.randn(2, 3, h, w, generator=g).cuda(), metas) for _ in range(n)]
     ref = [rt.detect(im, metas, det.test_cfg, rescale=True) for im, metas in work]
+    # a graph captured BEFORE the streams holds pointers into the plan's head-output buffers: the streams (odd batch counts)
+    # must leave the plan with its own set, and the graph's buffers alive
+    g_im, g_metas = work[-1]
+    g_ref = rt.detect_graph(g_im, g_metas, det.test_cfg, rescale=True)
+    own = {k: rt.engine.buf[k].data_ptr() for k in ("cls", "reg_u", "iou")}
     for _ in range(2):
         got = list(rt.detect_stream(iter(work), det.test_cfg, rescale=True))
         assert len(got) == len(ref)
         for a, b in zip(got, ref):
             for (da, la), (db, lb) in zip(a, b):
                 assert torch.equal(da, db) and torch.equal(la, lb) and da.shape[0] > 0
+        assert own == {k: rt.engine.buf[k].data_ptr() for k in own}
+        again = rt.detect_graph(g_im, g_metas, det.test_cfg, rescale=True)
+        for (da, la), (db, lb) in zip(again, g_ref):
+            assert torch.equal(da, db) and torch.equal(la, lb)

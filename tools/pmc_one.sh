@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes over one conv launch (tools/pmc_one.py): bash tools/pmc_one.sh <out file> <pmc_one.py arguments...>
+# Counter passes over one conv launch (tools/pmc_one.py, or PMC_PROG=tools/pmc_wgrad9.py): bash tools/pmc_one.sh <out file> <program arguments...>
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$(realpath -m $1); shift
 cd /tmp && export TMPDIR=/tmp
@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_ANY" \
            "TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ"; do
   rm -rf /tmp/pmc_one
-  timeout 150 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_one -o p --output-format csv -- python3 $R/tools/pmc_one.py "$@" > /tmp/pmc_one.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_one -o p --output-format csv -- python3 $R/${PMC_PROG:-tools/pmc_one.py} "$@" > /tmp/pmc_one.log 2>&1
   python3 - "$set" >> $OUT <<'PY'
 import csv, glob, sys, collections
 f = glob.glob('/tmp/pmc_one/**/*counter_collection.csv', recursive=True)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Shader clock / power sampled while the headline step runs: bash tools/clock_watch.sh <out file>
+# Shader clock / power sampled while the headline step runs: bash tools/clock_watch.sh <out file> [extra bench.py arguments]
 # (rocm-smi polled every ~0.2 s next to `python bench.py --steps 2000 ...`; the summary keeps the samples taken under load)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$(realpath -m ${1:-gpurun_out/clock_watch.txt})
-python3 $R/bench.py --steps 2000 --warmup 5 --no-cpu-baseline --no-mfma-line --no-extras --no-kernel-events > /tmp/cw_bench.json 2>/dev/null &
+OUT=$(realpath -m ${1:-gpurun_out/clock_watch.txt}); shift
+python3 $R/bench.py --steps 2000 --warmup 5 --no-cpu-baseline --no-mfma-line --no-extras --no-kernel-events "$@" > /tmp/cw_bench.json 2>/dev/null &
 BP=$!
 : > /tmp/cw_raw.txt
 while kill -0 $BP 2>/dev/null; do

@@ -194,6 +194,11 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
         roof["traffic_note"] = tnote
     roof["selection"] = ("largest share of the summed conv-GEMM kernel time of the step (HIP events around every conv launch, "
                          "second pass of the same K steps)")
+    roof["note"] = ("`frac` is priced on the launch's duration IN the step, where launches on the engine's four streams share the "
+                    "CUs (the tower weight gradients run next to the two dgrad chains by design: a workgroup of either owns a CU and "
+                    "their tiles interleave), so a launch's duration covers other launches' work too; `alone` = the same launches "
+                    "one at a time.  The step runs at the socket power limit (1.36 kW, ~2.2 GHz: profiles/round3_clock_power.txt); "
+                    "`peak` is the 2.4 GHz figure.")
     mult_all = 6.0 if x3 else 1.0
     peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
     all_tf = tot_fl / (tot_ms * 1e-3) / 1e12

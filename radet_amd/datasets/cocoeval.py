@@ -16,7 +16,10 @@ Knife-edges decided here from the published algorithm, with nothing to check the
     `area` field for gts and w * h for detections;
   * precision = tp / (tp + fp + eps) with eps = np.spacing(1), recall thresholds searched with `np.searchsorted(..., "left")`,
     empty categories / ranges report -1;
-  * `segm` and `proposal_fast` are not implemented (boxes only)."""
+  * `segm` is not implemented (boxes only); `proposal_fast` = eval_recalls() at the end of this file, which IS pinned (bit-equal
+    to the reference's eval_recalls on a golden written by it, tests/golden/recall.npz).
+tests/test_bop.py also runs the evaluator against a second, deliberately naive loop-by-loop restatement of the same published
+algorithm on random data (crowds, score ties, all three area ranges, images without ground truth / detections)."""
 import collections
 import copy
 import json

@@ -131,6 +131,128 @@ def test_evaluate_perfect_and_degraded(bop):
     assert set(saved) == {"0", "7"} and saved["0"][0].keys() == {"bbox_obj", "obj_id", "score"} and 1 in conv
 
 
+def _naive_coco_stats(images, anns, dets, cat_ids, iou_thrs, max_dets=(1, 10, 100)):
+    """pycocotools' published bbox evaluation, loop by loop (no vectorisation, no shared code with cocoeval.py): returns the 12
+    summary numbers.  Written to be obviously the algorithm, not to be fast."""
+    area_rngs = [(0, 1e10), (0, 32 ** 2), (32 ** 2, 96 ** 2), (96 ** 2, 1e10)]
+    rec_thrs = np.linspace(0.0, 1.0, 101)
+
+    def iou(d, g, crowd):
+        ix = max(0.0, min(d[0] + d[2], g[0] + g[2]) - max(d[0], g[0]))
+        iy = max(0.0, min(d[1] + d[3], g[1] + g[3]) - max(d[1], g[1]))
+        inter = ix * iy
+        union = d[2] * d[3] if crowd else d[2] * d[3] + g[2] * g[3] - inter
+        return inter / union if union > 0 else 0.0
+
+    T, R, K, A, M = len(iou_thrs), 101, len(cat_ids), 4, len(max_dets)
+    precision = -np.ones((T, R, K, A, M))
+    recall = -np.ones((T, K, A, M))
+    for k, cat in enumerate(cat_ids):
+        for ai, (lo, hi) in enumerate(area_rngs):
+            for mi, md in enumerate(max_dets):
+                scores, matched, ignored, npos = [], [[] for _ in range(T)], [[] for _ in range(T)], 0
+                for img in images:
+                    gts = [a for a in anns if a["image_id"] == img and a["category_id"] == cat]
+                    dts = [d for d in dets if d["image_id"] == img and d["category_id"] == cat]
+                    if not gts and not dts:
+                        continue
+                    g_ign = [bool(g["iscrowd"]) or g["area"] < lo or g["area"] > hi for g in gts]
+                    order = sorted(range(len(gts)), key=lambda i: g_ign[i])            # stable: non-ignored first
+                    gts, g_ign = [gts[i] for i in order], [g_ign[i] for i in order]
+                    d_order = np.argsort([-d["score"] for d in dts], kind="mergesort")[:md]
+                    dts = [dts[i] for i in d_order]
+                    npos += sum(1 for x in g_ign if not x)
+                    for ti, t in enumerate(iou_thrs):
+                        g_taken = [False] * len(gts)
+                        for d in dts:
+                            best, m = min(t, 1 - 1e-10), -1
+                            for gi, g in enumerate(gts):
+                                if g_taken[gi] and not g["iscrowd"]:
+                                    continue
+                                if m > -1 and not g_ign[m] and g_ign[gi]:
+                                    break
+                                v = iou(d["bbox"], g["bbox"], g["iscrowd"])
+                                if v < best:
+                                    continue
+                                best, m = v, gi
+                            if m > -1:
+                                g_taken[m] = True
+                                matched[ti].append(True)
+                                ignored[ti].append(g_ign[m])
+                            else:
+                                a_d = d["bbox"][2] * d["bbox"][3]
+                                matched[ti].append(False)
+                                ignored[ti].append(a_d < lo or a_d > hi)
+                    scores += [d["score"] for d in dts]
+                if npos == 0:
+                    continue
+                rank = np.argsort([-x for x in scores], kind="mergesort")
+                for ti in range(T):
+                    tp = fp = 0
+                    rc, pr = [], []
+                    for i in rank:
+                        if ignored[ti][i]:
+                            continue
+                        if matched[ti][i]:
+                            tp += 1
+                        else:
+                            fp += 1
+                        rc.append(tp / npos)
+                        pr.append(tp / (tp + fp + np.spacing(1)))
+                    recall[ti, k, ai, mi] = rc[-1] if rc else 0
+                    for i in range(len(pr) - 1, 0, -1):
+                        if pr[i] > pr[i - 1]:
+                            pr[i - 1] = pr[i]
+                    q = np.zeros(R)
+                    for ri, pi in enumerate(np.searchsorted(rc, rec_thrs, side="left")):
+                        if pi < len(pr):
+                            q[ri] = pr[pi]
+                    precision[ti, :, k, ai, mi] = q
+
+    def mean(x):
+        x = x[x > -1]
+        return float(x.mean()) if x.size else -1.0
+    t50, t75 = int(np.argmin(abs(np.asarray(iou_thrs) - 0.5))), int(np.argmin(abs(np.asarray(iou_thrs) - 0.75)))
+    return [mean(precision[:, :, :, 0, 2]), mean(precision[t50, :, :, 0, 2]), mean(precision[t75, :, :, 0, 2]),
+            mean(precision[:, :, :, 1, 2]), mean(precision[:, :, :, 2, 2]), mean(precision[:, :, :, 3, 2]),
+            mean(recall[:, :, 0, 0]), mean(recall[:, :, 0, 1]), mean(recall[:, :, 0, 2]),
+            mean(recall[:, :, 1, 2]), mean(recall[:, :, 2, 2]), mean(recall[:, :, 3, 2])]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cocoeval_random_vs_naive_restatement(seed):
+    """The NumPy evaluator against the loop-by-loop restatement above on random data: 3 categories, 9 images (one without
+    ground truth, one without detections), crowd boxes, tied scores, boxes of all three area ranges, more than 10
+    detections of a category in an image (so maxDets = 1 / 10 / 100 differ)."""
+    from radet_amd.datasets.cocoeval import COCO, COCOeval
+    rng = np.random.RandomState(seed)
+    images, anns, dets = list(range(1, 10)), [], []
+    for img in images:
+        for c in (1, 2, 3):
+            n_gt = 0 if img == 4 else rng.randint(0, 5)
+            for _ in range(n_gt):
+                w, h = rng.choice([12, 40, 150]) * rng.uniform(0.8, 1.2), rng.choice([12, 40, 150]) * rng.uniform(0.8, 1.2)
+                x, y = rng.uniform(0, 400), rng.uniform(0, 300)
+                anns.append(dict(id=len(anns) + 1, image_id=img, category_id=c, bbox=[float(x), float(y), float(w), float(h)],
+                                 area=float(w * h), iscrowd=int(rng.rand() < 0.15)))
+            n_dt = 0 if img == 7 else rng.randint(0, 14)
+            mine = [a for a in anns if a["image_id"] == img and a["category_id"] == c]
+            for j in range(n_dt):
+                if mine and rng.rand() < 0.6:                   # a jittered copy of a ground truth
+                    g = mine[rng.randint(len(mine))]["bbox"]
+                    b = [g[0] + rng.uniform(-8, 8), g[1] + rng.uniform(-8, 8), g[2] * rng.uniform(0.8, 1.2), g[3] * rng.uniform(0.8, 1.2)]
+                else:
+                    b = [rng.uniform(0, 400), rng.uniform(0, 300), rng.uniform(8, 160), rng.uniform(8, 160)]
+                dets.append(dict(image_id=img, category_id=c, bbox=[float(v) for v in b],
+                                 score=float(rng.choice([0.3, 0.5, 0.9]) if rng.rand() < 0.3 else rng.rand())))
+    gt = COCO(dict(images=[dict(id=i, width=640, height=480, file_name=str(i)) for i in images],
+                   categories=[dict(id=c, name=f"c{c}") for c in (1, 2, 3)], annotations=anns))
+    ev = COCOeval(gt, gt.loadRes(dets), "bbox")
+    ev.evaluate(); ev.accumulate(); ev.summarize()
+    ref = _naive_coco_stats(images, anns, dets, [1, 2, 3], list(ev.params.iouThrs))
+    assert np.allclose(ev.stats, ref, rtol=0, atol=1e-12), (list(ev.stats), ref)
+
+
 def test_eval_recalls_vs_reference_golden():
     """radet_amd.datasets.cocoeval.eval_recalls against the reference's eval_recalls (tests/golden/recall.npz, written by
     tests/golden/gen_golden.py recall): ragged images, tied scores, exact-threshold IoUs; bit-equal recalls."""

@@ -162,39 +162,51 @@ extern "C" int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_
 template <class T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C4,
                                int Ho, int Wo) {
-    const size_t total = (size_t)B * Ho * Wo * C4;
+    // one thread = TWO horizontally adjacent outputs of one channel quad: their 3 x 3 windows share a column, 15 loads
+    // instead of 18 (all unconditional: an out-of-range tap is clamped onto the border pixel, which is inside the window
+    // already -- max is idempotent -- instead of skipped: a skipped load is a branch and a wait per tap)
+    const int Wp = (Wo + 1) / 2;
+    const size_t total = (size_t)B * Ho * Wp * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
         size_t p = i / C4;
-        const int ox = (int)(p % Wo);
-        p /= Wo;
+        const int oxp = (int)(p % Wp);
+        p /= Wp;
         const int oy = (int)(p % Ho);
         const int n = (int)(p / Ho);
-        // nine unconditional loads in flight: an out-of-range tap is clamped onto the border pixel, which is inside the
-        // window already (max is idempotent), instead of skipped (a skipped load is a branch and a wait per tap)
-        float4 v[9];
+        const int ox = 2 * oxp;
+        float4 v[15];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = min(max(oy * 2 - 1 + r, 0), H - 1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < 5; ++q) {
                 const int ix = min(max(ox * 2 - 1 + q, 0), W - 1);
-                v[r * 3 + q] = ld4(x, ((size_t)(n * H + iy) * W + ix) * C4 + c);
+                v[r * 5 + q] = ld4(x, ((size_t)(n * H + iy) * W + ix) * C4 + c);
             }
         }
-        float4 m = v[0];
 #pragma unroll
-        for (int k = 1; k < 9; ++k) {
-            m.x = fmaxf(m.x, v[k].x); m.y = fmaxf(m.y, v[k].y); m.z = fmaxf(m.z, v[k].z); m.w = fmaxf(m.w, v[k].w);
+        for (int h = 0; h < 2; ++h) {
+            if (ox + h >= Wo) break;
+            // (the second output's window is columns 2 .. 4; when its right column is out of range the clamp makes it a copy of
+            // an in-range column of the same window)
+            float4 m = v[2 * h];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 u = v[r * 5 + 2 * h + q];
+                    m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
+                }
+            st4(y, ((size_t)(n * Ho + oy) * Wo + ox + h) * C4 + c, m);
         }
-        st4(y, i, m);
     }
 }
 
 extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     if (C % 4) return RADET_ERR_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4, Ho, Wo);
     return radet_check_launch();
@@ -203,7 +215,7 @@ extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W,
 extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream) {
     if (C % 4) return RADET_ERR_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(maxpool_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y,
                        B, H, W, C / 4, Ho, Wo);

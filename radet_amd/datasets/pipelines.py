@@ -43,45 +43,48 @@ class GenerateDistanceMap:
         return results["gt_masks"]
 
     def crop_boxes(self, img, img_shape, gt_bboxes):
-        """loading.py:596-634: padded box crops, the box's own region inside each crop, and which boxes are large enough"""
+        """What loading.py:596-634 hands to the distance transform, computed for all G boxes at once: per box a crop canvas
+        of the box grown by ceil(pad_ratio * side) on every side, filled with one random colour (three `random.randint(0, 255)`
+        per box, box after box: the only sequencing visible from outside) and overlaid with the part of the image the grown
+        window covers; the box's own rectangle inside its canvas; and which boxes exceed `small_object_size`.
+        Returns (list of u8 [h, w, 3] canvases, bool [G], int [G, 4] regions)."""
         import random
-        img_h, img_w = int(img_shape[0]), int(img_shape[1])
-        areas = (gt_bboxes[:, 2] - gt_bboxes[:, 0] + 1) * (gt_bboxes[:, 3] - gt_bboxes[:, 1] + 1)
-        maskenable = areas > self.small_object_size
-        boxes = gt_bboxes.copy().astype(np.int_)
-        box_images, regions = [], np.zeros_like(boxes)
-        for i, xyxy in enumerate(boxes):
-            pad_x = math.ceil((xyxy[2] - xyxy[0]) * self.pad_ratio)
-            pad_y = math.ceil((xyxy[3] - xyxy[1]) * self.pad_ratio)
-            box_image = np.zeros((xyxy[3] - xyxy[1] + 2 * pad_y, xyxy[2] - xyxy[0] + 2 * pad_x, 3), dtype=np.uint8)
-            box_image[:, :, :] = [random.randint(0, 255) for _ in range(3)]
-            bh, bw = box_image.shape[:2]
-            o = xyxy.copy()
-            xyxy += np.array([-pad_x, -pad_y, pad_x, pad_y], dtype=xyxy.dtype)
-            rx1, ry1 = np.clip(xyxy[0], 0, img_w - 1), np.clip(xyxy[1], 0, img_h - 1)
-            rx2, ry2 = np.clip(xyxy[2], 0, img_w - 1), np.clip(xyxy[3], 0, img_h - 1)
-            bx1, by1 = rx1 - xyxy[0], ry1 - xyxy[1]
-            bx2, by2 = bw - (xyxy[2] - rx2), bh - (xyxy[3] - ry2)
-            box_image[by1:by2, bx1:bx2] = img[ry1:ry2, rx1:rx2]
-            regions[i] = np.array([o[0] - xyxy[0], o[1] - xyxy[1], bw - (xyxy[2] - o[2]), bh - (xyxy[3] - o[3])])
-            box_images.append(box_image)
-        return box_images, maskenable, regions
+        bounds = np.array([img_shape[1] - 1, img_shape[0] - 1], dtype=np.int_)        # last valid (x, y)
+        side = gt_bboxes[:, 2:4] - gt_bboxes[:, 0:2]
+        large = (side + 1).prod(axis=1) > self.small_object_size
+        corners = gt_bboxes.astype(np.int_)                                             # truncation
+        lo, hi = corners[:, 0:2], corners[:, 2:4]
+        grow = np.ceil((hi - lo) * self.pad_ratio).astype(np.int_)
+        canvas_wh = hi - lo + 2 * grow
+        win_lo, win_hi = lo - grow, hi + grow                                           # grown window, image coordinates
+        src_lo, src_hi = np.clip(win_lo, 0, bounds), np.clip(win_hi, 0, bounds)         # its part inside the image
+        dst_lo, dst_hi = src_lo - win_lo, canvas_wh - (win_hi - src_hi)                 # where that part sits on the canvas
+        regions = np.concatenate([grow, canvas_wh - grow], axis=1)
+        fill = np.array([random.randint(0, 255) for _ in range(3 * len(corners))], dtype=np.uint8).reshape(-1, 3)
+        canvases = []
+        for g, (w, h) in enumerate(canvas_wh):
+            canvas = np.empty((h, w, 3), dtype=np.uint8)
+            canvas[...] = fill[g]
+            canvas[dst_lo[g, 1]:dst_hi[g, 1], dst_lo[g, 0]:dst_hi[g, 0]] = img[src_lo[g, 1]:src_hi[g, 1], src_lo[g, 0]:src_hi[g, 0]]
+            canvases.append(canvas)
+        return canvases, large, regions
 
     def forward_wo_gt_mask(self, results):
-        img = results["img"]
-        img_h, img_w, _ = results["img_shape"]
-        assert isinstance(img, np.ndarray), f"image should be numpy.ndarray, got {type(img)}"
-        assert img.dtype == np.uint8, f"image dtype should be np.uint8, got{img.dtype}"
-        assert img.ndim == 3, f"image should have three channel and BGR format, got{img.ndim} channels"
+        """loading.py:586-645: distance maps of the padded box crops, pasted back at the (truncated) box positions of
+        otherwise-zero images; here one f32 [G, img_h, img_w] device tensor instead of G host tensors."""
+        img, (img_h, img_w) = results["img"], results["img_shape"][:2]
+        for ok, why in ((isinstance(img, np.ndarray), f"image should be numpy.ndarray, got {type(img)}"),
+                        (getattr(img, "dtype", None) == np.uint8, f"image dtype should be np.uint8, got{getattr(img, 'dtype', None)}"),
+                        (getattr(img, "ndim", 0) == 3, f"image should have three channel and BGR format, got{getattr(img, 'ndim', 0)} channels")):
+            if not ok:
+                raise AssertionError(why)          # the reference's three asserts, same messages
         gt_bboxes = results["gt_bboxes"]
-        box_images, maskenable, regions = self.crop_boxes(img, (img_h, img_w), gt_bboxes)
-        maps = self.distance_transform(box_images, maskenable, regions)
+        maps = self.distance_transform(*self.crop_boxes(img, (img_h, img_w), gt_bboxes))
         dev = maps[0].device if maps else torch.device("cuda", torch.cuda.current_device())
-        out = torch.zeros(len(maps), img_h, img_w, dtype=torch.float32, device=dev)
-        for k, (m, bbox) in enumerate(zip(maps, gt_bboxes)):
-            b = bbox.astype(np.int_)
-            out[k, b[1]:b[3], b[0]:b[2]] = m.to(torch.float32)
-        return out
+        pasted = torch.zeros(len(maps), img_h, img_w, dtype=torch.float32, device=dev)
+        for g, (x0, y0, x1, y1) in enumerate(gt_bboxes.astype(np.int_)):
+            pasted[g, y0:y1, x0:x1] = maps[g]
+        return pasted
 
     def __call__(self, results):
         results["distance_maps"] = self.forward_with_gt_mask(results) if self.with_gt_mask else self.forward_wo_gt_mask(results)

@@ -1,7 +1,9 @@
 """RADet single-stage detector: same constructor, call signatures and outputs as
 radet/models/detectors/{base.py:65-253, single_stage.py:17-124, radet.py:8-32}."""
+import operator
 import weakref
 from collections import OrderedDict
+from functools import reduce
 
 import numpy as np
 import torch
@@ -146,22 +148,26 @@ class RADet(nn.Module):
         return [bbox2result(b, l, self.bbox_head.num_classes) for b, l in dets]
 
     def _parse_losses(self, losses):
-        log_vars = OrderedDict()
-        for name, value in losses.items():
-            if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
-            elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
-            else:
-                raise TypeError(f"{name} is not a tensor or list of tensors")
-        loss = sum(v for k, v in log_vars.items() if "loss" in k)
-        log_vars["loss"] = loss
-        for name, value in log_vars.items():
-            if dist.is_available() and dist.is_initialized():
-                value = value.data.clone()
-                dist.all_reduce(value.div_(dist.get_world_size()))
-            log_vars[name] = value.item()
-        return loss, log_vars
+        """detectors/base.py:185-216, same (loss, log_vars) result.  The logged scalars of the step are stacked into ONE
+        tensor: one all-reduce (mean over the ranks) and one device -> host copy for all of them, instead of one
+        collective and one `.item()` synchronisation per entry."""
+        def scalar(key, entry):
+            if torch.is_tensor(entry):
+                return entry.mean()
+            if isinstance(entry, list):
+                return reduce(operator.add, (t.mean() for t in entry))       # left to right, like the reference's sum()
+            raise TypeError(f"{key} is not a tensor or list of tensors")
+
+        keys = list(losses)
+        terms = [scalar(k, losses[k]) for k in keys]
+        picked = [t for k, t in zip(keys, terms) if "loss" in k]
+        loss = reduce(operator.add, picked) if picked else 0     # left to right; (0 = the reference's `sum()` of nothing)
+        report = torch.stack([t.detach() for t in terms] + [torch.as_tensor(loss).detach().to(terms[0])]) if terms \
+            else torch.zeros(1)
+        if dist.is_available() and dist.is_initialized():
+            report = report / dist.get_world_size()
+            dist.all_reduce(report)
+        return loss, OrderedDict(zip(keys + ["loss"], report.tolist()))
 
     def train_step(self, data, optimizer):
         losses = self(**data)

@@ -229,3 +229,52 @@ def test_two_rank_train_step_control_flow(tmp_path):
     assert sorted(r[0] for r in res) == [0, 1]
     for r in res:
         assert all(r[1:]), r
+
+
+def _parse_losses_of(losses):
+    from radet_amd.models.radet import RADet
+    return RADet._parse_losses(None, losses)          # the method does not touch the instance
+
+
+def test_parse_losses_single_process():
+    """detectors/base.py:185-216: tensors are averaged, lists of tensors summed entry by entry, the total sums every key that
+    contains 'loss' (left to right), other keys are logged only; anything else raises TypeError."""
+    a = torch.tensor([1.0, 3.0], requires_grad=True)
+    losses = {"loss_cls": a, "loss_bbox": [torch.tensor([2.0, 4.0]), torch.tensor(0.5)], "acc": torch.tensor([10.0, 30.0])}
+    loss, log = _parse_losses_of(losses)
+    assert list(log) == ["loss_cls", "loss_bbox", "acc", "loss"]
+    assert log == {"loss_cls": 2.0, "loss_bbox": 3.5, "acc": 20.0, "loss": 5.5}
+    assert all(type(v) is float for v in log.values())
+    loss.backward()                                    # the returned loss is differentiable, the log values are detached
+    assert torch.equal(a.grad, torch.tensor([0.5, 0.5]))
+    with pytest.raises(TypeError, match="loss_x is not a tensor or list of tensors"):
+        _parse_losses_of({"loss_x": 1.0})
+
+
+def _parse_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    loss, log = _parse_losses_of({"loss_cls": torch.tensor([1.0 + rank, 3.0 + rank]), "loss_iou": [torch.tensor(4.0 * rank)]})
+    dist.all_reduce = orig
+    q.put((rank, float(loss), dict(log), len(calls)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_parse_losses_two_ranks_one_collective():
+    """log_vars are the mean over the ranks (as in the reference), obtained with ONE all-reduce of the stacked scalars;
+    the loss that is back-propagated stays the local one."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_parse_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    [p.join(30) for p in ps]
+    for rank, loss, log, ncalls in res:
+        assert ncalls == 1
+        assert loss == (2.0 + rank) + 4.0 * rank                 # local
+        assert log == {"loss_cls": 2.5, "loss_iou": 2.0, "loss": 4.5}   # mean over the two ranks

@@ -1,6 +1,7 @@
 """CPU tests of the host side: C ABI surface, registry / config drop-in, parameter inventory, geometry,
 loud failure without a GPU.  No kernel is launched here."""
 import ctypes
+import math
 import os
 import re
 
@@ -252,3 +253,39 @@ def test_checkpoint_roundtrip_cpu(tmp_path):
     c = build()
     load_checkpoint(c, str(tmp_path / "ddp.pth"), strict=True)
     assert torch.equal(c.state_dict()["bbox_head.atss_cls.weight"], sa["bbox_head.atss_cls.weight"])
+
+
+def test_generate_distance_map_crops_properties():
+    """GenerateDistanceMap(with_gt_mask=False).crop_boxes (loading.py:596-634): canvas = box grown by ceil(pad_ratio * side),
+    filled with ONE colour per box drawn as three `random.randint(0, 255)` in box order, overlaid with the image where the
+    grown window is inside it; regions = the box inside its canvas; small boxes flagged."""
+    import random
+    from radet_amd.datasets.pipelines import GenerateDistanceMap
+    g = GenerateDistanceMap.__new__(GenerateDistanceMap)
+    g.with_gt_mask, g.small_object_size, g.pad_ratio = False, 32 ** 2, 0.05
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    boxes = np.array([[100.7, 50.2, 300.9, 250.1],      # interior
+                      [0.0, 0.0, 90.5, 70.5],            # grown window leaves the image at the top left
+                      [560.2, 400.3, 639.9, 479.9],      # ... and at the bottom right
+                      [10.0, 10.0, 30.0, 35.0]], np.float32)   # small object
+    random.seed(11)
+    crops, large, regions = g.crop_boxes(img, (480, 640), boxes)
+    random.seed(11)
+    colours = np.array([random.randint(0, 255) for _ in range(12)], np.uint8).reshape(4, 3)
+    after = random.random()
+    random.seed(11); [random.randint(0, 255) for _ in range(12)]
+    assert random.random() == after                      # exactly 3 draws per box
+    assert large.tolist() == [True, True, True, False]
+    ib = boxes.astype(np.int_)
+    for k, (x0, y0, x1, y1) in enumerate(ib):
+        px, py = math.ceil((x1 - x0) * 0.05), math.ceil((y1 - y0) * 0.05)
+        assert crops[k].shape == (y1 - y0 + 2 * py, x1 - x0 + 2 * px, 3) and crops[k].dtype == np.uint8
+        assert regions[k].tolist() == [px, py, x1 - x0 + px, y1 - y0 + py]
+        for cy in range(crops[k].shape[0]):               # every canvas pixel: image where the window covers it, else the colour
+            iy = y0 - py + cy
+            for cx in (0, px, crops[k].shape[1] // 2, crops[k].shape[1] - 1):
+                ix = x0 - px + cx
+                inside = 0 <= iy < min(479, y1 + py) and 0 <= ix < min(639, x1 + px)   # (the reference's clip to H-1 / W-1 is exclusive)
+                want = img[iy, ix] if inside else colours[k]
+                assert (crops[k][cy, cx] == want).all(), (k, cy, cx)

@@ -33,6 +33,50 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 
 
+INFER_FLOP_PER_IMG = 120.96e9      # forward conv MACs x 2 of one 640x480 image (backbone + FPN + head)
+
+
+class ClockSampler:
+    """Shader clock and socket power of the visible GPU, read with `rocm-smi --showclocks --showpower` (~80 ms per call) in a
+    background thread while a region runs; medians of the samples taken under load."""
+
+    def __init__(self):
+        import threading
+        self.rows, self._stop = [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+            p = re.search(r"Power \(W\): ([0-9.]+)", txt)
+            if m and p:
+                self.rows.append((time.perf_counter(), int(m.group(1)), float(p.group(1))))
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def report(self, t0, t1, what):
+        rows = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not rows:
+            return {"samples": 0, "note": "rocm-smi returned no sample inside the region"}
+        clk, pw = sorted(r[1] for r in rows), sorted(r[2] for r in rows)
+        return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
+                "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "samples": len(rows),
+                "note": f"rocm-smi --showclocks --showpower polled from a thread during {what}; peak sclk 2400 MHz, socket power "
+                        "cap 1400 W (MI355X_MICROARCH.md): the default arithmetic runs at the power limit"}
+
+
 def synth_objects(rng, G, H=IMG_H, W=IMG_W):
     """Synthetic boxes + visible masks (ellipse in the box, odd objects half occluded) -- SURVEY.md §8d."""
     boxes = np.zeros((G, 4), np.float32)
@@ -129,7 +173,7 @@ def cpu_baseline(steps=3):
                        f"of one GPU step; 6 objects per image), best of {n_timed} timed step(s), {nthreads} threads")
 
 
-def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
+def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
     """`roofline` (+ companions) from the per-launch HIP events of the instrumented pass.
     Per kernel instantiation: launches per step, average duration in the step, algorithmic flops, share of the summed
     conv-GEMM time.  `roofline` = the instantiation with the LARGEST share, in the step and alone on the device (every
@@ -155,6 +199,8 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
 
     def entry(k, f, alone=False):
         mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if planes(k) else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        if math in ("bf16", "bf16-storage") and not k.startswith("stem"):    # one issued bf16 MAC per algorithmic MAC
+            mult, peak = 1.0, BF16_MFMA_PEAK_TFLOPS
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
         e = {"kernel": k, "launches_per_step": round(f["n"] / steps, 2), "avg_us": round(f["ms"] / f["n"] * 1e3, 2),
              "flop_per_launch": f["flops"] / f["n"], "algorithmic_bytes_per_launch": round(f["bytes"] / f["n"]),
@@ -190,6 +236,8 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
         if tj.get("kernel", "").replace(" ", "") == dom_k.replace(" ", ""):
             traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
     roof["traffic"] = traffic
+    roof["traffic_source"] = ("profiles/roofline_traffic.json (committed rocprofv3 PMC pass of this kernel: FETCH_SIZE / WRITE_SIZE in separate "
+                              "runs, tools/pmc_traffic.py); NOT measured in this run") if traffic is not None else None
     if tnote:
         roof["traffic_note"] = tnote
     roof["selection"] = ("largest share of the summed conv-GEMM kernel time of the step (HIP events around every conv launch, "
@@ -201,6 +249,8 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
                     "`peak` is the 2.4 GHz figure.")
     mult_all = 6.0 if x3 else 1.0
     peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
+    if math in ("bf16", "bf16-storage"):
+        mult_all, peak_all = 1.0, BF16_MFMA_PEAK_TFLOPS
     all_tf = tot_fl / (tot_ms * 1e-3) / 1e12
     rep = {"roofline": roof,
            "roofline_all_conv_gemms": {
@@ -214,6 +264,7 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
                "kernels": [entry(k, f) for k, f in order[:8]]},
            "kernel_events": {"ms_per_step_with_events": round(dt_ev / steps * 1e3, 3), "ms_per_step": round(ms_clean, 3),
                              "conv_launches_per_step": round(len(events) / steps, 1)}}
+    rep["stages"] = stage_table(events, steps, mult_all, peak_all)
     tg = rt.engine.tower_gemm_flops()
     tower = [(k, f) for k, f in order if igemm_tag(k) is not None and (igemm_tag(k) & 1) and     # the tagged symbol: forward launches only
              min(abs(f["flops"] / f["n"] - tg), abs(f["flops"] / f["n"] - 2.0 * tg)) < 1.0]
@@ -230,6 +281,43 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value):
     return rep
 
 
+def stage_table(events, steps, mult, peak):
+    """Per part of the detector (stem, layer1..4, neck, head) and kind of launch (fwd / dgrad / wgrad): launches per step, summed
+    kernel time, WALL time from the first launch's start event to the last launch's end event (launches of one kind and stage
+    overlap with other streams' work, and wgrads run next to the dgrad chain, so walls of different rows overlap), algorithmic
+    flop, and the rate over the wall time as a fraction of the pipe the step's arithmetic runs on."""
+    per = len(events) // steps
+    acc = {}
+    for st in range(steps):
+        chunk = events[st * per:(st + 1) * per]
+        ref = chunk[0]["start"]
+        spans = {}
+        for ev in chunk:
+            k = (ev.get("stage") or "?", ev.get("kind") or "fwd")
+            t0, t1 = ref.elapsed_time(ev["start"]), ref.elapsed_time(ev["end"])
+            sp = spans.setdefault(k, [t0, t1, 0.0, 0.0, 0])
+            sp[0], sp[1] = min(sp[0], t0), max(sp[1], t1)
+            sp[2] += t1 - t0; sp[3] += ev["flops"]; sp[4] += 1
+        for k, sp in spans.items():
+            a = acc.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
+            a[0] += sp[1] - sp[0]; a[1] += sp[2]; a[2] += sp[3]; a[3] += sp[4]; a[4] += sp[0]
+    order = ["stem", "layer1", "layer2", "layer3", "layer4", "neck", "head"]
+    rows = []
+    for (stage, kind), a in sorted(acc.items(), key=lambda kv: (order.index(kv[0][0]) if kv[0][0] in order else 99,
+                                                                 ("fwd", "dgrad", "wgrad").index(kv[0][1]))):
+        wall_ms, sum_ms, fl = a[0] / steps, a[1] / steps, a[2] / steps
+        tf = fl / (wall_ms * 1e-3) / 1e12 if wall_ms > 0 else 0.0
+        rows.append({"stage": stage, "kind": kind, "launches_per_step": round(a[3] / steps, 1), "wall_us": round(wall_ms * 1e3, 1),
+                     "summed_kernel_us": round(sum_ms * 1e3, 1), "starts_at_us": round(a[4] / steps * 1e3, 1),
+                     "gflop": round(fl / 1e9, 2), "algorithmic_tflops_over_wall": round(tf, 1),
+                     "frac_of_pipe_over_wall": round(tf * (1.0 if stage == "stem" else mult) / (FP32_MFMA_PEAK_TFLOPS if stage == "stem" else peak), 4)})
+    return {"rows": rows,
+            "note": "from the HIP events of the instrumented pass (conv GEMM launches only: GroupNorm / loss / pooling / optimizer "
+                    "kernels are not in it); wall = first start .. last end of the row's launches inside one step, averaged over "
+                    "the steps; the stem runs on the fp32 MFMA pipe (priced against 157.3 TFLOP/s), everything else against "
+                    "the pipe of the step's arithmetic (x6 issued bf16 MACs / 2500 for the default fp32 mode)"}
+
+
 def _child(argv, timeout=900):
     import subprocess
     r = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout)
@@ -244,11 +332,39 @@ def extras(args):
     and configs[4] (R101 800x800 bs 2) as short runs, and the headline step on seeded trained-like parameters."""
     out = {}
     cfgs = os.path.join(ROOT, "tools", "bench_configs.py")
-    for key, argv in (("infer", [cfgs, "infer", "--json", "--images", "200"]), ("r101", [cfgs, "r101", "--json", "--steps", "8"])):
+    for key, argv in (("infer", [cfgs, "infer", "--json", "--images", "1000"]), ("r101", [cfgs, "r101", "--json", "--steps", "8"])):
         try:
             out[key] = _child(argv)
         except Exception as e:                   # the headline line must not depend on the secondary runs
             out[key] = {"error": repr(e)[:200]}
+    me = os.path.abspath(__file__)
+    short = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-mfma-line", "--no-extras"]
+    try:                                         # BASELINE configs[2] arithmetic on one GPU (bf16 tensors + operands)
+        d = _child([me, "--math", "bf16-storage"] + short)
+        out["bf16_storage"] = {
+            "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+            "losses_step1": d["config"]["losses_step1"],
+            "step_level": {"achieved": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "roofline": {k: d["roofline"][k] for k in ("kernel", "avg_us", "achieved", "peak", "frac", "share_of_conv_gemm_time")
+                         if k in d.get("roofline", {})},
+            "clock_power": d.get("clock_power"),
+            "note": "same step, `python bench.py --math bf16-storage` (BASELINE configs[2] arithmetic on ONE GPU: bf16 activations / "
+                    "folded weights / activation gradients in HBM, v_mfma_f32_32x32x16_bf16 with f32 accumulation, f32 loss / "
+                    "GroupNorm statistics / master weights / AdamW); one issued bf16 MAC per algorithmic MAC"}
+    except Exception as e:
+        out["bf16_storage"] = {"error": repr(e)[:200]}
+    try:                                         # the reference's own operating point: samples_per_gpu = 16
+        d = _child([me, "--batch", "16", "--no-kernel-events"] + short)
+        out["bs16"] = {
+            "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"], "per_gpu_batch": 16,
+            "step_level": {"achieved": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * 6, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * 6 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "clock_power": d.get("clock_power"),
+            "note": "same fp32 step at the reference config's samples_per_gpu = 16 (configs/bop/r50_ycbv_pbr.py:85), "
+                    "`python bench.py --batch 16`; secondary -- the headline is BASELINE's bs 4"}
+    except Exception as e:
+        out["bs16"] = {"error": repr(e)[:200]}
     try:
         d = _child([os.path.abspath(__file__), "--weights", "synth", "--steps", str(args.steps), "--warmup", str(args.warmup),
                     "--no-cpu-baseline", "--no-kernel-events", "--no-mfma-line", "--no-extras"])
@@ -272,6 +388,8 @@ def main():
     ap.add_argument("--no-mfma-line", action="store_true", help="skip the native-f32-MFMA comparison measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (inference config 4, R101 config 5, synthetic trained-like weights)")
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH,
+                    help="images per GPU (default 4 = BASELINE configs[1], the headline; 16 = the reference config's samples_per_gpu)")
     ap.add_argument("--weights", choices=("init", "synth"), default="init",
                     help="init = the detector's own random initialisation (headline); synth = seeded trained-like parameters "
                          "and running statistics (radet_amd/utils/synth_init.py): dense, decorrelated activations")
@@ -306,7 +424,7 @@ def main():
     rt.init_optimizer(lr=o.lr, betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay,
                       max_norm=float(cfg.optimizer_config.grad_clip.max_norm))
     rt.set_loss_from_head(det.bbox_head)
-    B = PER_GPU_BATCH
+    B = args.batch
     img, boxes, labels, p2g, pw = make_batch(rank, B, device)
     tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels],
                          list(p2g), list(pw))
@@ -322,15 +440,21 @@ def main():
         if first is None:
             first = out_l.clone()
     sync()
+    sampler = ClockSampler() if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_l = rt.train_step(img, tg)
         if first is None:
             first = out_l.clone()             # device-side copy: no host synchronisation inside the timed region
+    t_enq = time.perf_counter() - t0          # the Python loop body alone: every launch of K steps enqueued, nothing awaited
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    t_end = t0 + dt
+    dt_rank = dt
     losses = rt.engine.losses.cpu().numpy()
     # the same K steps once more with a pair of HIP events around EVERY conv GEMM launch, on the stream it is launched on
     # (radet_amd.kernels.EVENTS): the per-kernel table behind `roofline`.  Kept out of the region above so that `value` is
@@ -346,9 +470,24 @@ def main():
         torch.cuda.synchronize()
         dt_ev = time.perf_counter() - t1
         K.EVENTS = None
+    if sampler is not None:
+        # the timed region of a default run lasts 0.2 s = two or three rocm-smi reads: keep the same step running for ~1.5 s more
+        # (untimed) so that the medians rest on >= 15 samples; both windows are reported
+        t_keep0 = time.perf_counter()
+        if world == 1:
+            while time.perf_counter() - t_keep0 < 1.5:
+                for _ in range(10):
+                    rt.train_step(img, tg)
+                torch.cuda.synchronize()
+        t_keep1 = time.perf_counter()
+        sampler.__exit__()
     assert np.isfinite(losses).all(), f"non-finite losses {losses}"
     t = torch.tensor([dt], device=device, dtype=torch.float64)
+    rank_ms = None
     if world > 1:
+        per_rank = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([dt_rank, t_enq], device=device, dtype=torch.float64))
+        rank_ms = [[round(float(v[0]) / args.steps * 1e3, 3), round(float(v[1]) / args.steps * 1e3, 3)] for v in per_rank]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -368,7 +507,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         out = {
-            "metric": "images/sec train-step, r50_ycbv_pbr 640x480 bs=4/GPU",
+            "metric": f"images/sec train-step, r50_ycbv_pbr 640x480 bs={B}/GPU",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "fp32-mfma": "f32", "bf16": "bf16 operands, f32 accumulate (f32 tensors in HBM)",
@@ -380,6 +519,23 @@ def main():
                        "step_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
                        "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
         }
+        out["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 3)
+        out["host"] = {"cores": effective_cores(), "cpu": cpu_model(),
+                       "note": "host_enqueue_ms_per_step = wall time of the Python loop body of the timed region (all launches of a "
+                               "step enqueued, no synchronisation) per step, this rank; the step is GPU-bound while it stays below "
+                               "ms_per_step"}
+        if B != PER_GPU_BATCH:
+            out["metric"] += " [NOT the headline: BASELINE configs[1] is bs 4]"
+            out["config"]["workload"] = out["config"]["workload"].replace("bs=4", f"bs={B}").replace("(BASELINE configs[1])", "(secondary)")
+        if rank_ms is not None:
+            out["ranks"] = {"ms_per_step_min": min(r[0] for r in rank_ms), "ms_per_step_max": max(r[0] for r in rank_ms),
+                            "host_enqueue_ms_per_step_max": max(r[1] for r in rank_ms), "per_rank_ms_per_step": [r[0] for r in rank_ms],
+                            "note": "each rank's own wall time of the K timed steps (its synchronize + the closing barrier included); a "
+                                    "straggler shows as min << max"}
+        if sampler is not None:
+            out["clock_power"] = sampler.report(t0, t_end, "the timed region")
+            if world == 1:
+                out["clock_power"]["sustained"] = sampler.report(t_keep0, t_keep1, "~1.5 s of the same step right after the timed region")
         if comm is not None:
             out["comm"] = comm
         x3 = bool(rt.engine.x3)
@@ -394,7 +550,7 @@ def main():
             out["metric"] += " [bf16 math mode: NOT the headline fp32 metric]"
             out["config"]["workload"] = out["config"]["workload"].replace("fp32", "bf16-math").replace("configs[1]", "configs[2] arithmetic")
         if events:
-            out.update(kernel_report(events, args.steps, rt, x3, dt_ev, ms, value))
+            out.update(kernel_report(events, args.steps, rt, x3, dt_ev, ms, value, args.math))
         if world == 1 and x3 and not args.no_mfma_line:
             # the same step with the native f32 matrix instruction: a child process (its own streams and hardware
             # queues; measured inside this process after the main run it shared queues with the first runtime)

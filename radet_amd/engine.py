@@ -583,11 +583,13 @@ class Engine:
         B, H, W = self.B, self.H, self.W
         b = self.buf
         self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
+        K.STAGE = "stem"
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
         K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
         x = b["pool"]
         outs = []
         for li, blocks in enumerate(self.stages):
+            K.STAGE = f"layer{li + 1}"
             if blocks[0]["train"]:
                 self._await_fold()            # trainable weights are being folded on the side stream
             for bi, blk in enumerate(blocks):
@@ -607,6 +609,7 @@ class Engine:
         return outs  # C2..C5 row buffers
 
     def neck_forward(self, feats):
+        K.STAGE = "neck"
         self._await_fold()
         b, B = self.buf, self.B
         c = feats[1:]
@@ -772,6 +775,7 @@ class Engine:
         return yc, yr
 
     def head_forward(self, P):
+        K.STAGE = "head"
         b = self.buf
         n = self.stacked_convs
         if self.tower_mode in ("pair", "hybrid", "pairbwd"):
@@ -926,6 +930,7 @@ class Engine:
 
     def head_backward(self):
         """Consumes buf['dcls'] / buf['dregiou'] (written by loss()); leaves dL/dP in buf['dP']."""
+        K.STAGE = "head"
         b = self.buf
         n = self.stacked_convs
         dP = b["dP"]
@@ -1041,6 +1046,7 @@ class Engine:
             t.copy_(self.dscales[i])
 
     def neck_backward(self, dP):
+        K.STAGE = "neck"
         b, B, f = self.buf, self.B, self.feat
         P = b["P"]
         lr = [self.plv.level_rows(i) for i in range(5)]
@@ -1080,6 +1086,7 @@ class Engine:
             blocks = self.stages[li]
             if not blocks[0]["train"]:
                 break
+            K.STAGE = f"layer{li + 1}"        # (the dgrad into this stage's last block reads the next stage's conv1 / shortcut)
             for bi in range(len(blocks) - 1, -1, -1):
                 blk = blocks[bi]
                 pfx = f"l{li + 1}.{bi}"

@@ -73,6 +73,7 @@ _TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometr
 # the kernel instantiation the launcher dispatches to, `flops` = 2 * rows * Cout * Cin * taps of the launch (x 2 for a
 # grouped pair), `replay()` issues the same launch again (same buffers) for the "alone on the device" timing.
 EVENTS = None
+STAGE = ""          # part of the detector the engine is enqueueing (stem, layer1..4, neck, head): recorded with every event
 _TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2",
           7: "64, 64, 2, 2", 8: "64, 64, 2, 2"}
 
@@ -98,8 +99,9 @@ def _igemm_key(t, x):
     return f"conv_igemmg_kernel<{_TILES.get(tid, '?')}, {tag}, {bk}, {stages}, {'true' if skw and tag == 0 else 'false'}>"
 
 
-def _timed(key, flops, fn, nbytes=0.0):
-    """key: the kernel's name, or a callable producing it (only evaluated when a measurement is running)"""
+def _timed(key, flops, fn, nbytes=0.0, kind="fwd"):
+    """key: the kernel's name, or a callable producing it (only evaluated when a measurement is running); kind: fwd / dgrad /
+    wgrad; the engine's STAGE at the time of the call goes into the record (bench.py's per-stage table)"""
     ev = EVENTS
     if ev is None:
         return fn()
@@ -107,7 +109,8 @@ def _timed(key, flops, fn, nbytes=0.0):
     s.record()
     fn()
     e.record()
-    ev.append(dict(key=key() if callable(key) else key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn))
+    ev.append(dict(key=key() if callable(key) else key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn,
+                   stage=STAGE, kind=kind))
 
 
 def _conv_bytes(g, groups=1):
@@ -630,7 +633,7 @@ def conv_dgrad_pair(g, a, b, tile=0):
     t, table = _tile(g, tile, g.bwd_tile, a["x"], a["y"]), g.bwd_table
     _timed(lambda: _igemm_key(t, a["x"]), 4.0 * g.lin.rows * g.cout * g.cin * g.k * g.k,
            lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
-                             t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
+                             t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2), kind="dgrad")
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
@@ -647,7 +650,7 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
         real_k = min(kc, g.cout)
         _timed(_igemm_key(tile, dy) + (" [strided dgrad, class launch]" if g.stride > 1 else ""),
                2.0 * g.lout.rows * real_k * g.cin * g.k * g.k,
-               lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows), _conv_bytes(g))
+               lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows), _conv_bytes(g), kind="dgrad")
         return
     _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows)
 
@@ -695,7 +698,7 @@ def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
         co_ = g.cout if cout is None else cout
         _timed(_wgrad_key(g, dy, co_), 2.0 * g.lout.rows * co_ * g.cin * g.k * g.k,
                lambda: _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy),
-               4.0 * (g.lout.rows * co_ + g.lin.rows * g.cin + g.nsplit * co_ * g.k * g.k * g.cin))
+               4.0 * (g.lout.rows * co_ + g.lin.rows * g.cin + g.nsplit * co_ * g.k * g.k * g.cin), kind="wgrad")
         return
     _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy)
 
@@ -754,7 +757,10 @@ def _h(name, t):
 
 
 def stem(img, wf, bias, y, B, H, W):
-    _lib.call(_h("radet_stem_conv_bn_relu", y), _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream())
+    ho, wo = (H + 1) // 2, (W + 1) // 2
+    _timed("stem_kernel", 2.0 * B * ho * wo * 64 * 147,
+           lambda: _lib.call(_h("radet_stem_conv_bn_relu", y), _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream()),
+           4.0 * (B * 3 * H * W + 64 * 147 + B * ho * wo * 64))
 
 
 def convert_rows(src, dst, ncols=None, src_off=0, dst_off=0):

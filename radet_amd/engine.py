@@ -783,7 +783,7 @@ class Engine:
             if self.p3:
                 K.split_planes(P, b["Pp"])
                 xc = xr = b["Pp"]
-            if self.p3 and self.tower_fwd_streams:
+            if self.p3 and self.tower_fwd_streams and self.use_streams:
                 # plane operands: a tower GEMM is 200 tiles of 256 x 128 and a tile owns a CU, so the grouped cls + reg launch
                 # is two rounds on 256 CUs with the second 56 % full.  The two towers as two chains on two streams instead:
                 # the tiles of one chain's GEMM take the CUs the other chain's GEMM leaves free (1600 tiles = 6.25 rounds
@@ -934,7 +934,7 @@ class Engine:
         b = self.buf
         n = self.stacked_convs
         dP = b["dP"]
-        if self.p3 and self.tower_mode == "pairbwd" and os.environ.get("RADET_TOWER_BWD_CHAINS", "1") != "0":
+        if self.p3 and self.tower_mode == "pairbwd" and self.use_streams and os.environ.get("RADET_TOWER_BWD_CHAINS", "1") != "0":
             # plane operands: the two towers' backward as two CHAINS (cls on this stream, reg on the chain stream), each layer
             # GroupNorm backward -> weight gradient (on the side streams, as before) -> dgrad as ONE 200-tile launch.  The
             # grouped cls + reg dgrad (400 tiles of 256 x 128 that own a CU each = two rounds, the second 56 % full) held
@@ -1076,9 +1076,10 @@ class Engine:
         self.flush_wgrads()
         return [b["d_c0"], b["d_c1"], b["d_c2"]]
 
-    def backbone_backward(self, d_feats, after_stage=None):
+    def backbone_backward(self, d_feats, after_stage=None, block_ends=()):
         """d_feats: gradients w.r.t. C3, C4, C5 coming from the neck. `after_stage(li)` is called once
-        all weight gradients of stage li are complete (bucketed unfold / all-reduce hook)."""
+        all weight gradients of stage li are complete (bucketed unfold / all-reduce hook); for the (stage, block) pairs in
+        `block_ends` also `after_stage(li, bi)` right after block bi's weight gradients (per-block gradient buckets)."""
         b = self.buf
         d_next_pre = None     # d_pre of the block after the current one (same stage or next stage's first block)
         nxt = None            # that block
@@ -1119,7 +1120,10 @@ class Engine:
                 if ds is not None:
                     self._wgrad_async(ds.geom, d_pre, blk["x"], ds.slabs, ds.dbias_partials, conv=ds)
                 nxt = blk
-                if self.wgrad_flush_blocks and (len(blocks) - bi) % self.wgrad_flush_blocks == 0:
+                if (li, bi) in block_ends and after_stage is not None:
+                    self.flush_wgrads()
+                    after_stage(li, bi)
+                elif self.wgrad_flush_blocks and (len(blocks) - bi) % self.wgrad_flush_blocks == 0:
                     self.flush_wgrads()
             self.flush_wgrads()
             if after_stage is not None:

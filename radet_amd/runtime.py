@@ -95,12 +95,24 @@ class FlatParams:
         return p is None or (p.data_ptr() == self.p[self.train_names[0]].data_ptr())
 
 
-def compute_buckets(flat, conv_names, conv_trainable):
+def compute_buckets(flat, conv_names, conv_trainable, split=("backbone.layer4.",), min_bytes=15e6):
     """Gradient buckets in backward order: (prefix, conv-table range, gradient-arena range).
-    Arena ranges are contiguous, disjoint and together cover every trainable parameter."""
+    Arena ranges are contiguous, disjoint and together cover every trainable parameter.
+    A stage named in `split` is cut into one bucket per run of bottleneck blocks of >= min_bytes (fp32), last block first:
+    layer4 holds 47 % of all gradient bytes (59.9 MB) and is the first backbone stage of the backward pass, so as ONE message
+    its exchange could only start when the whole stage's weight gradients were reduced (3.97 ms into a 5.93-ms backward
+    pass); per block (17.8 + 17.8 + 24.3 MB) the first message leaves a third of the way through the stage.  xGMI links
+    want few large messages, hence the 15-MB floor (layer3's six blocks of 4.5 MB stay one 28-MB bucket)."""
     def rng(pf):
         idx = [i for i, n in enumerate(conv_names) if n.startswith(pf)]
         return (idx[0], idx[-1] + 1) if idx else None
+
+    def bucket(pf, groups, r, blocks=None):
+        arena = flat.group_ranges(groups)
+        d = dict(prefix=pf, convs=r, arena=(min(a[1] for a in arena), max(a[2] for a in arena)))
+        if blocks is not None:
+            d["blocks"] = blocks                  # (stage index, first block, last block) of a per-block bucket
+        return d
 
     buckets = []
     for pf in ("bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2.", "backbone.layer1.",
@@ -108,9 +120,30 @@ def compute_buckets(flat, conv_names, conv_trainable):
         r = rng(pf)
         if r is None or not any(conv_trainable[r[0]:r[1]]):
             continue
-        groups = ["backbone.conv1", "backbone.bn1"] if pf == "backbone.conv1" else [pf]
-        arena = flat.group_ranges(groups)
-        buckets.append(dict(prefix=pf, convs=r, arena=(min(a[1] for a in arena), max(a[2] for a in arena))))
+        if pf in split and os.environ.get("RADET_SPLIT_BUCKETS", "1") != "0":
+            nblk = 1 + max(int(n[len(pf):].split(".")[0]) for n in conv_names[r[0]:r[1]])
+            runs, hi = [], nblk - 1
+            while hi >= 0:                         # runs of blocks [lo, hi], last block first, each >= min_bytes
+                lo, size = hi, 0
+                while True:
+                    size += 4 * sum(e - b for _, b, e in flat.group_ranges([f"{pf}{lo}."]))
+                    if size >= min_bytes or lo == 0:
+                        break
+                    lo -= 1
+                runs.append((lo, hi))
+                hi = lo - 1
+            if len(runs) > 1 and 4 * sum(e - b for _, b, e in flat.group_ranges([f"{pf}{k}." for k in range(runs[-1][0], runs[-1][1] + 1)])) < min_bytes:
+                runs[-2] = (runs[-1][0], runs[-2][1])      # a short remainder joins the run before it
+                runs.pop()
+            if len(runs) > 1:
+                li = int(pf[len("backbone.layer"):-1]) - 1
+                for lo, hi in runs:
+                    names = [f"{pf}{k}." for k in range(lo, hi + 1)]
+                    cr = [rng(n) for n in names]
+                    buckets.append(bucket(f"{pf}{lo}-{hi}." if lo != hi else names[0], names, (min(c[0] for c in cr), max(c[1] for c in cr)),
+                                          blocks=(li, lo, hi)))
+                continue
+        buckets.append(bucket(pf, ["backbone.conv1", "backbone.bn1"] if pf == "backbone.conv1" else [pf], r))
     return buckets
 
 
@@ -127,6 +160,18 @@ class _StreamWork:
 
     def _get_duration(self):                                   # ms, valid once `done` has completed
         return self.t0.elapsed_time(self.done)
+
+
+def sync_collectives_run_on_current_stream():
+    """c10d issues `async_op=False` NCCL / RCCL collectives on the caller's current stream since torch 2.8 (before that
+    every collective ran on the process group's internal stream and the caller's stream waited for it).  The gradient exchange
+    relies on it to stay inside the four-stream budget (engine.py): on an older build the collectives would silently move
+    to RCCL's own stream -- a fifth stream, measured +35 % step time."""
+    try:
+        major, minor = (int(x) for x in torch.__version__.split("+")[0].split(".")[:2])
+    except ValueError:
+        return True
+    return (major, minor) >= (2, 8)
 
 
 class GradReducer:
@@ -232,14 +277,25 @@ class DetectorRuntime:
         self.buckets = compute_buckets(self.flat, [c.name for c in self.engine.convs],
                                        [c.trainable for c in self.engine.convs])
         self.reducer = None
+        self._replicas_synced = False
         # (no collective here: a runtime may be built by a subset of the ranks -- rank-0 evaluation, checkpoint
         # conversion.  Data-parallel replicas are equalised by init_optimizer(), the entry point of every training run.)
+
+    def aux_stream(self):
+        """A HIP stream the caller may borrow for its own small asynchronous work (the pinned upload of the next batch, a
+        metric read-back) INSTEAD of creating one: this device runs a process that uses more than four streams markedly
+        slower (DESIGN.md 5 "stream budget", measured cost in INTEGRATION.md), and the engine's four are all this process
+        should have.  It is the tower-chain stream: idle from the end of a step's head backward pass (train) / of a batch's
+        decode + NMS (inference) until the next head pass, in-order with the reg tower and the gradient exchange -- work queued
+        on it before `train_step` simply runs first.  Synchronise with events as with any stream."""
+        return self.engine._chain_stream()
 
     def sync_replicas(self, src=0):
         """Broadcast the parameter arenas (trainable + frozen / BN statistics) and, once it exists, the optimizer
         state from rank `src`: what wrapping the model in MMDistributedDataParallel does at construction in the
         reference (radet/apis/train.py:73-81) and what a checkpoint loaded on one rank needs.  Collective: every rank
         of the default process group must call it.  No-op without an initialised group / with a single rank."""
+        self._replicas_synced = True
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return False
         arenas = [self.flat.params, self.flat.frozen]
@@ -304,16 +360,37 @@ class DetectorRuntime:
         """Reverse program. After each parameter group's wgrads are done its slabs are reduced /
         un-folded into the gradient arena and `bucket_hook(bucket)` may start its all-reduce."""
         e = self.engine
+        if not self._replicas_synced:
+            # the reference's DDP wrap broadcasts rank 0's parameters at construction (apis/train.py:73-81); here that is
+            # sync_replicas(), called by init_optimizer() / load_checkpoint().  A module-API training loop with its own
+            # torch optimizer never passes through those: say so once instead of training diverging replicas silently
+            self._replicas_synced = True
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                import warnings
+                warnings.warn("radet_amd: backward pass under a process group of "
+                              f"{dist.get_world_size()} ranks before DetectorRuntime.sync_replicas() / init_optimizer() was "
+                              "called: the replicas still hold their own initial parameters (call "
+                              "det.runtime().sync_replicas() on every rank once, see INTEGRATION.md)")
 
         def unfold(bucket):
             self._unfold_bucket(bucket, bucket_hook)
 
         bk = {b["prefix"]: b for b in self.buckets}
+        per_block = {(b["blocks"][0], b["blocks"][1]): b for b in self.buckets if "blocks" in b}   # keyed by the run's FIRST block
         dP = e.head_backward()
         unfold(bk["bbox_head."])
         d_feats = e.neck_backward(dP)
         unfold(bk["neck."])
-        e.backbone_backward(d_feats, after_stage=lambda li: unfold(bk["backbone.conv1" if li == "stem" else f"backbone.layer{li + 1}."]))
+
+        def after(li, bi=None):
+            if bi is not None:                  # a block's weight gradients are all issued: its run's bucket, if it ends one
+                if (li, bi) in per_block:
+                    unfold(per_block[(li, bi)])
+                return
+            pf = "backbone.conv1" if li == "stem" else f"backbone.layer{li + 1}."
+            if pf in bk:                        # (a stage that is cut into per-block buckets has none of its own)
+                unfold(bk[pf])
+        e.backbone_backward(d_feats, after_stage=after, block_ends=set(per_block))
         e.join_side()                           # gradients complete on the current stream from here on
 
     def _unfold_bucket(self, bucket, bucket_hook=None):
@@ -397,7 +474,7 @@ class DetectorRuntime:
             rows = [(t["prefix"], t["bytes"], ev0.elapsed_time(t["ready"]), ev0.elapsed_time(t["done"]), dur(t["work"])) for t in step]
             b = ev0.elapsed_time(ev1)
             fwd += ev_b.elapsed_time(ev0); bwd += b
-            exposed += max(0.0, max(r[3] for r in rows) - b)
+            exposed += max(0.0, max((r[3] for r in rows), default=0.0) - b)     # (a traced step may have handed over no bucket)
             acc = rows if acc is None else [(a[0], a[1], a[2] + r[2], a[3] + r[3], a[4] + r[4]) for a, r in zip(acc, rows)]
         rep = dict(steps=n, forward_loss_ms=round(fwd / n, 3), backward_ms=round(bwd / n, 3),
                    exposed_comm_ms=round(exposed / n, 3), bf16_buckets=bool(self.reducer.bf16),
@@ -423,9 +500,18 @@ class DetectorRuntime:
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
         if use_reducer:
             if self.reducer is None:
+                on_chain = self.engine.use_streams and self.flat.grads.is_cuda
+                if on_chain and not sync_collectives_run_on_current_stream():
+                    # the process group's internal stream will carry the exchange: keep the process at four streams by
+                    # giving up the second weight-gradient stream (10.43 instead of 9.97 ms at one rank)
+                    import warnings
+                    warnings.warn(f"torch {torch.__version__} runs synchronous collectives on the process group's own stream: "
+                                  "the gradient exchange uses that stream and the engine drops its second weight-gradient "
+                                  "stream to stay inside the four-stream budget of this device")
+                    on_chain = False
+                    self.engine.wgrad_streams = 1
                 self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets(),
-                                           comm_stream=self.engine._chain_stream()
-                                           if (self.engine.use_streams and self.flat.grads.is_cuda) else None)
+                                           comm_stream=self.engine._chain_stream() if on_chain else None)
             tr = self.reducer.trace is not None
             if tr:
                 ev0 = torch.cuda.Event(enable_timing=True)
@@ -612,8 +698,13 @@ def _detect_stream(self, batches, test_cfg, rescale=False):
     try:
         yield from run()
     finally:
-        # leave every plan with its own set (captured graphs and the training step hold pointers to it); the last batch's
-        # decode has been waited for by collect(), or the caller abandoned the stream and nobody reads its results
+        # leave every plan with its own set (captured graphs and the training step hold pointers to it).  After a complete
+        # run collect() has host-synchronised the last batch; an abandoned generator (break / exception mid-iteration) can
+        # still have a batch's decode / NMS reading the head outputs and the shared post-processing workspaces on the chain
+        # stream: whatever the caller enqueues next on this stream waits for it
+        for ev in post_ev:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         for pid, odd in swapped.items():
             if odd and pid in alts:
                 plan, other = alts[pid]
@@ -648,7 +739,15 @@ def _post_launch(self, hw, sf, test_cfg, head_out=None):
     key = ("post", B, nlvl, nms_pre)
     posts = self.__dict__.setdefault("_posts", {})
     if key not in posts:
-        if len(posts) >= 8:
+        # the NMS workspace holds a dense cap x cap / 64 x 8 B suppression mask per image (+ sort keys): 7 MiB per image at
+        # the BOP configs' nms_pre = 1000, ~310 MB at nms_pre = 10000, 512 MiB at the 65536-candidate limit
+        need = K.nms_ws_bytes(B, cap) + K.decode_ws_bytes(B, nlvl, nms_pre)
+        limit = int(float(os.environ.get("RADET_POST_WS_LIMIT_GB", "16")) * 2 ** 30)
+        if need > limit:
+            raise MemoryError(f"decode + NMS workspaces for batch {B} with nms_pre={nms_pre} ({cap} candidates per image) need "
+                              f"{need / 2 ** 30:.1f} GiB (dense suppression mask: cap^2 / 8 bytes per image); lower nms_pre or the "
+                              f"batch, or raise RADET_POST_WS_LIMIT_GB (now {limit / 2 ** 30:.0f})")
+        while posts and (len(posts) >= 8 or sum(v["nws"].numel() for v in posts.values()) + need > limit):
             posts.pop(next(iter(posts)))
         dev = self.dev
         posts[key] = dict(

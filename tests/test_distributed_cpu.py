@@ -36,7 +36,17 @@ def _build_flat():
 
 def test_flat_arena_and_buckets():
     det, flat, buckets = _build_flat()
-    assert [b["prefix"] for b in buckets] == ["bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2."]
+    # layer4 (59.9 MB, 47 % of the gradient bytes) is cut per bottleneck block, last block first; every message >= 15 MB
+    # except the one that cannot be larger (layer2, the last of the backward pass)
+    assert [b["prefix"] for b in buckets] == ["bbox_head.", "neck.", "backbone.layer4.2.", "backbone.layer4.1.", "backbone.layer4.0.",
+                                              "backbone.layer3.", "backbone.layer2."]
+    assert [b.get("blocks") for b in buckets[2:5]] == [(3, 2, 2), (3, 1, 1), (3, 0, 0)]
+    assert all(4 * (b["arena"][1] - b["arena"][0]) >= 15e6 for b in buckets[:-1])
+    os.environ["RADET_SPLIT_BUCKETS"] = "0"
+    try:
+        assert [b["prefix"] for b in _build_flat()[2]] == ["bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2."]
+    finally:
+        del os.environ["RADET_SPLIT_BUCKETS"]
     spans = sorted(b["arena"] for b in buckets)
     assert spans[0][0] == 0
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
@@ -190,7 +200,8 @@ def _step_worker(rank, world, port, q, ckpt):
     dist.all_gather(gathered, rt.flat.params)
     same_end = all(torch.equal(gathered[0], t) for t in gathered)
     moved = float((rt.flat.params - p0).abs().max()) > 0
-    order_ok = rt.order[:5] == ["bbox_head.", "neck.", "backbone.layer4.", "backbone.layer3.", "backbone.layer2."]
+    order_ok = rt.order[:7] == ["bbox_head.", "neck.", "backbone.layer4.2.", "backbone.layer4.1.", "backbone.layer4.0.",
+                                "backbone.layer3.", "backbone.layer2."]
     # checkpoint written by rank 0 only, loaded by rank 0 only -> load_checkpoint's broadcast keeps the replicas equal
     if rank == 0:
         save_checkpoint(det, ckpt, meta=dict(iter=2), runtime=rt)

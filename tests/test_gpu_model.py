@@ -161,6 +161,38 @@ def test_stream_budget(det, golden):
     # the exchange runs on the chain stream the detector hands it, not on a stream of its own
     red = GradReducer(torch.ones(8, device="cuda"), torch.device("cuda", dev), comm_stream=e._chain_stream())
     assert red.comm_stream is e._chain_stream()
+    # a caller that needs a stream (next-batch upload of a loader) borrows the chain stream instead of creating a fifth one;
+    # with its copy in flight on it -- and, for comparison, on a stream of the caller's own (slower on this device, see
+    # tools/bench_user_stream.py / INTEGRATION.md, but correct) -- two steps produce the same bits as without
+    assert rt.aux_stream() is e._chain_stream()
+    d.train()
+    tg = rt.pack_targets(gt_b, gt_l, p2g, pw)
+    host, nxt = img.cpu().pin_memory(), torch.empty_like(img)
+
+    def two_steps(stream):
+        st = d.state_dict()
+        snap = {k: v.clone() for k, v in st.items()}
+        m, v = rt.opt_state["m"].clone(), rt.opt_state["v"].clone()
+        cnt = rt.step_count
+        out = []
+        for _ in range(2):
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    nxt.copy_(host, non_blocking=True)
+            out.append(rt.train_step(img, tg).clone())
+        torch.cuda.synchronize()
+        res = (torch.stack(out).cpu(), rt.flat.params.clone())
+        with torch.no_grad():                       # rewind
+            for k, t in st.items():
+                t.copy_(snap[k])
+        rt.opt_state["m"].copy_(m); rt.opt_state["v"].copy_(v); rt.step_count = cnt
+        rt.engine.params_changed()
+        return res
+    base = two_steps(None)
+    for stream in (rt.aux_stream(), torch.cuda.Stream()):
+        got = two_steps(stream)
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
+        assert torch.equal(nxt, img)
 
 
 _OWN_STREAM_PROBE = r"""
@@ -389,6 +421,34 @@ def test_multi_geometry_plans_no_retune_no_realloc():
     assert len(rt.engine._plans) <= rt.engine.max_plans
     again = rt.detect(img1, metas, det.test_cfg)
     assert torch.equal(again[0][0], first[0][0])
+
+
+def test_detect_stream_abandoned_mid_iteration():
+    """A caller that breaks out of rt.detect_stream leaves a batch's decode / NMS in flight on the chain stream, reading the
+    head outputs and the shared post-processing workspaces: the generator's clean-up makes the main stream wait for it and
+    hands the plan its own buffer set back, so the next detect() neither races with it nor sees swapped buffers."""
+    import numpy as np
+    det = make_det().eval()
+    rt = det.runtime()
+    with torch.no_grad():
+        det.bbox_head.atss_cls.bias += 2.0
+    g = torch.Generator().manual_seed(9)
+    metas = [dict(img_shape=(320, 384, 3), scale_factor=np.ones(4, np.float32)) for _ in range(2)]
+    work = [(torch.randn(2, 3, 320, 384, generator=g).cuda(), metas) for _ in range(4)]
+    ref = [rt.detect(im, m, det.test_cfg, rescale=True) for im, m in work]
+    own = {k: rt.engine.buf[k].data_ptr() for k in ("cls", "reg_u", "iou")}
+    for stop_after in (1, 2):
+        it = rt.detect_stream(iter(work), det.test_cfg, rescale=True)
+        for k, got in enumerate(it):
+            for (da, la), (db, lb) in zip(got, ref[k]):
+                assert torch.equal(da, db) and torch.equal(la, lb)
+            if k + 1 == stop_after:
+                break
+        it.close()                                   # (what leaving the loop does once the generator is collected)
+        assert own == {k: rt.engine.buf[k].data_ptr() for k in own}
+        again = rt.detect(*work[3], det.test_cfg, rescale=True)     # at once, on the main stream
+        for (da, la), (db, lb) in zip(again, ref[3]):
+            assert torch.equal(da, db) and torch.equal(la, lb) and da.shape[0] > 0
 
 
 def test_detect_stream_matches_detect():

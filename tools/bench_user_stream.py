@@ -1,0 +1,50 @@
+"""What a stream of the USER's costs next to the engine's four (DESIGN.md 5 "stream budget"):
+the headline train step (a) alone, (b) with a user-created HIP stream that uploads the next batch (pinned H2D copy of a
+4 x 3 x 480 x 640 image tensor per step, what a data loader's copy stream does), (c) the same upload on the stream the
+package lends for it (`rt.aux_stream()` = the tower-chain stream, idle outside the head), (d) with a user stream that
+exists but is never used.  python tools/bench_user_stream.py [steps]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from radet_amd.models import build_detector
+from radet_amd.utils import Config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+cfg = Config.fromfile(os.path.join(ROOT, "configs", "bop", "r50_ycbv_pbr.py")); cfg.model["pretrained"] = None
+torch.manual_seed(0)
+det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+rt = det.runtime(); rt.init_optimizer()
+dev = torch.device("cuda")
+img, boxes, labels, p2g, pw = bench.make_batch(0, 4, dev)
+tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
+host = img.cpu().pin_memory()
+nxt = torch.empty_like(img)
+
+
+def run(copy_stream=None, label=""):
+    for _ in range(5):
+        rt.train_step(img, tg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if copy_stream is not None:
+            with torch.cuda.stream(copy_stream):
+                nxt.copy_(host, non_blocking=True)
+        rt.train_step(img, tg)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    print(f"{label:70s} {ms:7.3f} ms/step", flush=True)
+    return ms
+
+
+a = run(None, "(a) train step alone (engine: main + 3 streams)")
+c = run(rt.aux_stream(), "(c) + next-batch upload on rt.aux_stream() (the lent chain stream)")
+a2 = run(None, "(a) again")
+user = torch.cuda.Stream()
+d = run(None, "(d) a fifth stream exists, never used")
+b = run(user, "(b) + next-batch upload on a user-created fifth stream")
+b2 = run(None, "(a) after the fifth stream was used")
+print(f"ratios vs (a): lent stream {c / a:.3f}, idle fifth stream {d / a2:.3f}, busy fifth stream {b / a2:.3f}, afterwards {b2 / a2:.3f}")

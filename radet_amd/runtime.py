@@ -281,15 +281,6 @@ class DetectorRuntime:
         # (no collective here: a runtime may be built by a subset of the ranks -- rank-0 evaluation, checkpoint
         # conversion.  Data-parallel replicas are equalised by init_optimizer(), the entry point of every training run.)
 
-    def aux_stream(self):
-        """A HIP stream the caller may borrow for its own small asynchronous work (the pinned upload of the next batch, a
-        metric read-back) INSTEAD of creating one: this device runs a process that uses more than four streams markedly
-        slower (DESIGN.md 5 "stream budget", measured cost in INTEGRATION.md), and the engine's four are all this process
-        should have.  It is the tower-chain stream: idle from the end of a step's head backward pass (train) / of a batch's
-        decode + NMS (inference) until the next head pass, in-order with the reg tower and the gradient exchange -- work queued
-        on it before `train_step` simply runs first.  Synchronise with events as with any stream."""
-        return self.engine._chain_stream()
-
     def sync_replicas(self, src=0):
         """Broadcast the parameter arenas (trainable + frozen / BN statistics) and, once it exists, the optimizer
         state from rank `src`: what wrapping the model in MMDistributedDataParallel does at construction in the

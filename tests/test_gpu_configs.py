@@ -439,11 +439,14 @@ def test_streamed_inference_b16_vs_oracle():
     samples_per_gpu), `rt.detect_stream` (head outputs alternating between two buffer sets, decode + NMS of batch k on the
     chain stream next to the forward pass of batch k + 1), the cls bias shifted so that 2 % of the logits pass score_thr
     (~1800 candidates per image into vote-NMS, every image returns max_per_img = 100 boxes) -- against the CPU oracle's
-    simple_test (radet_head.py:55-169, vote_ext.cpp:70-207) on three different batches.
-    Two correct fp32 implementations differ by ~1e-6 in a score, so a candidate whose score sits within that of score_thr
-    (or of the nms_pre-th score of its level) is in one candidate set and not in the other: the oracle's own margins say which
-    images are free of such knife-edges, and THOSE must agree exactly -- labels and order equal, boxes / scores within 1e-4
-    (+ 2e-3 px) -- the others in at least 95 of their 100 detections."""
+    simple_test (radet_head.py:55-169, vote_ext.cpp:70-207) on three different batches = 48 images.
+    A detection agrees when the oracle has one of the same label with box and score within 1e-4 (+ 2e-3 px / 1e-6), which
+    also pins the keep order up to swaps of scores closer than that.  Two correct fp32 forward passes differ by ~1e-6 in a
+    score, and each image has ~134 000 of them with ~2 700 above score_thr = 0.05: nearly every image holds a score within
+    1e-6 of the threshold (the oracle's own margins are measured below), so now and then a candidate is in one candidate set
+    and not in the other and moves the vote of its cluster.  Required: every image returns 100 detections of which >= 95 agree,
+    and all but at most 3 of the 48 images agree in ALL 100 (measured: 48 of 48, 46 of them position by position -- the other two
+    swap neighbours whose scores differ by less than the tolerance)."""
     from oracle import model as om, synth
     from radet_amd.models import build_detector
     from radet_amd.utils import Config
@@ -469,41 +472,29 @@ def test_streamed_inference_b16_vs_oracle():
     with torch.no_grad():
         for n, t in odet.sd.items():
             t.copy_(sd[n].cpu())
-    thr, nms_pre = float(det.test_cfg["score_thr"]), int(det.test_cfg["nms_pre"])
-    n_clean = n_exact = n_img = 0
-    worst_frac = 1.0
+    thr = float(det.test_cfg["score_thr"])
+    stats = []
     for bi, im in enumerate(batches):
         with torch.no_grad(), om.conv_math(odet.math):
             outs = om.head(odet.sd, odet.extract_feat(im))
         ref = om.get_bboxes(*outs, metas, odet.test_cfg, True)
         for i in range(B):
-            # the oracle's margins: distance of the nearest score to score_thr, and of the nms_pre-th to the next one per level
-            margin = np.inf
-            for c in outs[0]:
-                s = c[i].sigmoid().flatten()
-                margin = min(margin, float((s - thr).abs().min()))
-                above = s[s > thr]
-                if above.numel() > nms_pre:
-                    top = above.topk(nms_pre + 1).values
-                    margin = min(margin, float(top[-2] - top[-1]))
+            margin = min(float((c[i].sigmoid() - thr).abs().min()) for c in outs[0])     # nearest score to score_thr (oracle)
             d, l = _det_rows(*got[bi][i])
             r, rl = _det_rows(*ref[i])
+            assert len(r) == 100 and len(d) == 100, (bi, i, len(r), len(d))
             tol = 1e-4 * np.abs(r[:, :5]) + np.array([2e-3] * 4 + [1e-6])
-            exact = d.shape == r.shape and np.array_equal(l, rl) and bool((np.abs(d[:, :5] - r[:, :5]) <= tol).all())
             used, hit = np.zeros(len(d), bool), 0
-            for k in range(len(r)):             # order-free agreement: how many reference detections have a partner
+            for k in range(len(r)):
                 cand = np.where(~used & (l == rl[k]) & (np.abs(d[:, :5] - r[k, :5]) <= tol[k]).all(1))[0]
                 if len(cand):
                     used[cand[0]] = True
                     hit += 1
-            frac = hit / max(1, len(r))
-            worst_frac = min(worst_frac, frac)
-            clean = margin > 2e-6
-            n_img += 1; n_clean += clean; n_exact += exact
-            assert len(r) == 100 and len(d) == 100, (bi, i, len(r), len(d))
-            assert frac >= 0.95, (bi, i, frac, margin)
-            if clean:
-                assert exact, (bi, i, frac, margin)
-    print(f"streamed B=16 inference vs oracle: {n_img} images, {n_clean} free of threshold / top-k knife-edges, {n_exact} exact, "
-          f"worst order-free agreement {worst_frac:.3f}")
-    assert n_clean >= n_img // 2
+            in_order = bool(np.array_equal(l, rl) and (np.abs(d[:, :5] - r[:, :5]) <= tol).all())
+            stats.append((hit, in_order, margin))
+            assert hit >= 95, (bi, i, hit, margin)
+    full = sum(h == 100 for h, _, _ in stats)
+    print(f"streamed B=16 inference vs oracle: {len(stats)} images; all 100 detections agree in {full}, position by position in "
+          f"{sum(o for _, o, _ in stats)}; fewest agreeing {min(h for h, _, _ in stats)}; oracle's nearest score to score_thr: median "
+          f"{np.median([m for _, _, m in stats]):.1e}; images below 100: {[(h, f'{m:.0e}') for h, _, m in stats if h < 100]}")
+    assert full >= len(stats) - 3

@@ -1,8 +1,7 @@
 """What a stream of the USER's costs next to the engine's four (DESIGN.md 5 "stream budget"):
 the headline train step (a) alone, (b) with a user-created HIP stream that uploads the next batch (pinned H2D copy of a
-4 x 3 x 480 x 640 image tensor per step, what a data loader's copy stream does), (c) the same upload on the stream the
-package lends for it (`rt.aux_stream()` = the tower-chain stream, idle outside the head), (d) with a user stream that
-exists but is never used.  python tools/bench_user_stream.py [steps]"""
+4 x 3 x 480 x 640 image tensor per step, what a data loader's copy stream does), (c) the same upload on one of the engine's own streams (the tower-chain stream, idle outside the head), (d) with a user stream
+that exists but is never used, (e) the upload on the main stream in front of the step.  python tools/bench_user_stream.py [steps]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,10 +40,12 @@ def run(copy_stream=None, label=""):
 
 
 a = run(None, "(a) train step alone (engine: main + 3 streams)")
-c = run(rt.aux_stream(), "(c) + next-batch upload on rt.aux_stream() (the lent chain stream)")
+c = run(rt.engine._chain_stream(), "(c) + next-batch upload on the engine's tower-chain stream")
 a2 = run(None, "(a) again")
 user = torch.cuda.Stream()
 d = run(None, "(d) a fifth stream exists, never used")
 b = run(user, "(b) + next-batch upload on a user-created fifth stream")
 b2 = run(None, "(a) after the fifth stream was used")
-print(f"ratios vs (a): lent stream {c / a:.3f}, idle fifth stream {d / a2:.3f}, busy fifth stream {b / a2:.3f}, afterwards {b2 / a2:.3f}")
+e = run(torch.cuda.current_stream(), "(e) + next-batch upload on the main stream, in front of the step")
+print(f"main-stream upload {e / a2:.3f}")
+print(f"ratios vs (a): chain stream {c / a:.3f}, idle fifth stream {d / a2:.3f}, busy fifth stream {b / a2:.3f}, afterwards {b2 / a2:.3f}")

@@ -19,420 +19,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#define RADET_SPLIT_COUNTERS 16384     // arrival tickets at the head of the split workspace
-#ifndef RADET_P3_DBG
-#define RADET_P3_DBG 0                 // 1: ConvArgs::dbg ablation switches of the plane-operand loop are live (experiments)
-#endif
-
-struct ConvPtrs {
-    const float* x;       // input rows [*, Cin]
-    const float* w;       // [Cout][KH*KW][Cin]
-    const float* bias;    // [Cout] or null
-    const float* addend;  // [M][Cout] or null (added before relu / mask)
-    const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
-    float* y;             // [M][Cout]
-};
-
-struct ConvArgs {
-    ConvPtrs p[2];        // 1 or 2 independent problems of identical geometry in one launch (cls / reg tower)
-    int groups;
-    const int* rowtab;    // [KH*KW][Mp] input row of (output row, tap) or -1 (built once per geometry)
-    float* partial;       // split-K / tail split: tile-local partial tiles [split tile][z][BM][BN]
-    int* counters;        // arrival tickets, one per split tile (zero before the launch, left zero by it)
-    const int* out_rows;  // optional [M]: output row of GEMM row m (parity-class dgrad of strided convs)
-    int tap_ids[16];      // weight tap index of table tap t (identity unless a tap subset is used)
-    int KTw;              // taps in the weight tensor (row stride of w is KTw*Cin)
-    int M, Mp, Cin, Cout, KH, KW;
-    int relu;
-    int sk, it_per_split; // K-stage range of block z = blockIdx.y: [z*it_per_split, min(nK, (z+1)*it_per_split))
-    // tail split: tiles [0, n_full) run whole; the T % 256 left-over tiles (which would otherwise occupy a mostly
-    // empty last round on the 256 CUs) are cut sk_tail ways along K, their partial tiles reduced by a second pass
-    int n_full, sk_tail, it_per_tail;
-    // io = 0: fp32 tensors.  io = 1 / 2 (bf16 storage): x, w, addend, mask are bf16 and Cin counts PAIRS of channels
-    // (a 4-byte unit, so the loaders and LDS layouts are those of the fp32 kernel); y is bf16 (1) or fp32 (2)
-    int io;
-    // stream-K: sk_wgs persistent workgroups share the T * nK K-stages of the launch evenly (workgroup v owns stages
-    // [v * sk_base + min(v, sk_rem), ...) across tile boundaries); tiles cut by a boundary are reduced in the launch
-    int sk_wgs, sk_base, sk_rem;
-    // class launch (all parity classes of a strided dgrad in one grid): GEMM rows [cls_b[c-1], cls_b[c]) belong to class
-    // c (boundaries are multiples of 128, pad rows have out_rows = -1), class c runs (cls_nt >> 4c) & 15 taps and its
-    // tap t reads weight tap tap_ids[4c + t]; rowtab is [max taps][Mp].  cls_nt = 0: one tap list for all rows.
-    int cls_nt, cls_b[3];
-    int dbg;              // experiments (RADET_DBG_IGEMM, plane-operand kernels): 1 no tile loads after the prologue, 2 no MFMAs,
-                          // 4 no fragment reads after the first
-};
-
-__device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
-    return io ? (float)reinterpret_cast<const __bf16*>(p)[o] : p[o];
-}
-__device__ __forceinline__ void st_out(float* p, size_t o, float v, int io) {
-    if (io == 1) reinterpret_cast<__bf16*>(p)[o] = (__bf16)v;      // v_cvt_pk_bf16_f32: round to nearest even
-    else p[o] = v;
-}
+#include "conv_common.h"
 
 __device__ __attribute__((aligned(16))) float radet_zero_page[512];
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
-    int l = 0;
-#pragma unroll
-    for (int i = 0; i < RADET_MAX_SEG - 1; ++i)
-        if (i < s.nseg - 1 && m >= s.s[i].row_end) l = i + 1;
-    return l;
-}
-
-struct PixCtx {  // decoded output pixel, ready for the per-tap gather
-    int by, bx;  // oy*so + off, ox*so + off
-    int Hi, Wi;  // Hi == 0 marks an out-of-range row
-    int base;    // input row of (n, 0, 0)
-};
-
-__device__ __forceinline__ PixCtx decode_pixel(const RadetSegs& segs, int m, int M, int so, int off) {
-    PixCtx p;
-    p.Hi = 0; p.Wi = 0; p.by = 0; p.bx = 0; p.base = 0;
-    if (m < M) {
-        const int l = find_seg(segs, m);
-        const RadetSeg& sg = segs.s[l];
-        const int local = m - sg.row_begin;
-        const int hw = sg.Ho * sg.Wo;
-        const int n = local / hw;
-        const int rem = local - n * hw;
-        const int oy = rem / sg.Wo;
-        const int ox = rem - oy * sg.Wo;
-        p.by = oy * so + off;
-        p.bx = ox * so + off;
-        p.Hi = sg.Hi;
-        p.Wi = sg.Wi;
-        p.base = sg.in_row_off + n * sg.Hi * sg.Wi;
-    }
-    return p;
-}
-
-// returns the input row index for (pixel, tap) or -1
-__device__ __forceinline__ int gather_row(const PixCtx& p, int r, int q, int sr, int div) {
-    int iy = p.by + r * sr, ix = p.bx + q * sr;
-    if (div > 1) {
-        if ((iy % div) != 0 || (ix % div) != 0) return -1;
-        iy /= div;
-        ix /= div;
-    }
-    if (iy < 0 || iy >= p.Hi || ix < 0 || ix >= p.Wi) return -1;
-    return p.base + iy * p.Wi + ix;
-}
-
-// Fused epilogue of one block tile: y = relu?(acc + bias (+ addend)) masked by mask > 0.  All loads of an accumulator
-// tile (output-row indirection, residual, ReLU mask) are issued back to back BEFORE anything waits for them: written as
-// one loop with per-element branches the compiler emitted load -> s_waitcnt vmcnt(0) -> branch -> load -> ... for every
-// one of the 16 accumulator registers, i.e. up to 48 fully serialised L2 / HBM round trips per tile (44 % of the wave
-// cycles of the K = 256 residual layers were spent parked there).  Out-of-range rows / columns read a clamped address
-// and are dropped at the store; the storage type IO (0 fp32, 1 bf16, 2 bf16 in / fp32 out) is a compile-time branch.
-template <int IO>
-__device__ __forceinline__ float ld_act_t(const float* p, size_t o) {
-    if constexpr (IO != 0) return (float)reinterpret_cast<const __bf16*>(p)[o];
-    else return p[o];
-}
-template <int IO>
-__device__ __forceinline__ void st_out_t(float* p, size_t o, float v) {
-    if constexpr (IO == 1) reinterpret_cast<__bf16*>(p)[o] = (__bf16)v;   // v_cvt_pk_bf16_f32: round to nearest even
-    else p[o] = v;
-}
-
-// Everything the code after the K loop needs from the argument struct, loaded before the loop and pinned in SGPRs:
-// left to the compiler these become s_loads (each behind its own wait) between the last barrier and the first store.
-struct EpiArgs {
-    int M, Cout, relu, io;
-    const int* out_rows;
-    float* partial;       // split-K / stream-K workspace (ConvArgs::partial, ::counters)
-    int* counters;
-    int sk_base, sk_rem;  // stream-K partition
-};
-template <class T>
-__device__ __forceinline__ T pin_sgpr(T v) {
-    asm volatile("" : "+s"(v));
-    return v;
-}
-
-template <int BM, int BN, int WM, int WN, int IO>
-__device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs& P,
-                                               f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int wm, int wn,
-                                               int li, int lh) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    const bool has_add = P.addend != nullptr, has_mask = P.mask != nullptr, has_rows = a.out_rows != nullptr;   // uniform
-    const bool interior = !has_rows && m0 + BM <= a.M && n0 + BN <= a.Cout;                                        // uniform
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        size_t obase[16];
-        bool rvalid[16];
-        if (has_rows) {
-            int orow[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                orow[r] = a.out_rows[row < a.M ? row : 0];
-                rvalid[r] = row < a.M && orow[r] >= 0;             // (-1: pad row between the classes of a class launch)
-                if (orow[r] < 0) orow[r] = 0;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) obase[r] = (size_t)orow[r] * a.Cout;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                rvalid[r] = row < a.M;
-                obase[r] = (size_t)(rvalid[r] ? row : 0) * a.Cout;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + li;
-            const bool cvalid = col < a.Cout;
-            const int cc = cvalid ? col : 0;
-            const float bv = P.bias ? P.bias[cc] : 0.f;
-            float av[16], mv[16];
-            if (has_add) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) av[r] = ld_act_t<IO>(P.addend, obase[r] + cc);
-            }
-            if (has_mask) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = ld_act_t<IO>(P.mask, obase[r] + cc);
-            }
-            float out[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {                      // straight-line arithmetic: one wait for the loads above
-                float v = acc[i][j][r] + bv;
-                if (has_add) v += av[r];
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (has_mask) v = mv[r] > 0.f ? v : 0.f;
-                out[r] = v;
-            }
-            // stores last, with nothing left in flight that they would have to wait for (on gfx9-class hardware a
-            // store behind a conservative vmcnt(0) also waits for the store before it); interior tiles store unguarded
-            if (interior) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (cvalid && rvalid[r]) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
-            }
-        }
-    }
-}
-
-// Split episodes (split-K over the whole grid, or the K-split left-over tiles of a tail split) are reduced INSIDE the
-// launch: every workgroup of a tile writes its raw partial tile (tile-local layout), publishes it with one agent-scope
-// release and draws an arrival ticket; the workgroup that draws the last ticket acquires, re-reads all partial tiles in
-// split order z = 0, 1, ... (so the sum does not depend on the arrival order: deterministic, and equal to what a
-// separate reduction pass would produce) and runs the fused epilogue.  This replaces 60-80 reduction launches per
-// train step that sat between dependent GEMMs on the critical chain.  `ws` is any LDS word all waves are done with.
-// partial tile = register image: [wave][i][j][lane][16 accumulator floats] -> every lane moves 64 contiguous bytes with
-// 16-byte accesses.  The stores are write-through (sc1), so publishing needs no L2 write-back.
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void partial_write(float* dst, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)]) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int off = ((((wave * TM + i) * TN + j) * 64 + lane) * 16) * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4_ v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off + 16 * q, 0, 16);   // aux 16 = sc1
-            }
-        }
-}
-
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void partial_add(const float* pz, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)]) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float4* src = reinterpret_cast<const float4*>(pz + (((wave * TM + i) * TN + j) * 64 + lane) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = src[q];
-                acc[i][j][4 * q] += v.x; acc[i][j][4 * q + 1] += v.y; acc[i][j][4 * q + 2] += v.z; acc[i][j][4 * q + 3] += v.w;
-            }
-        }
-}
-
-template <class A>
-__device__ __forceinline__ int streamk_start(const A& a, int v) { return v * a.sk_base + (v < a.sk_rem ? v : a.sk_rem); }
-template <class A>
-__device__ __forceinline__ int streamk_owner(const A& a, int it) {       // workgroup that owns K-stage `it`
-    const int big = (a.sk_base + 1) * a.sk_rem;
-    return it < big ? it / (a.sk_base + 1) : a.sk_rem + (it - big) / a.sk_base;
-}
-
-// Stream-K: a workgroup's K-stage range [cur, cur + nseg) inside tile `tile` does not cover the tile.  Every contributor
-// writes its partial tile to its own slot (workgroup v has at most two cut tiles: the one its range starts in -> slot 0,
-// the one it ends in -> slot 1) and adds its stage count to the tile's counter; the contributor that completes the
-// count (nKs) re-reads ALL partials in K order (ascending workgroup), so the sum is independent of the arrival order.
-// Returns true in the workgroup that has to run the epilogue (acc = the reduced tile).
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ bool streamk_publish(const EpiArgs& a, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)],
-                                                int tile, int nseg, int nKs, int v, int slot, volatile int* ws) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    partial_write<BM, BN, WM, WN>(a.partial + (size_t)(2 * v + slot) * BM * BN, acc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        ws[0] = __hip_atomic_fetch_add(&a.counters[tile], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const bool last = ws[0] + nseg == nKs;
-    __syncthreads();                                           // ws is LDS tile memory: the next segment's loads may reuse it
-    if (!last) return false;
-    // every wave acquires for itself (agent scope: invalidates this CU's L1 before the partial tiles of other
-    // workgroups, published with write-through stores + a drained vmcnt + the ticket, are read with plain loads)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (threadIdx.x == 0)
-        __hip_atomic_store(&a.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int t0 = tile * nKs;
-    const int v0 = streamk_owner(a, t0), v1 = streamk_owner(a, t0 + nKs - 1);
-    for (int u = v0; u <= v1; ++u) {
-        const int sl = streamk_start(a, u) >= t0 ? 0 : 1;      // starts inside this tile -> its first cut tile
-        partial_add<BM, BN, WM, WN>(a.partial + (size_t)(2 * u + sl) * BM * BN, acc);
-    }
-    return true;
-}
-
-template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void igemm_store(const EpiArgs& e, const ConvPtrs& P,
-                                            f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], int m0, int n0, int nsplit,
-                                            int ctile, int z, int wm, int wn, int li, int lh, volatile int* ws) {
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    // epilogue: D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    if (nsplit > 1) {
-        // (a release fence here instead of write-through stores flushes every dirty line of the XCD's L2, i.e. the
-        // outputs of all concurrently running kernels: measured slower than the separate reduction launches it replaced)
-        float* base = e.partial + (size_t)ctile * nsplit * BM * BN;
-        partial_write<BM, BN, WM, WN>(base + (size_t)z * BM * BN, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0)
-            ws[0] = __hip_atomic_fetch_add(&e.counters[ctile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (ws[0] != nsplit - 1) return;                       // uniform: not the last arriver of this tile
-        // every wave acquires for itself (see streamk_publish)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&e.counters[ctile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int zz = 0; zz < nsplit; ++zz) partial_add<BM, BN, WM, WN>(base + (size_t)zz * BM * BN, acc);
-    }
-    if (e.io == 0) igemm_epilogue<BM, BN, WM, WN, 0>(e, P, acc, m0, n0, wm, wn, li, lh);
-    else if (e.io == 1) igemm_epilogue<BM, BN, WM, WN, 1>(e, P, acc, m0, n0, wm, wn, li, lh);
-    else igemm_epilogue<BM, BN, WM, WN, 2>(e, P, acc, m0, n0, wm, wn, li, lh);
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void lds_read128(f32x4& d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-// bf16 math mode: operands are rounded (RNE) to bf16 on the way from LDS to the matrix core, accumulation stays
-// fp32 (v_mfma_f32_32x32x8_bf16_1k: lane (i, h) holds k = 4h..4h+3 -- the same 4 consecutive k a ds_read_b128 of an
-// fp32 tile row delivers, so the fp32 LDS layouts are used unchanged); activations / weights stay fp32 in HBM
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {    // one v_cvt_pk_bf16_f32 (RNE)
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ s16x4 cvt_bf16x4(float a, float b, float c, float d) {
-    const u32x2 r = {cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)};
-    return __builtin_bit_cast(s16x4, r);
-}
-
-template <int OFF>
-__device__ __forceinline__ void lds_read32(float& d, unsigned addr) {
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-typedef short s16x4v_ __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ void lds_read_tr16(s16x4v_& d, unsigned addr) {   // gfx950 transposing LDS read (see conv_wgradh)
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_wait() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// fp32 operand -> three bf16 planes, exact: x = hi + mid + lo where hi / mid / lo are the top 8 / next 8 / last 8 bits of
-// the significand (truncation; each residual x - hi is exact in fp32).  Two 4-float fragments (8 k values of one lane)
-// become three bf16x8 MFMA operands; v_perm_b32 packs the high halves of two dwords.
-typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split3_bf16(const float (&a)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    u32x4_ h, m, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {            // pairs: the two residual subtractions are one v_pk_add_f32 each
-        const f32x2_ a2 = {a[2 * q], a[2 * q + 1]};
-        const unsigned ua0 = __float_as_uint(a2.x), ua1 = __float_as_uint(a2.y);
-        const f32x2_ h2 = {__uint_as_float(ua0 & 0xFFFF0000u), __uint_as_float(ua1 & 0xFFFF0000u)};
-        const f32x2_ r2 = a2 - h2;
-        const unsigned ur0 = __float_as_uint(r2.x), ur1 = __float_as_uint(r2.y);
-        const f32x2_ m2 = {__uint_as_float(ur0 & 0xFFFF0000u), __uint_as_float(ur1 & 0xFFFF0000u)};
-        const f32x2_ l2 = r2 - m2;
-        h[q] = __builtin_amdgcn_perm(ua1, ua0, 0x07060302u);
-        m[q] = __builtin_amdgcn_perm(ur1, ur0, 0x07060302u);
-        l[q] = __builtin_amdgcn_perm(__float_as_uint(l2.y), __float_as_uint(l2.x), 0x07060302u);
-    }
-    hi = __builtin_bit_cast(bf16x8, h);
-    mid = __builtin_bit_cast(bf16x8, m);
-    lo = __builtin_bit_cast(bf16x8, l);
-}
-__device__ __forceinline__ void split3_bf16(const f32x4& f0, const f32x4& f1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-    const float a[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
-    split3_bf16(a, hi, mid, lo);
-}
-// acc += A x B with fp32-accurate products from the planes of A and B (6 of the 9 plane products).  Order: the planes
-// that are ready first -- hi x hi needs one v_perm per pair, the mid / lo planes two / four more operations -- so that the
-// rest of the split runs in the shadow of the first MFMAs (the accumulator is fp32: the order of these six terms moves
-// the result by less than its last bit).
-__device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf16x8& am, const bf16x8& al,
-                                        const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-}
 
 // Implicit-GEMM kernel: the A (gathered pixels) and B (weights) tiles go global -> LDS with
 // global_load_lds_dwordx4, no staging registers and no ds_write pass.  A wave load writes 1 KiB lane-linearly, so
@@ -2419,6 +2008,10 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.sk_wgs > 0 ? a.sk_wgs : a.n_full + (T - a.n_full) * a.sk_tail;
+    if (tag & 64) {                       // split-at-fill tile (planes formed once per workgroup on the way into LDS)
+        if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2) radet_launch_igemm_sf(a, tiles, tag & 1, st);
+        return;
+    }
     if (tag & 16) {
         launch_p3<BM, BN, WM, WN>(a, st, tag, bk, stages, tiles);
         return;
@@ -2470,7 +2063,7 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
 }
 
 static long igemm_tiles(int M, int N, int choice) {
-    const int bm = (choice == 3 || choice >= 7) ? 64 : (choice == 6 ? 256 : 128);
+    const int bm = (choice == 3 || choice == 7 || choice == 8) ? 64 : (choice == 6 ? 256 : 128);
     const int bn = (choice == 1 || choice == 5 || choice == 6) ? 128 : (choice == 4 ? 32 : 64);
     return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
@@ -2618,6 +2211,9 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         const int kbk = choice == 7 ? 64 : 32;
         if (!x3 || Cin % kbk != 0 || ((tile_override >> 20) & 7)) return RADET_ERR_ARG;
         tag |= 32; bk = kbk;
+    } else if (choice == 9) {                                  // 128 x 128 split-at-fill tile (conv_igemm_sf_kernel)
+        if (!x3 || Cin % 32 != 0 || ((tile_override >> 20) & 7) || second != nullptr) return RADET_ERR_ARG;
+        tag = (tag & 1) | 64; bk = 32;
     } else
     if (choice > 4 && !p3) return RADET_ERR_ARG;               // the 8-wave tiles exist for plane operands only
     if (choice == 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
@@ -2670,6 +2266,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         case 5: launch_igemm<128, 128, 2, 4, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         case 6: launch_igemm<256, 128, 4, 2, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         case 7: case 8: launch_igemm<64, 64, 2, 2, true>(a, st, tag, bk, splitk_ws_floats, 2, skw); break;   // K-divided
+        case 9: launch_igemm<128, 128, 2, 2, true>(a, st, tag, bk, splitk_ws_floats, 2, skw); break;         // split-at-fill
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();

@@ -113,14 +113,6 @@ int radet_conv2d_igemm_classes(const float* x, const float* w, const float* adde
  * Arithmetic: fp32 products from three bf16 planes per operand (as tile_override 0x1000000).  Cin % 16 == 0. */
 int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntiles, const float* w0, const float* bias0,
                         float* y0, int c0, const float* w1, const float* bias1, float* y1, int c1, void* stream);
-/* 3x3 / stride 1 / pad 1 convolution of PLANE operands from an LDS patch -- the convs of the head towers
- * (radet/models/dense_heads/atss_head.py:118-145: cls_convs / reg_convs, applied per level) and, with flip = 1 and the
- * transposed weight planes, their dgrad.  x: plane rows [rows][3 Cin] over all pyramid levels, w: plane rows
- * [(n * 9 + tap)][3 Cin] (RadetConvDesc.w16 = 2), y / addend fp32 [rows][Cout], bias [Cout] or null.  blocks_dev: nblocks x
- * {base_row, H, W, (y0 << 16) | x0} (int32): 4 x 8 blocks of output pixels covering every (level, image).  Every input row is
- * staged 1.9 times instead of 9 x Cout / 128 times (implicit GEMM).  Cin % 64 == 0. */
-int radet_conv3x3_patch_p(const void* x, const void* w, const float* bias, const float* addend, float* y,
-                          const int* blocks_dev, int nblocks, int Cin, int Cout, int flip, void* stream);
 /* wgrad: slabs[s][o][tap][c] = sum over pixel split s of dy[m,o] * x[table[tap][m],c];
  * optional dbias_partials[s][o] = column sums of dy.  S from radet_conv2d_wgrad_splits.
  * flags bit 0: bf16 math mode (as tile_override 0x400 of radet_conv2d_igemm); bit 8 (0x100): fp32 products from three bf16

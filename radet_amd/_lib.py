@@ -40,7 +40,6 @@ SIGNATURES = {
     "radet_conv2d_igemm_taps": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "radet_conv2d_igemm_classes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "radet_pred3x3_patch": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
-    "radet_conv3x3_patch_p": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "radet_conv2d_wgrad_group": (_i, [_p, _i, _i, _p]),

@@ -1,4 +1,5 @@
-// Pieces shared by the implicit-GEMM translation units (conv_igemm.hip, conv_sf.hip): launch arguments, the fused epilogue,
+// Pieces shared by the implicit-GEMM kernels (conv_igemm.hip; kept apart so that experimental tiles can be built as their own
+// translation units against the same epilogue / split-K code): launch arguments, the fused epilogue,
 // the in-launch split-K reduction, the exact fp32 -> three-bf16-planes split.  gfx950 only.
 #pragma once
 #include "common.h"
@@ -420,6 +421,3 @@ __device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf1
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 }
 
-
-// conv_sf.hip: 128 x 128 split-at-fill tile; `a` as prepared by launch_igemm (split-K / tail-split fields set)
-void radet_launch_igemm_sf(const ConvArgs& a, int tiles, int tagged, hipStream_t st);

@@ -2008,10 +2008,6 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
         }
     }
     const int tiles = a.sk_wgs > 0 ? a.sk_wgs : a.n_full + (T - a.n_full) * a.sk_tail;
-    if (tag & 64) {                       // split-at-fill tile (planes formed once per workgroup on the way into LDS)
-        if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2) radet_launch_igemm_sf(a, tiles, tag & 1, st);
-        return;
-    }
     if (tag & 16) {
         launch_p3<BM, BN, WM, WN>(a, st, tag, bk, stages, tiles);
         return;
@@ -2211,9 +2207,6 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         const int kbk = choice == 7 ? 64 : 32;
         if (!x3 || Cin % kbk != 0 || ((tile_override >> 20) & 7)) return RADET_ERR_ARG;
         tag |= 32; bk = kbk;
-    } else if (choice == 9) {                                  // 128 x 128 split-at-fill tile (conv_igemm_sf_kernel)
-        if (!x3 || Cin % 32 != 0 || ((tile_override >> 20) & 7) || second != nullptr) return RADET_ERR_ARG;
-        tag = (tag & 1) | 64; bk = 32;
     } else
     if (choice > 4 && !p3) return RADET_ERR_ARG;               // the 8-wave tiles exist for plane operands only
     if (choice == 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
@@ -2266,7 +2259,6 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         case 5: launch_igemm<128, 128, 2, 4, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         case 6: launch_igemm<256, 128, 4, 2, true>(a, st, tag, bk, splitk_ws_floats, stages3, skw); break;   // 8 waves
         case 7: case 8: launch_igemm<64, 64, 2, 2, true>(a, st, tag, bk, splitk_ws_floats, 2, skw); break;   // K-divided
-        case 9: launch_igemm<128, 128, 2, 2, true>(a, st, tag, bk, splitk_ws_floats, 2, skw); break;         // split-at-fill
         default: return RADET_ERR_ARG;
     }
     return radet_check_launch();

@@ -732,18 +732,13 @@ class Engine:
         return y
 
     tower_fwd_streams = os.environ.get("RADET_TOWER_FWD_STREAMS", "1") != "0"
-    # plane-operand tower convs (forward and dgrad) from an LDS patch (csrc/conv_patch.hip) instead of the implicit GEMM
-    tower_patch = os.environ.get("RADET_TOWER_PATCH", "0") == "1"
 
     def _tower_fwd_layer_p(self, t, tower, i, x, ws):
         """one tower layer with plane operands on the current stream: GEMM (256 x 128 tiles, no split-K) + GroupNorm + ReLU"""
         b, p = self.buf, self.p
         c = tower[i]
         z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
-        if self.tower_patch:
-            K.conv3x3_patch(self.plv, x, c.wf, None, z, c.cin, c.cout)
-        else:
-            self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12))
+        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12))
         gn = f"bbox_head.{t}_convs.{i}.gn"
         pl = K._isp(y)                  # the last layer's output feeds the predictor convs: fp32
         K.gn_relu_fwd_p(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], None if pl else y, y if pl else None,
@@ -959,10 +954,7 @@ class Engine:
                 x = b[f"{t}.y{i - 1}"] if i > 0 else b["Pp"]
                 wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 if i > 0:
-                    if self.tower_patch:
-                        K.conv3x3_patch(self.plv, b[f"{t}.dz{i & 1}"], tower[i].wft, None, b[f"{t}.dy"], tower[i].cout, tower[i].cin, flip=True)
-                    else:
-                        K.conv_dgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], tower[i].wft, b[f"{t}.dy"], tile=6 | (1 << 12))
+                    K.conv_dgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], tower[i].wft, b[f"{t}.dy"], tile=6 | (1 << 12))
             self._tower_bwd_head_async("cls")
             self._fork(cs)
             with torch.cuda.stream(cs):
@@ -972,17 +964,10 @@ class Engine:
                 with torch.cuda.stream(cs):
                     layer("reg", self.reg_tower, self.gn_ws2, i)
             # both first layers write dL/dP: cls on this stream, then reg accumulates onto it on the chain stream
-            c0, r0 = self.cls_tower[0], self.reg_tower[0]
-            if self.tower_patch:
-                K.conv3x3_patch(self.plv, b["cls.dz0"], c0.wft, None, dP, c0.cout, c0.cin, flip=True)
-            else:
-                K.conv_dgrad(c0.geom, b["cls.dz0"], c0.wft, dP, tile=6 | (1 << 12))
+            K.conv_dgrad(self.cls_tower[0].geom, b["cls.dz0"], self.cls_tower[0].wft, dP, tile=6 | (1 << 12))
             self._fork(cs)
             with torch.cuda.stream(cs):
-                if self.tower_patch:
-                    K.conv3x3_patch(self.plv, b["reg.dz0"], r0.wft, None, dP, r0.cout, r0.cin, addend=dP, flip=True)
-                else:
-                    K.conv_dgrad(r0.geom, b["reg.dz0"], r0.wft, dP, addend=dP, tile=6 | (1 << 12))
+                K.conv_dgrad(self.reg_tower[0].geom, b["reg.dz0"], self.reg_tower[0].wft, dP, addend=dP, tile=6 | (1 << 12))
             self._join(cs)
         elif self.tower_mode in ("pair", "pairbwd"):
             p, g = self.p, self.g

@@ -552,34 +552,6 @@ def pred_conv_patch(lv, x, a, b=None):
                              _ptr(w1), _ptr(b1), _ptr(y1), c1, _stream()))
 
 
-def _patch_blocks(lv):
-    """4 x 8 output-pixel blocks of every (level, image) of the pyramid `lv` for radet_conv3x3_patch_p (built once per
-    Levels); a workgroup takes four consecutive blocks: ordered so that the four share a (level, image) and are neighbours"""
-    import numpy as np
-    t = getattr(lv, "_patch_blocks", None)
-    if t is None:
-        rows = []
-        for (h, w), off in zip(lv.hw, lv.offsets):
-            for n in range(lv.B):
-                for by in range(-(-h // 4)):
-                    for bx in range(-(-w // 8)):
-                        rows.append((off + n * h * w, h, w, ((4 * by) << 16) | (8 * bx)))
-        t = torch.from_numpy(np.asarray(rows, np.int32)).cuda()
-        if not torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream().synchronize()
-        lv._patch_blocks = t
-    return t
-
-
-def conv3x3_patch(lv, x, w, bias, y, cin, cout, addend=None, flip=False):
-    """3x3 / 1 / pad 1 conv of plane operands from an LDS patch (head towers): x Planes [rows, cin], w Planes [(n, tap), cin]"""
-    t = _patch_blocks(lv)
-    _timed("conv3x3_patch_kernel", 2.0 * lv.rows * cout * cin * 9,
-           lambda: _lib.call("radet_conv3x3_patch_p", _ptr(x.t), _ptr(w.t), _ptr(bias), _ptr(addend), _ptr(y), _ptr(t), t.shape[0],
-                             cin, cout, int(flip), _stream()), 6.0 * lv.rows * cin + 6.0 * cout * 9 * cin + 4.0 * lv.rows * cout,
-           kind="dgrad" if flip else "fwd")
-
-
 _WTUNE_CACHE = _LRU(8192)
 
 

@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 # host-only enqueue time: no sync between calls except detect's own result fetch
 print(f"eager  B={B}: {dt * 1e3:.2f} ms per call ({B / dt:.0f} images/s)")
-if hasattr(rt, "detect_graph"):
+if hasattr(rt, "detect_graph") and os.environ.get("LAT_NO_GRAPH") != "1":
     for _ in range(3):
         out2 = rt.detect_graph(imgs, metas, det.test_cfg, rescale=True)
     torch.cuda.synchronize()

@@ -45,7 +45,14 @@ TOW_K=$(echo "$TOW" | head -1); TOW_B=$(echo "$TOW" | tail -1)
 python3 $R/tools/pmc_traffic.py /tmp/pmc_fp32_FETCH_SIZE /tmp/pmc_fp32_WRITE_SIZE "$TOW_K" \
     $OUT/pmc_hbm_traffic_tower.txt $OUT/roofline_traffic_tower.json $TOW_B > /dev/null 2>> $OUT/bench_default.err
 # 4. inference (config 4) kernel stats, R101 (config 5) log, fill-path micro-benchmark
-db=$(prof infer $R/tools/bench_configs.py infer)
+db=$(prof infer $R/tools/bench_configs.py infer --images 400)
+python3 $R/tools/trace_timeline.py --infer $db 7 $OUT/infer_timeline.txt > /dev/null
+python3 $R/tools/bench_configs.py infer > $OUT/infer.log 2>&1
+python3 $R/tools/bench_latency.py > $OUT/latency_b1.log 2>&1
+export LAT_NO_GRAPH=1
+db=$(prof latency $R/tools/bench_latency.py)
+unset LAT_NO_GRAPH
+python3 $R/tools/trace_timeline.py --infer $db 21 $OUT/latency_b1_timeline.txt > /dev/null
 python3 $R/tools/bench_configs.py r101 > $OUT/r101.log 2>&1
 [ -x $R/tools/_probe/fill_probe ] && $R/tools/_probe/fill_probe > $OUT/fill_probe.txt 2>&1
 ls -la $OUT

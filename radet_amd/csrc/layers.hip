@@ -360,7 +360,7 @@ extern "C" int radet_stem_wgrad(const float* img_nchw, const float* ds, float* s
 //   wf[o][t][c] = s[o] * w[o][c][t] ; wft[c][t][o] = same value ; bias_f[o] = beta - mean*s | conv bias | 0
 // One work item = (o-tile of 16, c-tile of 32): the OIHW slab [16][32*KT] is read with contiguous runs,
 // transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
-#define FOLD_TO 16
+#define FOLD_TO 32
 #define FOLD_TC 32
 // folded weight store: element `col` of row `row` (row length ld): fp32, bf16 (w16 = 1) or bf16 plane triple (w16 = 2:
 // rows of ld / 32 groups [hi | mid | lo] x 32 channels, see common.h; ld % 32 == 0)

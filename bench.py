@@ -47,10 +47,18 @@ class ClockSampler:
 
     def _run(self):
         import re
+        import shutil
         import subprocess
+        # rocm-smi is a `#!/usr/bin/env python3` script: started through the interpreter directly (one exec in the child, no
+        # `env` hop), and not at all under rocprofv3 -- its preloaded library initialises the GPU in every process it is
+        # inherited by, and a process that has done so must not exec again on this pool
+        smi = shutil.which("rocm-smi")
+        if smi is None or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            return
+        cmd = [sys.executable, os.path.realpath(smi), "--showclocks", "--showpower"]
         while not self._stop.is_set():
             try:
-                txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                txt = subprocess.run(cmd, capture_output=True, text=True, timeout=5).stdout
             except Exception:
                 return
             m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
@@ -69,12 +77,12 @@ class ClockSampler:
     def report(self, t0, t1, what):
         rows = [r for r in self.rows if t0 <= r[0] <= t1]
         if not rows:
-            return {"samples": 0, "note": "rocm-smi returned no sample inside the region"}
+            return {"samples": 0, "note": "no rocm-smi sample inside the region (not polled under rocprofv3)"}
         clk, pw = sorted(r[1] for r in rows), sorted(r[2] for r in rows)
         return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
                 "socket_power_w_median": pw[len(pw) // 2], "socket_power_w_max": pw[-1], "samples": len(rows),
-                "note": f"rocm-smi --showclocks --showpower polled from a thread during {what}; peak sclk 2400 MHz, socket power "
-                        "cap 1400 W (MI355X_MICROARCH.md): the default arithmetic runs at the power limit"}
+                "note": f"rocm-smi --showclocks --showpower polled from a thread during {what} (the interface lags by ~0.2 s: the "
+                        "`sustained` window is the steady state); peak sclk 2400 MHz"}
 
 
 def synth_objects(rng, G, H=IMG_H, W=IMG_W):
@@ -401,13 +409,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_distributed.py): RADET_BENCH_SHARE_GPU=1 lets the ranks of a 1-GPU box share device 0 and
+    # RADET_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so that the N > 1 code path of this
+    # script runs before the driver's 8-GPU run does
+    share = os.environ.get("RADET_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("RADET_BENCH_BACKEND", "nccl")
+    if share:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("RADET_FORCE_REDUCER") == "1":   # the latter: 1-rank RCCL run of the bucketed exchange
         os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")      # per-collective durations for the `comm` report
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from radet_amd.models import build_detector
@@ -482,11 +500,12 @@ def main():
         t_keep1 = time.perf_counter()
         sampler.__exit__()
     assert np.isfinite(losses).all(), f"non-finite losses {losses}"
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    cdev = device if (not dist.is_initialized() or dist.get_backend() == "nccl") else torch.device("cpu")   # (gloo: host tensors)
+    t = torch.tensor([dt], device=cdev, dtype=torch.float64)
     rank_ms = None
     if world > 1:
-        per_rank = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([dt_rank, t_enq], device=device, dtype=torch.float64))
+        per_rank = [torch.zeros(2, device=cdev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([dt_rank, t_enq], device=cdev, dtype=torch.float64))
         rank_ms = [[round(float(v[0]) / args.steps * 1e3, 3), round(float(v[1]) / args.steps * 1e3, 3)] for v in per_rank]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

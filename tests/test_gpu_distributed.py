@@ -91,3 +91,30 @@ def test_two_ranks_one_gpu_train_step(tmp_path):
         rt.optimizer_step(lr=1e-4, grad_div=2.0)
     torch.cuda.synchronize()
     assert torch.equal(rt.flat.params.cpu(), r0["params"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_script_two_ranks_on_one_gpu():
+    """bench.py's own N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank),
+    with the two ranks sharing cuda:0 over gloo (test hooks RADET_BENCH_SHARE_GPU / RADET_BENCH_BACKEND): the barrier +
+    synchronize bracketing, the MAX over ranks, the per-rank step times, the traced bucket exchange (`comm`) and the one JSON
+    line on rank 0 -- the code the 8-GPU RCCL run executes, minus RCCL itself."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RADET_BENCH_SHARE_GPU="1", RADET_BENCH_BACKEND="gloo", GPU_MAX_HW_QUEUES="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=REPO)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-400:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]           # whole-job images / s
+    rk = d["ranks"]
+    assert len(rk["per_rank_ms_per_step"]) == 2 and rk["ms_per_step_min"] <= rk["ms_per_step_max"] <= d["ms_per_step"] * 1.001
+    assert all(np.isfinite(d["config"]["losses"])) and "cpu_baseline" not in d and "roofline" not in d
+    names = [b["bucket"] for b in d["comm"]["buckets"]]
+    assert names == ["bbox_head.", "neck.", "backbone.layer4.2.", "backbone.layer4.1.", "backbone.layer4.0.", "backbone.layer3.",
+                     "backbone.layer2."]

@@ -359,9 +359,7 @@ def extras(args):
             "clock_power": d.get("clock_power"),
             "note": "same step, `python bench.py --math bf16-storage` (BASELINE configs[2] arithmetic on ONE GPU: bf16 activations / "
                     "folded weights / activation gradients in HBM, v_mfma_f32_32x32x16_bf16 with f32 accumulation, f32 loss / "
-                    "GroupNorm statistics / master weights / AdamW); one issued bf16 MAC per algorithmic MAC.  In this mode the "
-                    "device needs ~4.9 ms per step and the Python loop ~5.3 ms to enqueue it (host_enqueue_ms_per_step): the step is "
-                    "HOST-bound on one GPU (0.7 ms of idle gaps in the kernel trace), unlike the fp32 headline"}
+                    "GroupNorm statistics / master weights / AdamW); one issued bf16 MAC per algorithmic MAC"}
     except Exception as e:
         out["bf16_storage"] = {"error": repr(e)[:200]}
     try:                                         # the reference's own operating point: samples_per_gpu = 16

@@ -143,8 +143,13 @@ def check(rc, name):
         raise RadetHipError(f"{name} failed with code {rc} (-1 bad argument, -2 launch failure)")
 
 
+_FN = {}
+
+
 def call(name, *args):
-    fn = getattr(load(), name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
     rc = fn(*args)
     if rc != 0:
         raise RadetHipError(f"{name} failed with code {rc} (-1 bad argument, -2 launch failure)")

@@ -4,10 +4,9 @@ reference's visibility-guided positive-sample assigner.
 Follows radet/datasets/pipelines/label_assignment.py:
   * candidate test            :57-76   (generate_candidate_cell)
   * mask lookup at the centre :78-86   (cal_sample_pro)
-  * per-gt sampling           :97-131  (random_sample, balance_sample=True,
-                                        random_sample_by_distance=True,
-                                        adapt_positive_num=False,
-                                        multiply_samplepro_for_weight=False)
+  * per-gt sampling           :88-131  (adapt_cal_k, random_sample: balance_sample,
+                                        multiply_samplepro_for_weight and adapt_positive_num
+                                        on or off; random_sample_by_distance=True only)
   * ascending-area visit, 'min_area' ambiguity rule, scatter  :136-201 (__call__)
 Anchor centres follow core/anchor/anchor_generator.py:206-271 with center_offset=0:
 one square anchor per cell centred at (j*stride, i*stride), levels concatenated,
@@ -77,7 +76,8 @@ def legacy_choice(p32, size, replace, uniforms):
 
 
 def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFAULT_STRIDES,
-                  regress_ranges=DEFAULT_RANGES, positive_num=10, neg_threshold=0.2):
+                  regress_ranges=DEFAULT_RANGES, positive_num=10, neg_threshold=0.2, balance_sample=True,
+                  multiply_samplepro_for_weight=False, adapt_positive_num=False):
     """Returns (points_to_gt_index int64[N], points_weight float32[N]).
 
     gt_bboxes f32[G,4], gt_labels i64[G] (unused by the arithmetic), masks [G,H,W] (0/1),
@@ -87,7 +87,7 @@ def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFA
     img_h, img_w = int(img_shape[0]), int(img_shape[1])
     gt_bboxes = np.asarray(gt_bboxes, np.float32).reshape(-1, 4)
     G = gt_bboxes.shape[0]
-    cx, cy, _, lvl = point_grid(img_h, img_w, strides)
+    cx, cy, anchor_size, lvl = point_grid(img_h, img_w, strides)
     N = cx.shape[0]
     p2g = np.full(N, -1, np.int64)
     wts = np.ones(N, np.float32)
@@ -116,12 +116,24 @@ def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFA
         nn_p = p[keep]
         n = nn_idx.shape[0]
         sample_p = nn_p / np.sum(nn_p)
-        chosen = rng.choice(a=n, size=positive_num, p=sample_p, replace=bool(n < positive_num))
+        k = positive_num
+        if adapt_positive_num:                 # adapt_cal_k (:88-95): sizes of ALL candidate cells, object size = max(w, h)
+            sz, cnt_l = np.unique(anchor_size[idx], return_counts=True)
+            obj = max(gt_bboxes[g, 2] - gt_bboxes[g, 0], gt_bboxes[g, 3] - gt_bboxes[g, 1])
+            dk = ((cnt_l / idx.shape[0]) * np.exp((obj - sz) / (2 * sz))).sum()
+            k = int(positive_num * dk + 0.5)
+        if n < k and not balance_sample:       # (:112-113) all of them, no draw
+            chosen = np.arange(0, n)
+        else:
+            chosen = rng.choice(a=n, size=k, p=sample_p, replace=bool(n < k))
         uniq, cnt = np.unique(chosen, return_counts=True)
+        weight = cnt.astype(np.float32)
+        if multiply_samplepro_for_weight:      # (:127-128) the clipped map value, not the normalised probability
+            weight *= nn_p[uniq]
         p2g[nn_idx] = 0
         wts[nn_idx] = 0.0
         p2g[nn_idx[uniq]] = g + 1
-        wts[nn_idx[uniq]] = cnt.astype(np.float32)
+        wts[nn_idx[uniq]] = weight
     return p2g, wts
 
 

@@ -113,3 +113,13 @@ def fill_state_dict(sd, seed=0):
         else:
             raise KeyError(f"unclassified tensor {name} {tuple(t.shape)}")
     return sd
+
+
+def graded_maps(masks):
+    """float32 [G, H, W] sampling maps with values in {0} u [0.25, 1]: the visible masks times a fixed spatial pattern -- inputs
+    of the assigner tests that need NON-binary map values (multiply_samplepro_for_weight; the mask-free sampler's maps)."""
+    m = np.asarray(masks)
+    H, W = m.shape[-2:]
+    yy, xx = np.mgrid[0:H, 0:W]
+    pat = (0.25 + 0.75 * (((xx * 7 + yy * 13) % 32) / 31.0)).astype(np.float32)
+    return (m.astype(np.float32) * pat[None]).astype(np.float32)

@@ -69,8 +69,8 @@ SIGNATURES = {
     "radet_nms_ws_bytes": (_sz, [_i, _i]),
     "radet_nms": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "radet_assign_ws_bytes": (_sz, [_i, _i]),
-    "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
-    "radet_assign_points_f": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_assign_points": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
+    "radet_assign_points_f": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "radet_resize_linear_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "radet_resize_linear_f": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "radet_gaussian_blur9_u8": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),

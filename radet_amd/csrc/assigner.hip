@@ -103,7 +103,7 @@ template <class MT>
 __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ gt_boxes, const int* __restrict__ gt_off,
                                                      const MT* __restrict__ masks, int H, int W,
                                                      const double* __restrict__ uniforms, int U, const AsgLevels L,
-                                                     int K, float neg_thr, int64_t* __restrict__ p2g_all,
+                                                     int K0, int flags, float neg_thr, int64_t* __restrict__ p2g_all,
                                                      float* __restrict__ pw_all, int* __restrict__ used_out,
                                                      char* __restrict__ ws_all, size_t ws_per_image) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
     __shared__ int s_i[8];
     __shared__ float s_f[4];
     __shared__ int chosen[ASG_MAXK], found[ASG_MAXK], uniq_idx[ASG_MAXK], uniq_cnt[ASG_MAXK];
+    __shared__ int s_lvl[RADET_MAX_SEG];        // candidates per level (adapt_positive_num)
+    // flags (label_assignment.py:30-46, 88-131): bit 0 balance_sample (fewer non-negative candidates than positive_num: draw
+    // positive_num with replacement; off: take them all once), bit 1 multiply_samplepro_for_weight (weight = count x the
+    // candidate's clipped map value), bit 2 adapt_positive_num (positive_num per gt from the candidates' anchor sizes)
+    const bool balance = (flags & 1) != 0, mulpro = (flags & 2) != 0, adapt = (flags & 4) != 0;
     __shared__ double xs[ASG_MAXK];
 
     for (int p = tid; p < N; p += 256) { p2g[p] = -1; pw[p] = 1.f; }
@@ -156,6 +161,10 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         // ---- candidates, ordered
         int nc = 0;
         float pmax = 0.f;
+        if (adapt) {
+            if (tid < RADET_MAX_SEG) s_lvl[tid] = 0;
+            __syncthreads();
+        }
         for (int c0 = 0; c0 < N; c0 += 256) {
             const int p = c0 + tid;
             int flag = 0;
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
                 const float mx = fmaxf(fmaxf(left, top), fmaxf(right, bottom));
                 if (mn > 0.01f && mx >= L.lo[l] && mx <= L.hi[l] && p2g[p] == -1) {
                     flag = 1;
+                    if (adapt) atomicAdd(&s_lvl[l], 1);          // (integer counts: order independent)
                     prob = fmaxf((float)mk[(size_t)(iy * L.stride[l]) * W + ix * L.stride[l]], 1e-8f);
                 }
             }
@@ -188,6 +198,26 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         __syncthreads();
         pmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
         const float thr = neg_thr * pmax;
+        // positive_num of this gt.  adapt_cal_k (label_assignment.py:88-95): over the anchor sizes present among the candidates
+        // (ascending = level order), ratio (float64) x exp((object_size - size) / (2 size)) (float32), summed in order,
+        // x positive_num, rounded half up.  expf: numpy's float32 exp may differ in the last bit -- it only matters within an
+        // ulp of a .5 boundary of the product
+        int K = K0;
+        if (adapt) {
+            if (tid == 0) {
+                const float obj = fmaxf(x2 - x1, y2 - y1);
+                double dk = 0.0;
+                for (int l = 0; l < L.n; ++l)
+                    if (s_lvl[l] > 0) {
+                        const float sz = (float)(8 * L.stride[l]);
+                        dk += ((double)s_lvl[l] / (double)nc) * (double)expf((obj - sz) / (2.f * sz));
+                    }
+                s_i[4] = (int)((double)K0 * dk + 0.5);
+            }
+            __syncthreads();
+            K = s_i[4];
+            if (K > ASG_MAXK) { if (tid == 0) used_out[b] = -3; return; }
+        }
         // ---- non-negative subset (p > thr), ordered
         int n = 0;
         for (int c0 = 0; c0 < nc; c0 += 256) {
@@ -204,6 +234,12 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         const float ssum = s_f[0];
         for (int i = tid; i < n; i += 256) p64[i] = (double)(nn_p[i] / ssum);
         __syncthreads();
+        // ---- fewer non-negative candidates than positive_num and no balancing: all of them, once each (no draw)
+        if (n < K && !balance) {
+            for (int i = tid; i < n; i += 256) { p2g[nn_idx[i]] = g + 1; pw[nn_idx[i]] = mulpro ? nn_p[i] : 1.f; }
+            __syncthreads();
+            continue;
+        }
         // ---- numpy legacy choice
         const bool replace = n < K;
         if (replace) {
@@ -277,7 +313,10 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         __syncthreads();
         for (int i = tid; i < n; i += 256) { p2g[nn_idx[i]] = 0; pw[nn_idx[i]] = 0.f; }
         __syncthreads();
-        if (tid < s_i[3]) { p2g[nn_idx[uniq_idx[tid]]] = g + 1; pw[nn_idx[uniq_idx[tid]]] = (float)uniq_cnt[tid]; }
+        if (tid < s_i[3]) {
+            p2g[nn_idx[uniq_idx[tid]]] = g + 1;
+            pw[nn_idx[uniq_idx[tid]]] = mulpro ? (float)uniq_cnt[tid] * nn_p[uniq_idx[tid]] : (float)uniq_cnt[tid];
+        }
         __syncthreads();
     }
     if (tid == 0) used_out[b] = s_i[0];
@@ -287,9 +326,9 @@ extern "C" size_t radet_assign_ws_bytes(int B, int N) { return (size_t)B * (((si
 
 template <class MT>
 static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks, int H, int W, const double* uniforms, int U,
-                       const int* level_desc, const float* regress_ranges, int nlvl, int B, int positive_num,
+                       const int* level_desc, const float* regress_ranges, int nlvl, int B, int positive_num, int flags,
                        float neg_threshold, int64_t* p2g, float* pw, int* used, void* ws, void* stream) {
-    if (nlvl < 1 || nlvl > RADET_MAX_SEG || positive_num < 1 || positive_num > ASG_MAXK || B < 1) return RADET_ERR_ARG;
+    if (nlvl < 1 || nlvl > RADET_MAX_SEG || positive_num < 1 || positive_num > ASG_MAXK || B < 1 || (flags & ~7)) return RADET_ERR_ARG;
     AsgLevels L;
     L.n = nlvl;
     int pt = 0;
@@ -303,22 +342,22 @@ static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks
     for (int l = nlvl; l < RADET_MAX_SEG; ++l) { L.h[l] = 1; L.w[l] = 1; L.stride[l] = 1; L.lo[l] = 0.f; L.hi[l] = 0.f; }
     const size_t per = ((size_t)pt * 32 + 255) / 256 * 256;
     hipLaunchKernelGGL(assign_kernel<MT>, dim3(B), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_off, masks, H, W, uniforms,
-                       U, L, positive_num, neg_threshold, p2g, pw, used, (char*)ws, per);
+                       U, L, positive_num, flags, neg_threshold, p2g, pw, used, (char*)ws, per);
     return radet_check_launch();
 }
 
 extern "C" int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
                                    const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
-                                   int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw,
+                                   int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw,
                                    int* used, void* ws, void* stream) {
     return assign_impl<uint8_t>(gt_boxes, gt_off, masks, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B, positive_num,
-                                neg_threshold, p2g, pw, used, ws, stream);
+                                flags, neg_threshold, p2g, pw, used, ws, stream);
 }
 
 extern "C" int radet_assign_points_f(const float* gt_boxes, const int* gt_off, const float* distance_maps, int H, int W,
                                      const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
-                                     int nlvl, int B, int positive_num, float neg_threshold, int64_t* p2g, float* pw,
+                                     int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw,
                                      int* used, void* ws, void* stream) {
     return assign_impl<float>(gt_boxes, gt_off, distance_maps, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B,
-                              positive_num, neg_threshold, p2g, pw, used, ws, stream);
+                              positive_num, flags, neg_threshold, p2g, pw, used, ws, stream);
 }

@@ -108,13 +108,19 @@ class LabelAssignment:
                  positive_num=10, neg_threshold=0.2, adapt_positive_num=False, balance_sample=False,
                  multiply_samplepro_for_weight=False, ambiguous_sample="min_area", random_sample_by_distance=True):
         assert len(strides) == len(regress_ranges)
-        if adapt_positive_num or not balance_sample or multiply_samplepro_for_weight or ambiguous_sample != "min_area" \
-                or not random_sample_by_distance:
-            raise NotImplementedError("LabelAssignment on MI355X implements the configuration of "
-                                      "configs/base/datasets/bop_detection.py (balance_sample=True, min_area, "
-                                      "probability-weighted draw)")
+        if ambiguous_sample != "min_area":
+            # ('max_dis' does not run in the reference either: label_assignment.py:158-161 reads an undefined `is_candidate`)
+            raise NotImplementedError("LabelAssignment: ambiguous_sample='min_area' is the only rule the reference can execute")
+        if not random_sample_by_distance:
+            # np.random.choice WITHOUT p draws integers (randint / permutation: masked rejection sampling on raw 32-bit
+            # outputs), a different consumption of the RandomState than the uniform stream this kernel is driven by
+            raise NotImplementedError("LabelAssignment on MI355X draws by the map values (random_sample_by_distance=True, every "
+                                      "RADet config); the uniform integer draw of random_sample_by_distance=False is not built")
         self.strides, self.regress_ranges = tuple(strides), tuple(tuple(r) for r in regress_ranges)
         self.positive_num, self.neg_threshold = positive_num, neg_threshold
+        self.adapt_positive_num, self.balance_sample = bool(adapt_positive_num), bool(balance_sample)
+        self.multiply_sample_pro_for_weight = bool(multiply_samplepro_for_weight)
+        self.flags = (1 if balance_sample else 0) | (2 if multiply_samplepro_for_weight else 0) | (4 if adapt_positive_num else 0)
         self.uniform_budget = 4096      # uniforms drawn per image: positive_num (+ rejection redraws) per gt, 256 gts x 10 fit
 
     def _levels(self, H, W):
@@ -165,10 +171,11 @@ class LabelAssignment:
         ws = torch.empty(K.assign_ws_bytes(B, N), dtype=torch.uint8, device=dev)
         K.assign_points(torch.from_numpy(boxes).to(dev), torch.from_numpy(off).to(dev), mk, H, W,
                         torch.from_numpy(u).to(dev), U, ldesc, rr, nlvl, B, self.positive_num, float(self.neg_threshold),
-                        p2g, pw, used, ws)
+                        p2g, pw, used, ws, flags=self.flags)
         used_h = used.cpu().numpy()
         if (used_h < 0).any():
-            raise RuntimeError(f"LabelAssignment: uniform stream exhausted / too many gts (codes {used_h.tolist()})")
+            raise RuntimeError("LabelAssignment: uniform stream exhausted (-1) / more than 256 gts (-2) / an adapted positive_num "
+                               f"above 64 (-3): codes {used_h.tolist()}")
         for (r, st), k in zip(states, used_h):      # leave each RNG exactly where the reference would
             r.set_state(st)
             if k:

@@ -1049,10 +1049,12 @@ def mask_transform(src, out_hw=None, resized_hw=None, flip=None, pad_val=0, norm
 
 
 def assign_points(gt_boxes, gt_off, masks, H, W, uniforms, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
-                  ws):
-    """masks: u8 [sumG, H, W] visible masks, or f32 per-box distance maps (mask-free sampler)"""
-    _lib.call("radet_assign_points_f" if masks.dtype == torch.float32 else "radet_assign_points", _ptr(gt_boxes), _ptr(gt_off), _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges,
-              nlvl, B, positive_num, neg_thr, _ptr(p2g), _ptr(pw), _ptr(used), _ptr(ws), _stream())
+                  ws, flags=1):
+    """masks: u8 [sumG, H, W] visible masks, or f32 per-box distance maps (mask-free sampler); flags: bit 0 balance_sample,
+    bit 1 multiply_samplepro_for_weight, bit 2 adapt_positive_num"""
+    _lib.call("radet_assign_points_f" if masks.dtype == torch.float32 else "radet_assign_points", _ptr(gt_boxes), _ptr(gt_off),
+              _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges, nlvl, B, positive_num, int(flags), neg_thr, _ptr(p2g), _ptr(pw),
+              _ptr(used), _ptr(ws), _stream())
 
 
 # ---------------------------------------------------------------------- image processing around MBD / GDT (packed crops)

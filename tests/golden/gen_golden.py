@@ -67,12 +67,23 @@ ASSIGN_CASES = [
 ]
 
 
-def run_ref_assigner(boxes, labels, masks, np_seed):
-    la = LabelAssignment(anchor_generator_cfg=ANCHOR_CFG, neg_threshold=0.2, positive_num=10,
-                         adapt_positive_num=False, balance_sample=True)
+class _Maps:
+    """what LabelAssignment.__call__ needs of `distance_maps` (label_assignment.py:152): float maps instead of BitmapMasks"""
+
+    def __init__(self, a):
+        self.a = a
+
+    def to_ndarray(self):
+        return self.a
+
+
+def run_ref_assigner(boxes, labels, masks, np_seed, graded=False, **opts):
+    kw = dict(adapt_positive_num=False, balance_sample=True)
+    kw.update(opts)
+    la = LabelAssignment(anchor_generator_cfg=ANCHOR_CFG, neg_threshold=0.2, positive_num=10, **kw)
     np.random.seed(np_seed)
     res = dict(img_shape=(480, 640, 3), gt_bboxes=boxes, gt_labels=labels,
-               distance_maps=BitmapMasks([m for m in masks], 480, 640))
+               distance_maps=_Maps(synth.graded_maps(masks)) if graded else BitmapMasks([m for m in masks], 480, 640))
     st0 = np.random.get_state()
     res = la(res)
     # how many uniforms were consumed: replay the stream until the state matches
@@ -109,6 +120,40 @@ def gen_assigner():
         print(tag, "pos", int((p2g > 0).sum()), "ign", int((p2g == 0).sum()), "sumw", float(w[p2g > 0].sum()),
               "uniforms", used)
     save("assigner", **out)
+    return out
+
+
+# the constructor options no BOP config sets (label_assignment.py:30-46): outputs of the reference for each of them and all
+ASSIGN_OPT_CASES = [
+    # (tag, synth seed, G, tiny_visible, np seed, options)
+    ("nobal", 7, 8, True, 31, dict(balance_sample=False)),
+    ("mulpro", 0, 8, False, 32, dict(multiply_samplepro_for_weight=True)),
+    ("mulpro_tiny", 7, 8, True, 33, dict(multiply_samplepro_for_weight=True)),
+    ("adapt", 0, 8, False, 34, dict(adapt_positive_num=True)),
+    ("adapt20", 3, 20, False, 35, dict(adapt_positive_num=True)),
+    ("adapt_nobal", 7, 8, True, 36, dict(adapt_positive_num=True, balance_sample=False)),
+    ("all3", 11, 3, False, 37, dict(adapt_positive_num=True, balance_sample=False, multiply_samplepro_for_weight=True)),
+    # float maps with graded values (oracle/synth.py::graded_maps): the weights really carry the map value
+    ("g_mulpro", 0, 8, False, 38, dict(graded=True, multiply_samplepro_for_weight=True)),
+    ("g_all3", 7, 8, True, 39, dict(graded=True, adapt_positive_num=True, balance_sample=False, multiply_samplepro_for_weight=True)),
+    ("g_plain", 3, 20, False, 40, dict(graded=True)),
+]
+
+
+def gen_assigner_opts():
+    out = {}
+    for tag, sseed, G, tiny, npseed, opts in ASSIGN_OPT_CASES:
+        boxes, labels, masks = synth.synth_objects(sseed, G, tiny_visible=tiny)
+        p2g, w, used = run_ref_assigner(boxes, labels, masks, npseed, **opts)
+        out[tag + "_synth"] = np.asarray([sseed, G, int(tiny), npseed, int(bool(opts.get("graded")))], np.int64)   # (inputs: oracle/synth.py)
+        out[tag + "_flags"] = np.int64((1 if opts.get("balance_sample", True) else 0) | (2 if opts.get("multiply_samplepro_for_weight") else 0)
+                                       | (4 if opts.get("adapt_positive_num") else 0))
+        out[tag + "_p2g"] = p2g.astype(np.int16)
+        out[tag + "_w"] = w.astype(np.float32)
+        out[tag + "_used"] = np.int64(used)
+        print(tag, opts, "pos", int((p2g > 0).sum()), "ign", int((p2g == 0).sum()), "sumw", float(w[p2g > 0].sum()), "uniforms", used,
+              "max w", float(w.max()))
+    save("assigner_opts", **out)
     return out
 
 
@@ -522,6 +567,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ops2":       # only the second op set (the other fixtures stay as committed)
         gen_ops2()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "assigner_opts":   # only assigner_opts.npz
+        gen_assigner_opts()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "recall":     # only recall.npz
         gen_recall()
         return
@@ -544,6 +592,7 @@ def main():
     model_cfg, train_cfg, test_cfg = ref_import.load_cfg()
     gen_anchors()
     assign = gen_assigner()
+    gen_assigner_opts()
     gen_ops()
     gen_ops2()
     gen_nms(test_cfg)

@@ -837,6 +837,30 @@ def test_assigner_bit_exact(golden):
         assert rngs[i].random_sample() == probe.random_sample()
 
 
+def test_assigner_constructor_options_bit_exact(golden):
+    """LabelAssignment(balance_sample=False / multiply_samplepro_for_weight=True / adapt_positive_num=True), alone and
+    together, on visible masks (u8) and on graded float maps (the mask-free sampler's entry point): == outputs of the reference
+    for the same NumPy seeds, RNG position included."""
+    from oracle import synth
+    from radet_amd.datasets import LabelAssignment
+    from test_oracle import ASSIGN_OPT_TAGS, assigner_opt_case
+    g = golden("assigner_opts")
+    for t in ASSIGN_OPT_TAGS:
+        boxes, labels, maps, npseed, opts = assigner_opt_case(g, t)
+        la = LabelAssignment(anchor_generator_cfg=None, neg_threshold=0.2, positive_num=10, **opts)
+        rng = np.random.RandomState(npseed)
+        p2g, pw = la.assign_batch([boxes], [maps], (480, 640, 3), rngs=[rng])
+        assert np.array_equal(p2g[0].cpu().numpy(), g[t + "_p2g"].astype(np.int64)), t
+        assert np.array_equal(pw[0].cpu().numpy(), g[t + "_w"]), t
+        probe = np.random.RandomState(npseed)
+        probe.random_sample(int(g[t + "_used"]))
+        assert rng.random_sample() == probe.random_sample(), t
+    with pytest.raises(NotImplementedError):
+        LabelAssignment(random_sample_by_distance=False)
+    with pytest.raises(NotImplementedError):
+        LabelAssignment(ambiguous_sample="max_dis")
+
+
 def test_assigner_all_masks_empty():
     """No visible pixel: every candidate has p = 1e-8, sum needs NumPy's pairwise order; compare with the oracle."""
     from oracle import assigner as oa

@@ -68,6 +68,44 @@ def test_nms_score_ties_follow_index_order():
 
 
 @pytest.mark.parametrize("seed", range(6))
+def test_assigner_random_batches_with_options(seed):
+    """The constructor options of label_assignment.py:30-46 on ragged random batches with graded float maps, against the
+    oracle (which the reference's goldens pin): flags cycle through the eight combinations."""
+    from oracle import assigner as oa, synth
+    from radet_amd.datasets import LabelAssignment
+    rs = np.random.RandomState(700 + seed)
+    H, W = [(480, 640), (200, 264), (320, 320)][seed % 3]
+    f = (seed * 3 + 2) % 8
+    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4))
+    B = 4
+    boxes, maps, rngs, orngs = [], [], [], []
+    for i in range(B):
+        G = int(rs.randint(1, 11))
+        bx = np.zeros((G, 4), np.float32)
+        mk = np.zeros((G, H, W), np.uint8)
+        for g in range(G):
+            w, h = rs.randint(4, W // 2), rs.randint(4, H // 2)
+            x, y = rs.randint(0, W - w), rs.randint(0, H - h)
+            bx[g] = (x, y, x + w, y + h)
+            kind = rs.randint(0, 3)
+            if kind == 0:
+                mk[g, y:y + h, x:x + w] = 1
+            elif kind == 1:
+                mk[g, y:y + h, x + w // 2:x + w] = 1
+            else:
+                mk[g, y + h // 2:y + h // 2 + 3, x + w // 2:x + w // 2 + 3] = 1
+        boxes.append(bx); maps.append(synth.graded_maps(mk) if seed % 2 else mk)
+        rngs.append(np.random.RandomState(1900 + seed * 10 + i)); orngs.append(np.random.RandomState(1900 + seed * 10 + i))
+    la = LabelAssignment(neg_threshold=0.2, positive_num=10, **opts)
+    p2g, pw = la.assign_batch(boxes, maps, (H, W, 3), rngs=rngs)
+    p2g, pw = p2g.cpu().numpy(), pw.cpu().numpy()
+    for i in range(B):
+        rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), maps[i], (H, W, 3), rng=orngs[i], **opts)
+        assert np.array_equal(p2g[i], rp) and np.array_equal(pw[i], rw), (seed, i, opts)
+        assert rngs[i].random_sample() == orngs[i].random_sample()
+
+
+@pytest.mark.parametrize("seed", range(6))
 def test_assigner_random_batches(seed):
     """Ragged batches (0..12 gts per image, overlapping / tiny / fully occluded objects), 200x264 .. 480x640."""
     from oracle import assigner as oa

@@ -343,3 +343,32 @@ def test_imgproc_oracle_against_scipy():
     ramp = np.tile(np.arange(0, 200, 4, dtype=np.uint8)[None, :, None], (9, 1, 3))              # linear ramp stays linear
     r2 = ip.resize_linear_u8(ramp, (100, 9))[4, 2:-2, 0].astype(int)
     assert set(np.diff(r2)) <= {1, 2, 3}
+
+
+ASSIGN_OPT_TAGS = ["nobal", "mulpro", "mulpro_tiny", "adapt", "adapt20", "adapt_nobal", "all3", "g_mulpro", "g_all3", "g_plain"]
+
+
+def assigner_opt_case(g, tag):
+    """inputs of an assigner_opts.npz case (regenerated by oracle/synth.py) and the reference's constructor options"""
+    sseed, G, tiny, npseed, graded = (int(v) for v in g[tag + "_synth"])
+    boxes, labels, masks = synth.synth_objects(sseed, G, tiny_visible=bool(tiny))
+    maps = synth.graded_maps(masks) if graded else masks
+    f = int(g[tag + "_flags"])
+    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4))
+    return boxes, labels, maps, npseed, opts
+
+
+@pytest.mark.parametrize("tag", ASSIGN_OPT_TAGS)
+def test_assigner_constructor_options(golden, tag):
+    """balance_sample=False, multiply_samplepro_for_weight, adapt_positive_num (label_assignment.py:30-46, 88-131), alone and
+    together, on binary masks and on graded float maps: the oracle against outputs of the reference itself, with NumPy's own
+    RandomState and with the explicit uniform stream (= what the HIP kernel consumes), incl. the stream position."""
+    g = golden("assigner_opts")
+    boxes, labels, maps, npseed, opts = assigner_opt_case(g, tag)
+    p2g, w = assigner.assign_points(boxes, labels, maps, (480, 640, 3), rng=np.random.RandomState(npseed), **opts)
+    assert np.array_equal(p2g, g[tag + "_p2g"].astype(np.int64))
+    assert np.array_equal(w, g[tag + "_w"])
+    u = np.random.RandomState(npseed).random_sample(4096)
+    p2g, w, used = assigner.assign_points_explicit(boxes, labels, maps, (480, 640, 3), u, **opts)
+    assert np.array_equal(p2g, g[tag + "_p2g"].astype(np.int64)) and np.array_equal(w, g[tag + "_w"])
+    assert used == int(g[tag + "_used"])

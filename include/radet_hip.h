@@ -272,21 +272,22 @@ int radet_nms(const float* boxes, const float* cluster_scores, const float* vote
               void* ws, void* stream);
 
 /* ---- visibility-guided positive-sample assigner (radet/datasets/pipelines/label_assignment.py:57-201).
- *      One image per workgroup.  masks u8 [sumG, H, W]; uniforms f64 [B, U] = the image's
- *      RandomState.random_sample() stream; out p2g i64 [B,N], pw f32 [B,N], used i32 [B] (uniforms
+ *      One image per workgroup.  masks u8 [sumG, H, W]; rng_words u32 [B, U] = the next U raw 32-bit outputs of the image's
+ *      RandomState (MT19937; a random_sample() is two words); out p2g i64 [B,N], pw f32 [B,N], used i32 [B] (words
  *      consumed; -1 = stream exhausted, -2 = more than 256 gts, -3 = an adapted positive_num above 64).
- *      flags: bit 0 balance_sample, bit 1 multiply_samplepro_for_weight, bit 2 adapt_positive_num (the constructor
- *      arguments of label_assignment.py:30-46; the BOP configs use flags = 1).  ws: radet_assign_ws_bytes(B, N) bytes. */
+ *      flags: bit 0 balance_sample, bit 1 multiply_samplepro_for_weight, bit 2 adapt_positive_num, bit 3 NOT
+ *      random_sample_by_distance (uniform integer draws: randint / permutation) -- the constructor arguments of
+ *      label_assignment.py:30-46; the BOP configs use flags = 1.  ws: radet_assign_ws_bytes(B, N) bytes. */
 size_t radet_assign_ws_bytes(int B, int N);
 int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
-                        const double* uniforms, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
+                        const uint32_t* rng_words, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
                         int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw, int* used,
                         void* ws, void* stream);
 
 /* same with float per-box distance maps f32 [sumG, H, W] (mask-free sampler: MBD / GDT output mapped into the image,
  * radet/datasets/pipelines/loading.py:586-645, read as np.float32 by label_assignment.py:85-92) */
 int radet_assign_points_f(const float* gt_boxes, const int* gt_off, const float* distance_maps, int H, int W,
-                          const double* uniforms, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
+                          const uint32_t* rng_words, int U, const int* level_desc, const float* regress_ranges /*host, nlvl x 2*/,
                           int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw, int* used,
                           void* ws, void* stream);
 

@@ -77,7 +77,7 @@ def legacy_choice(p32, size, replace, uniforms):
 
 def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFAULT_STRIDES,
                   regress_ranges=DEFAULT_RANGES, positive_num=10, neg_threshold=0.2, balance_sample=True,
-                  multiply_samplepro_for_weight=False, adapt_positive_num=False):
+                  multiply_samplepro_for_weight=False, adapt_positive_num=False, random_sample_by_distance=True):
     """Returns (points_to_gt_index int64[N], points_weight float32[N]).
 
     gt_bboxes f32[G,4], gt_labels i64[G] (unused by the arithmetic), masks [G,H,W] (0/1),
@@ -124,8 +124,10 @@ def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFA
             k = int(positive_num * dk + 0.5)
         if n < k and not balance_sample:       # (:112-113) all of them, no draw
             chosen = np.arange(0, n)
-        else:
+        elif random_sample_by_distance:
             chosen = rng.choice(a=n, size=k, p=sample_p, replace=bool(n < k))
+        else:                                  # (:111, :118) uniform draw: randint / permutation inside numpy
+            chosen = rng.choice(a=n, size=k, replace=bool(n < k))
         uniq, cnt = np.unique(chosen, return_counts=True)
         weight = cnt.astype(np.float32)
         if multiply_samplepro_for_weight:      # (:127-128) the clipped map value, not the normalised probability
@@ -137,20 +139,66 @@ def assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=None, strides=DEFA
     return p2g, wts
 
 
-def assign_points_explicit(gt_bboxes, gt_labels, masks, img_shape, uniforms, **kw):
-    """Same as assign_points but driven by an explicit uniform stream through
-    `legacy_choice` (the algorithm the HIP kernel implements). Returns
-    (p2g, weights, n_uniforms_consumed)."""
+def uniforms_from_words(words):
+    """RandomState.random_sample() values from consecutive pairs of raw MT19937 outputs (genrand_res53)"""
+    w = np.asarray(words, np.uint64)
+    n = w.shape[0] // 2
+    return ((w[0:2 * n:2] >> np.uint64(5)).astype(np.float64) * 67108864.0 + (w[1:2 * n:2] >> np.uint64(6)).astype(np.float64)) / 9007199254740992.0
+
+
+def legacy_bounded(words, pos, rng):
+    """numpy legacy bounded integer in [0, rng] (random_interval; the masked path of randint): raw 32-bit outputs & mask until
+    <= rng.  Returns (value, new position)."""
+    if rng == 0:
+        return 0, pos
+    mask = rng
+    for sh in (1, 2, 4, 8, 16):
+        mask |= mask >> sh
+    while True:
+        v = int(words[pos]) & mask
+        pos += 1
+        if v <= rng:
+            return v, pos
+
+
+def legacy_choice_uniform(n, size, replace, words):
+    """numpy legacy `RandomState.choice(n, size, replace=...)` WITHOUT p, with the stream of raw 32-bit outputs given explicitly:
+    randint(0, n, size) with replacement, permutation(n)[:size] (Fisher-Yates from the top) without.  Returns (indices, words
+    consumed); checked against numpy itself in tests/test_oracle.py."""
+    pos = 0
+    if replace:
+        out = np.zeros(size, np.int64)
+        for k in range(size):
+            out[k], pos = legacy_bounded(words, pos, n - 1)
+        return out, pos
+    perm = np.arange(n, dtype=np.int64)
+    for i in range(n - 1, 0, -1):
+        v, pos = legacy_bounded(words, pos, i)
+        perm[i], perm[v] = perm[v], perm[i]
+    return perm[:size].copy(), pos
+
+
+def assign_points_explicit(gt_bboxes, gt_labels, masks, img_shape, uniforms=None, words=None, **kw):
+    """Same as assign_points but driven by an explicit random stream through `legacy_choice` / `legacy_choice_uniform` (the
+    algorithms the HIP kernel implements): `uniforms` = successive random_sample() outputs (weighted draws only), or `words` =
+    the RandomState's raw 32-bit outputs (what the kernel is handed; both kinds of draw).  Returns (p2g, weights, uniforms
+    resp. words consumed)."""
 
     class _Stream:
-        def __init__(self, u):
-            self.u, self.used = np.asarray(u, np.float64), 0
+        def __init__(self, u, w):
+            self.u, self.w, self.used = (None if u is None else np.asarray(u, np.float64)), w, 0
 
-        def choice(self, a, size, p, replace):
-            idx, k = legacy_choice(p, size, replace, self.u[self.used:])
+        def choice(self, a, size, p=None, replace=True):
+            if p is None:
+                idx, k = legacy_choice_uniform(a, size, replace, self.w[self.used:])
+            elif self.w is not None:           # uniforms of the weighted draw from the word stream: two words each
+                idx, k = legacy_choice(p, size, replace, uniforms_from_words(self.w[self.used:self.used + 16384]))
+                k *= 2
+            else:
+                idx, k = legacy_choice(p, size, replace, self.u[self.used:])
             self.used += k
             return idx
 
-    s = _Stream(uniforms)
+    s = _Stream(uniforms, words)
     p2g, w = assign_points(gt_bboxes, gt_labels, masks, img_shape, rng=s, **kw)
     return p2g, w, s.used

@@ -6,8 +6,9 @@
 // gather run in parallel (ordered wave-ballot compaction keeps NumPy's index order); the float32
 // normaliser reproduces NumPy's pairwise summation; the draw is numpy's legacy
 // RandomState.choice(p=..., replace = n < positive_num) -- float64 sequential cumsum, normalised cdf,
-// searchsorted(side='right'), first-occurrence de-duplication -- driven by the host-supplied uniform
-// stream (RandomState.random_sample()), so results equal the reference's for the same seed.
+// searchsorted(side='right'), first-occurrence de-duplication -- or, with random_sample_by_distance=False, the integer draws
+// of choice() WITHOUT p (randint / permutation: masked rejection sampling) -- driven by the host-supplied stream of the
+// RandomState's raw 32-bit outputs (a uniform is two words: genrand_res53), so results equal the reference's for the same seed.
 #include "common.h"
 #include "../../include/radet_hip.h"
 
@@ -97,12 +98,29 @@ __device__ __forceinline__ int upper_bound_d(const double* cdf, int n, double x)
     return lo;
 }
 
+// one double of RandomState.random_sample() from two consecutive MT19937 outputs (genrand_res53)
+__device__ __forceinline__ double uniform_from_words(const uint32_t* w) {
+    return ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6)) / 9007199254740992.0;
+}
+// legacy bounded integer in [0, rng] (numpy random_interval / the masked path of randint): words & mask until <= rng.
+// Returns the new stream position, or -1 when the stream is exhausted.
+__device__ __forceinline__ int bounded_from_words(const uint32_t* w, int pos, int U, unsigned rng, unsigned* out) {
+    if (rng == 0) { *out = 0; return pos; }
+    unsigned mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    while (true) {
+        if (pos >= U) return -1;
+        const unsigned v = w[pos++] & mask;
+        if (v <= rng) { *out = v; return pos; }
+    }
+}
+
 // MT = uint8_t: visible instance masks (GenerateDistanceMap(with_gt_mask=True)); float: the per-box distance maps of
 // the mask-free sampler (MBD / GDT transforms, loading.py:586-645), read as np.float32 like label_assignment.py:85-92
 template <class MT>
 __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ gt_boxes, const int* __restrict__ gt_off,
                                                      const MT* __restrict__ masks, int H, int W,
-                                                     const double* __restrict__ uniforms, int U, const AsgLevels L,
+                                                     const uint32_t* __restrict__ rng_words, int U, const AsgLevels L,
                                                      int K0, int flags, float neg_thr, int64_t* __restrict__ p2g_all,
                                                      float* __restrict__ pw_all, int* __restrict__ used_out,
                                                      char* __restrict__ ws_all, size_t ws_per_image) {
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
     int64_t* p2g = p2g_all + (size_t)b * N;
     float* pw = pw_all + (size_t)b * N;
-    const double* u = uniforms + (size_t)b * U;
+    const uint32_t* u = rng_words + (size_t)b * U;      // this image's stream of raw 32-bit outputs; s_i[0] = words consumed
     char* w = ws_all + (size_t)b * ws_per_image;
     double* p64 = (double*)w; w += (size_t)N * 8;
     double* cdf = (double*)w; w += (size_t)N * 8;
@@ -131,7 +149,9 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
     // flags (label_assignment.py:30-46, 88-131): bit 0 balance_sample (fewer non-negative candidates than positive_num: draw
     // positive_num with replacement; off: take them all once), bit 1 multiply_samplepro_for_weight (weight = count x the
     // candidate's clipped map value), bit 2 adapt_positive_num (positive_num per gt from the candidates' anchor sizes)
-    const bool balance = (flags & 1) != 0, mulpro = (flags & 2) != 0, adapt = (flags & 4) != 0;
+    // bit 3: random_sample_by_distance = False: np.random.choice without p -- randint(0, n, K) when drawing with replacement,
+    // permutation(n)[:K] (Fisher-Yates from the top, one bounded integer per position) otherwise
+    const bool balance = (flags & 1) != 0, mulpro = (flags & 2) != 0, adapt = (flags & 4) != 0, uniform = (flags & 8) != 0;
     __shared__ double xs[ASG_MAXK];
 
     for (int p = tid; p < N; p += 256) { p2g[p] = -1; pw[p] = 1.f; }
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
             while (j >= 0 && area[order[j]] > ai) { order[j + 1] = order[j]; --j; }
             order[j + 1] = oi;
         }
-        s_i[0] = 0;  // uniforms consumed
+        s_i[0] = 0;  // 32-bit words of the stream consumed
     }
     __syncthreads();
     if (G > ASG_MAXG) { if (tid == 0) used_out[b] = -2; return; }
@@ -242,12 +262,39 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
         }
         // ---- numpy legacy choice
         const bool replace = n < K;
-        if (replace) {
+        if (uniform) {
+            // choice(a = n, size = K, replace) without p (label_assignment.py:111, 118): sequential by construction
+            if (tid == 0) {
+                int pos = s_i[0];
+                if (replace) {
+                    for (int k = 0; k < K && pos >= 0; ++k) {
+                        unsigned v;
+                        pos = bounded_from_words(u, pos, U, (unsigned)(n - 1), &v);
+                        chosen[k] = (int)v;
+                    }
+                } else {
+                    int* perm = (int*)cdf;                       // scratch of N doubles: the permutation being shuffled
+                    for (int i = 0; i < n; ++i) perm[i] = i;
+                    for (int i = n - 1; i >= 1 && pos >= 0; --i) {
+                        unsigned v;
+                        pos = bounded_from_words(u, pos, U, (unsigned)i, &v);
+                        if (pos >= 0) { const int t = perm[i]; perm[i] = perm[v]; perm[v] = t; }
+                    }
+                    if (pos >= 0)
+                        for (int k = 0; k < K; ++k) chosen[k] = perm[k];
+                }
+                s_i[1] = pos < 0 ? 1 : 0;
+                if (pos >= 0) s_i[0] = pos;
+            }
+            __syncthreads();
+            if (s_i[1]) { if (tid == 0) used_out[b] = -1; return; }
+        } else if (replace) {
             if (tid == 0) {
                 double acc = 0.0;
                 for (int i = 0; i < n; ++i) { acc += p64[i]; cdf[i] = acc; }
                 int us = s_i[0];
-                if (us + K > U) s_i[1] = 1; else { s_i[1] = 0; for (int k = 0; k < K; ++k) xs[k] = u[us + k]; s_i[0] = us + K; }
+                if (us + 2 * K > U) s_i[1] = 1;
+                else { s_i[1] = 0; for (int k = 0; k < K; ++k) xs[k] = uniform_from_words(u + us + 2 * k); s_i[0] = us + 2 * K; }
             }
             __syncthreads();
             if (s_i[1]) { if (tid == 0) used_out[b] = -1; return; }
@@ -266,11 +313,11 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
                 const int kk = K - n_uniq;
                 if (tid == 0) {
                     const int us = s_i[0];
-                    if (us + kk > U) s_i[1] = 1;
+                    if (us + 2 * kk > U) s_i[1] = 1;
                     else {
                         s_i[1] = 0;
-                        for (int k = 0; k < kk; ++k) xs[k] = u[us + k];
-                        s_i[0] = us + kk;
+                        for (int k = 0; k < kk; ++k) xs[k] = uniform_from_words(u + us + 2 * k);
+                        s_i[0] = us + 2 * kk;
                         for (int k = 0; k < n_uniq; ++k) p64[found[k]] = 0.0;
                         double acc = 0.0;
                         for (int i = 0; i < n; ++i) { acc += p64[i]; cdf[i] = acc; }
@@ -325,10 +372,10 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ g
 extern "C" size_t radet_assign_ws_bytes(int B, int N) { return (size_t)B * (((size_t)N * 32 + 255) / 256 * 256); }
 
 template <class MT>
-static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks, int H, int W, const double* uniforms, int U,
+static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks, int H, int W, const uint32_t* rng_words, int U,
                        const int* level_desc, const float* regress_ranges, int nlvl, int B, int positive_num, int flags,
                        float neg_threshold, int64_t* p2g, float* pw, int* used, void* ws, void* stream) {
-    if (nlvl < 1 || nlvl > RADET_MAX_SEG || positive_num < 1 || positive_num > ASG_MAXK || B < 1 || (flags & ~7)) return RADET_ERR_ARG;
+    if (nlvl < 1 || nlvl > RADET_MAX_SEG || positive_num < 1 || positive_num > ASG_MAXK || B < 1 || (flags & ~15)) return RADET_ERR_ARG;
     AsgLevels L;
     L.n = nlvl;
     int pt = 0;
@@ -341,23 +388,23 @@ static int assign_impl(const float* gt_boxes, const int* gt_off, const MT* masks
     L.pt_off[nlvl] = pt;
     for (int l = nlvl; l < RADET_MAX_SEG; ++l) { L.h[l] = 1; L.w[l] = 1; L.stride[l] = 1; L.lo[l] = 0.f; L.hi[l] = 0.f; }
     const size_t per = ((size_t)pt * 32 + 255) / 256 * 256;
-    hipLaunchKernelGGL(assign_kernel<MT>, dim3(B), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_off, masks, H, W, uniforms,
+    hipLaunchKernelGGL(assign_kernel<MT>, dim3(B), dim3(256), 0, (hipStream_t)stream, gt_boxes, gt_off, masks, H, W, rng_words,
                        U, L, positive_num, flags, neg_threshold, p2g, pw, used, (char*)ws, per);
     return radet_check_launch();
 }
 
 extern "C" int radet_assign_points(const float* gt_boxes, const int* gt_off, const uint8_t* masks, int H, int W,
-                                   const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
+                                   const uint32_t* rng_words, int U, const int* level_desc, const float* regress_ranges,
                                    int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw,
                                    int* used, void* ws, void* stream) {
-    return assign_impl<uint8_t>(gt_boxes, gt_off, masks, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B, positive_num,
+    return assign_impl<uint8_t>(gt_boxes, gt_off, masks, H, W, rng_words, U, level_desc, regress_ranges, nlvl, B, positive_num,
                                 flags, neg_threshold, p2g, pw, used, ws, stream);
 }
 
 extern "C" int radet_assign_points_f(const float* gt_boxes, const int* gt_off, const float* distance_maps, int H, int W,
-                                     const double* uniforms, int U, const int* level_desc, const float* regress_ranges,
+                                     const uint32_t* rng_words, int U, const int* level_desc, const float* regress_ranges,
                                      int nlvl, int B, int positive_num, int flags, float neg_threshold, int64_t* p2g, float* pw,
                                      int* used, void* ws, void* stream) {
-    return assign_impl<float>(gt_boxes, gt_off, distance_maps, H, W, uniforms, U, level_desc, regress_ranges, nlvl, B,
+    return assign_impl<float>(gt_boxes, gt_off, distance_maps, H, W, rng_words, U, level_desc, regress_ranges, nlvl, B,
                               positive_num, flags, neg_threshold, p2g, pw, used, ws, stream);
 }

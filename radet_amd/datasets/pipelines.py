@@ -97,11 +97,13 @@ class LabelAssignment:
     """Same constructor and result keys as the reference. `__call__(results)` handles one image like the
     reference; `assign_batch` is the MI355X-native entry point (one workgroup per image).
 
-    RNG: the reference consumes NumPy's global legacy RandomState. Here the stream is drawn on the host
-    from `rng` (default: the global np.random, whose state is advanced by exactly the number of uniforms
-    the kernel consumed) and the draw itself runs on the GPU -- results are identical for equal seeds.  Images that
-    share one RNG object are assigned one after the other so that each continues the stream where the previous
-    one stopped (the reference's sequential consumption); one RandomState per image runs as a single launch."""
+    RNG: the reference consumes NumPy's global legacy RandomState. Here the next raw 32-bit outputs of `rng` (default: the
+    RandomState behind the global np.random functions) are read on the host and handed to the kernel, which performs numpy's
+    own draws on them -- the weighted `choice(p=...)` (two outputs per uniform) or, with random_sample_by_distance=False, the
+    integer draws of `choice()` without p -- and reports how many it consumed; the RNG is then advanced by exactly that
+    number: results AND the generator's state are identical to the reference's for equal seeds.  Images that share one RNG
+    object are assigned one after the other so that each continues the stream where the previous one stopped (the reference's
+    sequential consumption); one RandomState per image runs as a single launch."""
 
     def __init__(self, strides=(8, 16, 32, 64, 128),
                  regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF)), anchor_generator_cfg=None,
@@ -111,17 +113,17 @@ class LabelAssignment:
         if ambiguous_sample != "min_area":
             # ('max_dis' does not run in the reference either: label_assignment.py:158-161 reads an undefined `is_candidate`)
             raise NotImplementedError("LabelAssignment: ambiguous_sample='min_area' is the only rule the reference can execute")
-        if not random_sample_by_distance:
-            # np.random.choice WITHOUT p draws integers (randint / permutation: masked rejection sampling on raw 32-bit
-            # outputs), a different consumption of the RandomState than the uniform stream this kernel is driven by
-            raise NotImplementedError("LabelAssignment on MI355X draws by the map values (random_sample_by_distance=True, every "
-                                      "RADet config); the uniform integer draw of random_sample_by_distance=False is not built")
         self.strides, self.regress_ranges = tuple(strides), tuple(tuple(r) for r in regress_ranges)
         self.positive_num, self.neg_threshold = positive_num, neg_threshold
         self.adapt_positive_num, self.balance_sample = bool(adapt_positive_num), bool(balance_sample)
         self.multiply_sample_pro_for_weight = bool(multiply_samplepro_for_weight)
-        self.flags = (1 if balance_sample else 0) | (2 if multiply_samplepro_for_weight else 0) | (4 if adapt_positive_num else 0)
-        self.uniform_budget = 4096      # uniforms drawn per image: positive_num (+ rejection redraws) per gt, 256 gts x 10 fit
+        self.random_sample_by_distance = bool(random_sample_by_distance)
+        self.flags = (1 if balance_sample else 0) | (2 if multiply_samplepro_for_weight else 0) | (4 if adapt_positive_num else 0) \
+            | (0 if random_sample_by_distance else 8)
+        # raw 32-bit outputs handed to the kernel per image: two per uniform of the weighted draw (positive_num + rejection
+        # redraws per gt: 256 gts x 10 fit); the uniform integer draw shuffles ALL non-negative candidates of a gt (one or two
+        # words each): its budget grows on demand
+        self.word_budget = 8192
 
     def _levels(self, H, W):
         return K.Levels([(math.ceil(H / s), math.ceil(W / s)) for s in self.strides], 1)
@@ -157,29 +159,38 @@ class LabelAssignment:
             mk = torch.cat([t.to(dev, mdt) for t in ts]).contiguous()
         else:
             mk = torch.zeros(1, H, W, dtype=torch.uint8, device=dev)
-        U = self.uniform_budget
-        states, u = [], np.empty((B, U), np.float64)
-        for i, r in enumerate(rngs):
-            r = np.random if r is None else r
-            states.append((r, r.get_state()))
-            u[i] = r.random_sample(U)
         ldesc, nlvl = K.level_desc(lv, self.strides)
         rr = (C.c_float * (2 * nlvl))(*[float(v) for r in self.regress_ranges for v in r])
         p2g = torch.empty(B, N, dtype=torch.long, device=dev)
         pw = torch.empty(B, N, device=dev)
         used = torch.zeros(B, dtype=torch.int32, device=dev)
         ws = torch.empty(K.assign_ws_bytes(B, N), dtype=torch.uint8, device=dev)
-        K.assign_points(torch.from_numpy(boxes).to(dev), torch.from_numpy(off).to(dev), mk, H, W,
-                        torch.from_numpy(u).to(dev), U, ldesc, rr, nlvl, B, self.positive_num, float(self.neg_threshold),
-                        p2g, pw, used, ws, flags=self.flags)
-        used_h = used.cpu().numpy()
+        boxes_d, off_d = torch.from_numpy(boxes).to(dev), torch.from_numpy(off).to(dev)
+        # the RandomStates' next raw outputs (legacy RandomState = MT19937: random_sample() is two of them, the integer draws
+        # of choice() without p one per trial); the global np.random is the RandomState behind the module functions
+        gens = [np.random.mtrand._rand if (r is None or r is np.random) else r for r in rngs]
+        states = [g.get_state() for g in gens]
+        U = self.word_budget
+        while True:
+            words = np.empty((B, U), np.uint32)
+            for i, g in enumerate(gens):
+                g.set_state(states[i])
+                words[i] = g._bit_generator.random_raw(U)
+            K.assign_points(boxes_d, off_d, mk, H, W, torch.from_numpy(words.view(np.int32)).to(dev), U, ldesc, rr, nlvl, B,
+                            self.positive_num, float(self.neg_threshold), p2g, pw, used, ws, flags=self.flags)
+            used_h = used.cpu().numpy()
+            if (used_h == -1).any() and U < (1 << 24):     # stream exhausted (a shuffle of thousands of candidates): more words,
+                U *= 4                                     # same results -- the kernel is a function of the stream's prefix
+                continue
+            break
+        for g, st in zip(gens, states):
+            g.set_state(st)
         if (used_h < 0).any():
-            raise RuntimeError("LabelAssignment: uniform stream exhausted (-1) / more than 256 gts (-2) / an adapted positive_num "
+            raise RuntimeError("LabelAssignment: random stream exhausted (-1) / more than 256 gts (-2) / an adapted positive_num "
                                f"above 64 (-3): codes {used_h.tolist()}")
-        for (r, st), k in zip(states, used_h):      # leave each RNG exactly where the reference would
-            r.set_state(st)
+        for g, k in zip(gens, used_h):              # leave each RNG exactly where the reference would
             if k:
-                r.random_sample(int(k))
+                g._bit_generator.random_raw(int(k))
         return p2g, pw
 
     def __call__(self, results):

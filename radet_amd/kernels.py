@@ -1048,12 +1048,13 @@ def mask_transform(src, out_hw=None, resized_hw=None, flip=None, pad_val=0, norm
     return dst
 
 
-def assign_points(gt_boxes, gt_off, masks, H, W, uniforms, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
+def assign_points(gt_boxes, gt_off, masks, H, W, rng_words, U, ldesc, ranges, nlvl, B, positive_num, neg_thr, p2g, pw, used,
                   ws, flags=1):
-    """masks: u8 [sumG, H, W] visible masks, or f32 per-box distance maps (mask-free sampler); flags: bit 0 balance_sample,
-    bit 1 multiply_samplepro_for_weight, bit 2 adapt_positive_num"""
+    """masks: u8 [sumG, H, W] visible masks, or f32 per-box distance maps (mask-free sampler); rng_words: int32 / uint32 bit
+    patterns [B, U] of the RandomStates' next raw outputs; flags: bit 0 balance_sample, bit 1 multiply_samplepro_for_weight,
+    bit 2 adapt_positive_num, bit 3 uniform integer draws (random_sample_by_distance=False)"""
     _lib.call("radet_assign_points_f" if masks.dtype == torch.float32 else "radet_assign_points", _ptr(gt_boxes), _ptr(gt_off),
-              _ptr(masks), H, W, _ptr(uniforms), U, ldesc, ranges, nlvl, B, positive_num, int(flags), neg_thr, _ptr(p2g), _ptr(pw),
+              _ptr(masks), H, W, _ptr(rng_words), U, ldesc, ranges, nlvl, B, positive_num, int(flags), neg_thr, _ptr(p2g), _ptr(pw),
               _ptr(used), _ptr(ws), _stream())
 
 

@@ -77,7 +77,7 @@ class _Maps:
         return self.a
 
 
-def run_ref_assigner(boxes, labels, masks, np_seed, graded=False, **opts):
+def run_ref_assigner(boxes, labels, masks, np_seed, graded=False, words=False, **opts):
     kw = dict(adapt_positive_num=False, balance_sample=True)
     kw.update(opts)
     la = LabelAssignment(anchor_generator_cfg=ANCHOR_CFG, neg_threshold=0.2, positive_num=10, **kw)
@@ -86,15 +86,19 @@ def run_ref_assigner(boxes, labels, masks, np_seed, graded=False, **opts):
                distance_maps=_Maps(synth.graded_maps(masks)) if graded else BitmapMasks([m for m in masks], 480, 640))
     st0 = np.random.get_state()
     res = la(res)
-    # how many uniforms were consumed: replay the stream until the state matches
+    # how much of the stream was consumed: replay it until the state matches -- in uniforms (two raw 32-bit outputs each; the
+    # weighted draws) or, for the integer draws of random_sample_by_distance=False, in raw outputs (`words=True`)
     probe = np.random.RandomState()
     probe.set_state(st0)
     st1 = np.random.get_state()
     used = 0
     while not (probe.get_state()[2] == st1[2] and np.array_equal(probe.get_state()[1], st1[1])):
-        probe.random_sample()
+        if words:
+            probe._bit_generator.random_raw(1)
+        else:
+            probe.random_sample()
         used += 1
-        assert used < 100000
+        assert used < 2000000
     return res["points_to_gt_index"], res["points_weight"], used
 
 
@@ -137,6 +141,12 @@ ASSIGN_OPT_CASES = [
     ("g_mulpro", 0, 8, False, 38, dict(graded=True, multiply_samplepro_for_weight=True)),
     ("g_all3", 7, 8, True, 39, dict(graded=True, adapt_positive_num=True, balance_sample=False, multiply_samplepro_for_weight=True)),
     ("g_plain", 3, 20, False, 40, dict(graded=True)),
+    # random_sample_by_distance=False: np.random.choice without p (randint / permutation inside numpy)
+    ("unif", 0, 8, False, 41, dict(random_sample_by_distance=False)),
+    ("unif_tiny", 7, 8, True, 42, dict(random_sample_by_distance=False)),
+    ("unif_nobal", 7, 8, True, 43, dict(random_sample_by_distance=False, balance_sample=False)),
+    ("unif20_all", 3, 20, False, 44, dict(graded=True, random_sample_by_distance=False, adapt_positive_num=True,
+                                          multiply_samplepro_for_weight=True)),
 ]
 
 
@@ -144,13 +154,13 @@ def gen_assigner_opts():
     out = {}
     for tag, sseed, G, tiny, npseed, opts in ASSIGN_OPT_CASES:
         boxes, labels, masks = synth.synth_objects(sseed, G, tiny_visible=tiny)
-        p2g, w, used = run_ref_assigner(boxes, labels, masks, npseed, **opts)
+        p2g, w, used = run_ref_assigner(boxes, labels, masks, npseed, words=True, **opts)
         out[tag + "_synth"] = np.asarray([sseed, G, int(tiny), npseed, int(bool(opts.get("graded")))], np.int64)   # (inputs: oracle/synth.py)
         out[tag + "_flags"] = np.int64((1 if opts.get("balance_sample", True) else 0) | (2 if opts.get("multiply_samplepro_for_weight") else 0)
-                                       | (4 if opts.get("adapt_positive_num") else 0))
+                                       | (4 if opts.get("adapt_positive_num") else 0) | (0 if opts.get("random_sample_by_distance", True) else 8))
         out[tag + "_p2g"] = p2g.astype(np.int16)
         out[tag + "_w"] = w.astype(np.float32)
-        out[tag + "_used"] = np.int64(used)
+        out[tag + "_used_words"] = np.int64(used)        # raw 32-bit outputs of the RandomState consumed
         print(tag, opts, "pos", int((p2g > 0).sum()), "ign", int((p2g == 0).sum()), "sumw", float(w[p2g > 0].sum()), "uniforms", used,
               "max w", float(w.max()))
     save("assigner_opts", **out)

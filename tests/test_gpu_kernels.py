@@ -838,9 +838,9 @@ def test_assigner_bit_exact(golden):
 
 
 def test_assigner_constructor_options_bit_exact(golden):
-    """LabelAssignment(balance_sample=False / multiply_samplepro_for_weight=True / adapt_positive_num=True), alone and
-    together, on visible masks (u8) and on graded float maps (the mask-free sampler's entry point): == outputs of the reference
-    for the same NumPy seeds, RNG position included."""
+    """LabelAssignment(balance_sample=False / multiply_samplepro_for_weight=True / adapt_positive_num=True /
+    random_sample_by_distance=False), alone and together, on visible masks (u8) and on graded float maps (the mask-free
+    sampler's entry point): == outputs of the reference for the same NumPy seeds, RNG position included."""
     from oracle import synth
     from radet_amd.datasets import LabelAssignment
     from test_oracle import ASSIGN_OPT_TAGS, assigner_opt_case
@@ -853,10 +853,8 @@ def test_assigner_constructor_options_bit_exact(golden):
         assert np.array_equal(p2g[0].cpu().numpy(), g[t + "_p2g"].astype(np.int64)), t
         assert np.array_equal(pw[0].cpu().numpy(), g[t + "_w"]), t
         probe = np.random.RandomState(npseed)
-        probe.random_sample(int(g[t + "_used"]))
+        probe._bit_generator.random_raw(int(g[t + "_used_words"]))
         assert rng.random_sample() == probe.random_sample(), t
-    with pytest.raises(NotImplementedError):
-        LabelAssignment(random_sample_by_distance=False)
     with pytest.raises(NotImplementedError):
         LabelAssignment(ambiguous_sample="max_dis")
 

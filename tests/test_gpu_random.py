@@ -70,13 +70,14 @@ def test_nms_score_ties_follow_index_order():
 @pytest.mark.parametrize("seed", range(6))
 def test_assigner_random_batches_with_options(seed):
     """The constructor options of label_assignment.py:30-46 on ragged random batches with graded float maps, against the
-    oracle (which the reference's goldens pin): flags cycle through the eight combinations."""
+    oracle (which the reference's goldens pin): flags cycle through the combinations, incl. the uniform integer draw."""
     from oracle import assigner as oa, synth
     from radet_amd.datasets import LabelAssignment
     rs = np.random.RandomState(700 + seed)
     H, W = [(480, 640), (200, 264), (320, 320)][seed % 3]
-    f = (seed * 3 + 2) % 8
-    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4))
+    f = (seed * 3 + 2) % 8 + (8 if seed % 3 == 1 else 0)
+    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4),
+                random_sample_by_distance=not (f & 8))
     B = 4
     boxes, maps, rngs, orngs = [], [], [], []
     for i in range(B):

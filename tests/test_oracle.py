@@ -345,7 +345,8 @@ def test_imgproc_oracle_against_scipy():
     assert set(np.diff(r2)) <= {1, 2, 3}
 
 
-ASSIGN_OPT_TAGS = ["nobal", "mulpro", "mulpro_tiny", "adapt", "adapt20", "adapt_nobal", "all3", "g_mulpro", "g_all3", "g_plain"]
+ASSIGN_OPT_TAGS = ["nobal", "mulpro", "mulpro_tiny", "adapt", "adapt20", "adapt_nobal", "all3", "g_mulpro", "g_all3", "g_plain",
+                   "unif", "unif_tiny", "unif_nobal", "unif20_all"]
 
 
 def assigner_opt_case(g, tag):
@@ -354,21 +355,40 @@ def assigner_opt_case(g, tag):
     boxes, labels, masks = synth.synth_objects(sseed, G, tiny_visible=bool(tiny))
     maps = synth.graded_maps(masks) if graded else masks
     f = int(g[tag + "_flags"])
-    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4))
+    opts = dict(balance_sample=bool(f & 1), multiply_samplepro_for_weight=bool(f & 2), adapt_positive_num=bool(f & 4),
+                random_sample_by_distance=not (f & 8))
     return boxes, labels, maps, npseed, opts
 
 
 @pytest.mark.parametrize("tag", ASSIGN_OPT_TAGS)
 def test_assigner_constructor_options(golden, tag):
-    """balance_sample=False, multiply_samplepro_for_weight, adapt_positive_num (label_assignment.py:30-46, 88-131), alone and
-    together, on binary masks and on graded float maps: the oracle against outputs of the reference itself, with NumPy's own
-    RandomState and with the explicit uniform stream (= what the HIP kernel consumes), incl. the stream position."""
+    """balance_sample=False, multiply_samplepro_for_weight, adapt_positive_num, random_sample_by_distance=False
+    (label_assignment.py:30-46, 88-131), alone and together, on binary masks and on graded float maps: the oracle against
+    outputs of the reference itself, with NumPy's own RandomState and with the explicit stream of the RandomState's raw 32-bit
+    outputs (= what the HIP kernel consumes), incl. the stream position."""
     g = golden("assigner_opts")
     boxes, labels, maps, npseed, opts = assigner_opt_case(g, tag)
     p2g, w = assigner.assign_points(boxes, labels, maps, (480, 640, 3), rng=np.random.RandomState(npseed), **opts)
     assert np.array_equal(p2g, g[tag + "_p2g"].astype(np.int64))
     assert np.array_equal(w, g[tag + "_w"])
-    u = np.random.RandomState(npseed).random_sample(4096)
-    p2g, w, used = assigner.assign_points_explicit(boxes, labels, maps, (480, 640, 3), u, **opts)
+    words = np.random.RandomState(npseed)._bit_generator.random_raw(65536)
+    p2g, w, used = assigner.assign_points_explicit(boxes, labels, maps, (480, 640, 3), words=words, **opts)
     assert np.array_equal(p2g, g[tag + "_p2g"].astype(np.int64)) and np.array_equal(w, g[tag + "_w"])
-    assert used == int(g[tag + "_used"])
+    assert used == int(g[tag + "_used_words"])
+
+
+def test_legacy_integer_draws_match_numpy():
+    """choice(n, size, replace) WITHOUT p of the legacy RandomState (randint / permutation: masked rejection on raw 32-bit
+    outputs) restated over an explicit word stream == numpy itself, values and stream position."""
+    rs = np.random.RandomState(17)
+    for trial in range(300):
+        n = int(rs.randint(1, 3000))
+        size = int(rs.randint(0, 40))
+        replace = bool(rs.randint(0, 2)) or size > n
+        seed = int(rs.randint(0, 2 ** 31 - 1))
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        ref = a.choice(a=n, size=size, replace=replace)
+        words = b._bit_generator.random_raw(8192)
+        mine, used = assigner.legacy_choice_uniform(n, size, replace, words)
+        assert np.array_equal(mine, ref), (trial, n, size, replace)
+        assert a.random_sample() == assigner.uniforms_from_words(words[used:used + 2])[0]

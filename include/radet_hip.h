@@ -45,8 +45,32 @@ typedef struct RadetConvDesc {
     int wft_ld;            /* row stride of wft's last dim (>= Cout; zero-padded K for small heads), 0 = Cout */
     int wft_off;           /* column offset inside that padded row */
     int w16;               /* 1: wf / wft are bf16 buffers (bf16-storage mode); 2: bf16 plane triples (rows [3][Cin] resp.
-                              [3][wft_ld], see "planes" below); bias_f stays fp32 */
+                              [3][wft_ld], see "planes" below); 3: fp16 plane pairs (rows [2][Cin] resp. [2][wft_ld], see
+                              "plane pairs" below; needs w_amax); bias_f stays fp32 */
+    float* w_amax;         /* 4 bytes or NULL: amax slot of the folded weights (largest |wf|, bit pattern; written by
+                              radet_fold_weights) -- the weight operand's scale in the fp16 hi / lo arithmetic */
 } RadetConvDesc;
+
+/* ---- amax slots (round 5, "fp16 hi / lo arithmetic").  The default fp32 conv arithmetic forms fp32-accurate products
+ * from TWO fp16 numbers per operand element: t = x 2^e, hi = fp16(t), lo = fp16((t - hi) 2^11), and
+ * x x' = 2^-(e + e') (hi hi' + 2^-11 (hi lo' + lo hi')) -- three v_mfma_f32_32x32x16_f16 per K = 16 step instead of the six
+ * bf16 plane products of 0x1000000 (the dropped lo lo' term is <= 2^-24 relative; x = 2^-e (hi + 2^-11 lo) to 2^-23
+ * relative for every element within 2^-27 of the tensor's largest).  fp16 has 5 exponent bits, so every operand tensor is
+ * scaled by an exact power of two 2^e that puts its largest magnitude into [2^14, 2^15).  e comes from the tensor's "amax
+ * slot": 4 bytes of device memory holding the bit pattern of a non-negative float that is >= every |element| (the largest
+ * magnitude, or any bound on it), e = 141 - biased_exponent(slot) (0 for a zero slot).  Slots are maintained by the
+ * kernels that WRITE a tensor: they raise the slot with atomicMax on the bit pattern (order independent, hence
+ * deterministic) -- conv epilogues (RadetScales.y_amax), the _a variants of the elementwise kernels, radet_absmax -- or
+ * store a bound they can derive before writing (GroupNorm: radet_gn_relu_fwd_q / _bwd_q).  The caller zeroes a slot
+ * before the first kernel of a step that raises it.  Host struct of device pointers: */
+typedef struct RadetScales {
+    const void* x_amax;    /* slot of the GEMM's x operand (dgrad: dy; wgrad: dy) */
+    const void* w_amax;    /* slot of the w operand (RadetConvDesc.w_amax; wgrad: the slot of x) */
+    void* y_amax;          /* slot raised to the largest |y| stored, or NULL (works with every arithmetic) */
+    const void* x1_amax;   /* the same for the second problem of a pair launch */
+    const void* w1_amax;
+    void* y1_amax;
+} RadetScales;
 
 /* Gather table of one conv geometry: table[tap][Mp] = input row feeding (output row m, tap) or -1 (padding /
  * stride hole); Mp = radet_gather_table_rows(M).  Forward / wgrad: (so, sr, off, div) = (stride, 1, -pad, 1) with
@@ -83,6 +107,26 @@ int radet_conv2d_igemm(const float* x, const float* w, const float* bias, const 
                        float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
                        int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream);
 /* Two independent convolutions of identical geometry (cls / reg tower layers of the shared head) in ONE launch */
+/* ... with amax slots: tile_override +0x8000000 (together with 0x1000000: fp32 tensors split in registers, tiles 1-4, 7, 8;
+ * or with 0x2000000: operands arrive as fp16 plane pairs, tiles 5 / 6) selects the fp16 hi / lo arithmetic described at
+ * RadetScales; x_amax and w_amax are required then.  y_amax alone may be used with any arithmetic. */
+int radet_conv2d_igemm_s(const float* x, const float* w, const float* bias, const float* addend, const float* mask,
+                         float* y, const int* gather_table, int M, int Cin, int Cout, int KH, int KW, int relu,
+                         int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream, const RadetScales* sc);
+int radet_conv2d_igemm_pair_s(const float* x0, const float* w0, const float* bias0, const float* addend0,
+                              const float* mask0, float* y0, const float* x1, const float* w1, const float* bias1,
+                              const float* addend1, const float* mask1, float* y1, const int* gather_table, int M,
+                              int Cin, int Cout, int KH, int KW, int relu, int tile_override, float* splitk_ws,
+                              size_t splitk_ws_floats, void* stream, const RadetScales* sc);
+int radet_conv2d_igemm_taps_s(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                              const int* gather_table, const int* out_rows, const int* tap_ids_host, int ntaps, int kt_w,
+                              int M, int Cin, int Cout, int tile_override, float* splitk_ws, size_t splitk_ws_floats,
+                              void* stream, const RadetScales* sc);
+int radet_conv2d_igemm_classes_s(const float* x, const float* w, const float* addend, const float* mask, float* y,
+                                 const int* gather_table, const int* out_rows, const int* tap_ids_host,
+                                 const int* cls_ntaps, const int* cls_start, int ncls, int kt_w, int M, int Cin, int Cout,
+                                 int tile_override, float* splitk_ws, size_t splitk_ws_floats, void* stream,
+                                 const RadetScales* sc);
 int radet_conv2d_igemm_pair(const float* x0, const float* w0, const float* bias0, const float* addend0,
                             const float* mask0, float* y0, const float* x1, const float* w1, const float* bias1,
                             const float* addend1, const float* mask1, float* y1, const int* gather_table, int M, int Cin,
@@ -125,6 +169,13 @@ int radet_pred3x3_patch(const float* x, int Cin, const int* tiles_dev, int ntile
 int radet_conv2d_wgrad_splits(int M, int Cin, int Cout, int KH, int KW);
 int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                        int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream);
+/* ... with amax slots: flags +0x1000 = fp16 hi / lo arithmetic (see RadetScales; sc->x_amax = the slot of dy, sc->w_amax = the
+ * slot of x, both required): fp32 tensors split in registers with the one-tap tiles (bits 4-5, 7, 10-11 as for 0x100), or,
+ * with +0x200, dy rows [2][ld_dy] / x rows [2][Cin] fp16 plane pairs (3x3 convs, Cin % 32 == 0, ld_dy % 32 == 0:
+ * conv_wgrad9q_kernel, 128 output x 32 input channels x 9 taps per workgroup). */
+int radet_conv2d_wgrad_s(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
+                         int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream,
+                         const RadetScales* sc);
 /* Grouped wgrad: up to 32 independent weight-gradient GEMMs (one-tap kernel) in ONE launch -- the convs of a backbone
  * stage / of the neck, whose individual grids are too short to fill 256 CUs.  Each job = the arguments of
  * radet_conv2d_wgrad (host array; Cout and Cin multiples of the tile).  flags bit 0: bf16 math mode; bits 4-5 = 1:
@@ -203,6 +254,42 @@ int radet_convert_rows(const void* src, void* dst, size_t rows, int ncols, int s
  * resnet.py:260-299 / fpn.py:170-221 / atss_head.py:118-145.  C % 8 == 0, row strides in floats, % 4 == 0. */
 int radet_split_planes(const float* src, void* dst_planes, size_t rows, int C, int src_ld, void* stream);
 int radet_merge_planes(const void* src_planes, float* dst, size_t rows, int C, int dst_ld, void* stream);
+/* ---- fp16 plane pairs ("plane pairs"): the operand format of the fp16 hi / lo arithmetic for tensors that only conv GEMMs
+ * read.  A row of C channels (C % 32 == 0) is C / 32 groups of 128 bytes [hi x 32 | lo x 32] fp16 -- 4 bytes per element,
+ * one cache line per 32-channel K stage and row -- holding x 2^e split as described at RadetScales, e from the tensor's amax
+ * slot.  radet_split_pairs scales by the slot of src and copies the slot's bits to dst_amax; radet_merge_pairs is the
+ * inverse (tests / API boundary).  radet_conv2d_igemm_s (+0x8000000 + 0x2000000) and radet_conv2d_wgrad_s (0x1000 + 0x200)
+ * multiply them with three v_mfma_f32_32x32x16_f16 per K = 16 step and no operand work in their K loops. */
+int radet_split_pairs(const float* src, void* dst_pairs, size_t rows, int C, int src_ld, const void* src_amax, void* dst_amax,
+                      void* stream);
+int radet_merge_pairs(const void* src_pairs, float* dst, size_t rows, int C, int dst_ld, const void* amax, void* stream);
+/* GroupNorm + ReLU with plane-pair outputs.  forward: y (fp32, may be NULL; y_amax, may be NULL, is raised to its largest
+ * magnitude) and / or yq (plane pairs, may be NULL) scaled by the power of two of a bound on |y| that needs no pass over the
+ * data -- max|gamma| sqrt(n - 1) + max|beta| for the n values of a group -- which is stored to yq_amax; zhat_amax (may be
+ * NULL) is raised to the largest normalised magnitude.  backward: dz (fp32, may be NULL) and / or dzq (plane pairs) scaled by
+ * the bound rstd_max max|gamma| dy_amax (2 + zhat_max), stored to dzq_amax; dy_amax = the amax slot of dy (required with
+ * dzq), zhat_amax from the forward call (NULL: sqrt(n - 1)). */
+int radet_gn_relu_fwd_q(const float* z, const float* gamma, const float* beta, float* y, void* yq, float* stats,
+                        float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,
+                        void* stream, void* y_amax, void* yq_amax, void* zhat_amax);
+int radet_gn_relu_fwd_pair_q(const float* z0, const float* gamma0, const float* beta0, float* y0, void* yq0, float* stats0,
+                             float* partial_ws0, void* y_amax0, void* yq_amax0, void* zhat_amax0, const float* z1,
+                             const float* gamma1, const float* beta1, float* y1, void* yq1, float* stats1,
+                             float* partial_ws1, void* y_amax1, void* yq_amax1, void* zhat_amax1, int B, int C, int groups,
+                             float eps, int relu, const int* seg_desc, int nseg, void* stream);
+int radet_gn_relu_bwd_q(const float* dy, const float* z, const float* stats, const float* gamma, const float* beta, float* dz,
+                        void* dzq, float* dgamma, float* dbeta, float* partial_ws, int B, int C, int groups, int relu,
+                        const int* seg_desc, int nseg, void* stream, const void* dy_amax, const void* zhat_amax,
+                        void* dzq_amax);
+/* Elementwise kernels that also raise the amax slot of the tensor they write (not reset here), and a stand-alone pass for
+ * tensors whose producer does not (n % 4 == 0). */
+int radet_maxpool3x3s2_a(const float* x, float* y, int B, int H, int W, int C, void* y_amax, void* stream);
+int radet_upsample_add_a(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* dst_amax,
+                         void* stream);
+int radet_upsample_add_bwd_a(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* dsrc_amax,
+                             void* stream);
+int radet_relu_bwd_a(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* dx_amax, void* stream);
+int radet_absmax(const float* x, size_t n, void* amax, void* stream);
 /* GroupNorm + ReLU with plane outputs: y / dz as fp32 (may be NULL) and / or as planes (yp / dzp, may be NULL) */
 int radet_gn_relu_fwd_p(const float* z, const float* gamma, const float* beta, float* y, void* yp, float* stats,
                         float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,

@@ -22,7 +22,12 @@ class RadetConvDesc(C.Structure):
                 ("wf", _p), ("wft", _p), ("bias_f", _p), ("dwf_slabs", _p), ("dbias_partials", _p),
                 ("dw", _p), ("dbias", _p), ("dgamma", _p), ("dbeta", _p),
                 ("cout", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("nsplit", _i), ("eps", _f),
-                ("wft_ld", _i), ("wft_off", _i), ("w16", _i)]
+                ("wft_ld", _i), ("wft_off", _i), ("w16", _i), ("w_amax", _p)]
+
+
+class RadetScales(C.Structure):
+    """Mirror of `struct RadetScales` (include/radet_hip.h): amax slots of the fp16 hi / lo arithmetic (device pointers)."""
+    _fields_ = [("x_amax", _p), ("w_amax", _p), ("y_amax", _p), ("x1_amax", _p), ("w1_amax", _p), ("y1_amax", _p)]
 
 
 class RadetWgradJob(C.Structure):
@@ -39,6 +44,21 @@ SIGNATURES = {
     "radet_conv2d_igemm_pair": (_i, [_p] * 13 + [_i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "radet_conv2d_igemm_taps": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "radet_conv2d_igemm_classes": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "radet_conv2d_igemm_s": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "radet_conv2d_igemm_pair_s": (_i, [_p] * 13 + [_i, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "radet_conv2d_igemm_taps_s": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "radet_conv2d_igemm_classes_s": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "radet_conv2d_wgrad_s": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "radet_split_pairs": (_i, [_p, _p, _sz, _i, _i, _p, _p, _p]),
+    "radet_merge_pairs": (_i, [_p, _p, _sz, _i, _i, _p, _p]),
+    "radet_gn_relu_fwd_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p, _p]),
+    "radet_gn_relu_fwd_pair_q": (_i, [_p] * 20 + [_i, _i, _i, _f, _i, _p, _i, _p]),
+    "radet_gn_relu_bwd_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "radet_maxpool3x3s2_a": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "radet_upsample_add_a": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "radet_upsample_add_bwd_a": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "radet_relu_bwd_a": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
+    "radet_absmax": (_i, [_p, _sz, _p, _p]),
     "radet_pred3x3_patch": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -149,6 +169,8 @@ _FN = {}
 def call(name, *args):
     fn = _FN.get(name)
     if fn is None:
+        if name not in SIGNATURES:             # without argtypes ctypes would pass device pointers as 32-bit ints
+            raise RadetHipError(f"{name} has no entry in radet_amd._lib.SIGNATURES")
         fn = _FN[name] = getattr(load(), name)
     rc = fn(*args)
     if rc != 0:

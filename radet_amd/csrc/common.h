@@ -125,3 +125,73 @@ __device__ __forceinline__ float4 ld4_planes(const __bf16* p, size_t row, int C,
     r.w = (__uint_as_float(h.y & 0xFFFF0000u) + __uint_as_float(m.y & 0xFFFF0000u)) + __uint_as_float(l.y & 0xFFFF0000u);
     return r;
 }
+
+// ---- fp16 plane pairs ("h2", round 5): an fp32 value x of a tensor whose largest magnitude is known (or bounded) by `amax`
+// is stored / fed to the matrix cores as TWO fp16 numbers  hi = fp16(t),  lo = fp16((t - hi) * 2^11),  t = x * 2^e,
+// e = radet_h2_exp(amax) (an exact power-of-two scale that puts the largest |t| into [2^14, 2^15): hi never overflows).
+// Both conversions round to nearest even; t - hi is exact in fp32, so x = 2^-e (hi + 2^-11 lo) up to the rounding of lo:
+// <= 2^-23 |x| for every element within 2^-28 of the tensor's largest (hi normal); smaller elements keep an ABSOLUTE
+// error of 2^-36 2^-e, i.e. 2^-51 of the largest element.  A product of two such numbers is formed as
+// hi hi' + 2^-11 (hi lo' + lo hi') -- three v_mfma_f32_32x32x16_f16 into two fp32 accumulators instead of the six bf16
+// plane products of the round-2 scheme; the dropped lo lo' term is <= 2^-24 relative.  `amax` lives in a 4-byte device slot
+// next to the tensor: fp32 tensors get theirs from the producing kernel's epilogue (atomicMax of |y| bit patterns, order
+// independent), plane tensors from a bound their producer computes before it writes (GroupNorm), see DESIGN.md 3.
+__host__ __device__ __forceinline__ int radet_h2_exp(unsigned amax_bits) {
+    const int ex = (int)((amax_bits >> 23) & 0xFFu);          // biased exponent of the largest magnitude
+    if (ex == 0 || ex == 255) return 0;                       // all zero (or denormal) / not finite: no scaling
+    const int e = 141 - ex;                                   // 14 - (ex - 127)
+    return e > 100 ? 100 : e;                                 // (2^(e + 11) must stay a normal float)
+}
+__host__ __device__ __forceinline__ float radet_pow2(int e) {           // -126 <= e <= 127
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float((unsigned)(e + 127) << 23);
+#else
+    union { unsigned u; float f; } c; c.u = (unsigned)(e + 127) << 23; return c.f;
+#endif
+}
+// two values -> packed (hi0 | hi1 << 16), (lo0 | lo1 << 16); s = 2^e, s2 = 2^(e + 11).  3 VALU operations per element:
+// v_mul (u = x s2), v_fma_mixlo/hi_f16 (hi = fp16(x s)), v_fma_mixlo/hi_f16 (lo = fp16(u - 2048 hi): one rounding)
+__device__ __forceinline__ void radet_split2(float x0, float x1, float s, float s2, unsigned& hi, unsigned& lo) {
+    const float u0 = x0 * s2, u1 = x1 * s2;
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x0), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x1), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(-2048.0f), "v"(u0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "s"(-2048.0f), "v"(u1));
+    hi = h;
+    lo = l;
+}
+// the value a pair stands for, in units of 2^-e: hi + lo / 2048 (exact in fp32: 11 + 11 significand bits)
+__device__ __forceinline__ float radet_pair_value(unsigned short hi, unsigned short lo) {
+    return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo) * (1.0f / 2048.0f);
+}
+// A row of C channels (C % 32 == 0) is C / 32 groups of 128 bytes: [hi of 32 channels | lo of 32 channels] -- one cache
+// line per 32-channel K stage and row, 4 bytes per element like the fp32 tensor it replaces.
+__host__ __device__ __forceinline__ size_t radet_pair_off(int c) {       // element offset of channel c's hi value in its row
+    return (size_t)(c >> 5) * 64 + (c & 31);                              // (lo: + 32)
+}
+__device__ __forceinline__ void st4_pairs(_Float16* p, size_t row, int C, int col4, const float4 v, float s, float s2) {
+    unsigned h0, l0, h1, l1;
+    radet_split2(v.x, v.y, s, s2, h0, l0);
+    radet_split2(v.z, v.w, s, s2, h1, l1);
+    uint2* q = reinterpret_cast<uint2*>(p + row * 2 * (size_t)C + radet_pair_off(col4 * 4));
+    q[0] = make_uint2(h0, h1);
+    q[8] = make_uint2(l0, l1);
+}
+__device__ __forceinline__ float4 ld4_pairs(const _Float16* p, size_t row, int C, int col4, float inv_s) {
+    const uint2* q = reinterpret_cast<const uint2*>(p + row * 2 * (size_t)C + radet_pair_off(col4 * 4));
+    const uint2 h = q[0], l = q[8];
+    float4 r;
+    r.x = radet_pair_value((unsigned short)(h.x & 0xFFFFu), (unsigned short)(l.x & 0xFFFFu)) * inv_s;
+    r.y = radet_pair_value((unsigned short)(h.x >> 16), (unsigned short)(l.x >> 16)) * inv_s;
+    r.z = radet_pair_value((unsigned short)(h.y & 0xFFFFu), (unsigned short)(l.y & 0xFFFFu)) * inv_s;
+    r.w = radet_pair_value((unsigned short)(h.y >> 16), (unsigned short)(l.y >> 16)) * inv_s;
+    return r;
+}
+// largest magnitude seen by this wave -> the tensor's amax slot (bit patterns of non-negative floats order like unsigned
+// integers; atomicMax is order independent, so the slot's final value -- and with it every scale derived from it -- is
+// the same in every run).  One atomic per wave.
+__device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}

@@ -19,6 +19,12 @@ struct ConvPtrs {
     const float* addend;  // [M][Cout] or null (added before relu / mask)
     const float* mask;    // [M][Cout] or null: out = mask > 0 ? out : 0   (ReLU backward)
     float* y;             // [M][Cout]
+    // fp16 hi / lo arithmetic (common.h "h2"): amax slots of x and w (bit pattern of the largest magnitude, or of a bound on
+    // it; the operands are scaled by 2^radet_h2_exp(slot) before they are split / were scaled when their planes were written)
+    // and the slot this launch raises to the largest |y| it stores (null: not tracked)
+    const unsigned* xs;
+    const unsigned* ws;
+    unsigned* ys;
 };
 
 struct ConvArgs {
@@ -148,6 +154,7 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     const bool has_add = P.addend != nullptr, has_mask = P.mask != nullptr, has_rows = a.out_rows != nullptr;   // uniform
     const bool interior = !has_rows && m0 + BM <= a.M && n0 + BN <= a.Cout;                                        // uniform
+    float amax = 0.f;                                            // largest |y| this lane stores (P.ys: the tensor's amax slot)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         size_t obase[16];
@@ -200,13 +207,21 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
             if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                if (P.ys) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(out[r]));
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (cvalid && rvalid[r]) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                    if (cvalid && rvalid[r]) {
+                        st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                        amax = fmaxf(amax, fabsf(out[r]));
+                    }
             }
         }
     }
+    if (P.ys) radet_amax_publish(amax, P.ys);                      // (uniform branch; one atomicMax per wave)
 }
 
 // Split episodes (split-K over the whole grid, or the K-split left-over tiles of a tail split) are reduced INSIDE the
@@ -421,3 +436,51 @@ __device__ __forceinline__ void mfma_x3(f32x16& acc, const bf16x8& ah, const bf1
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
 }
 
+
+// ---- fp16 hi / lo arithmetic (common.h "h2"): fp32-accurate products from TWO fp16 planes per operand, three
+// v_mfma_f32_32x32x16_f16 per K = 16 step and accumulator pair instead of the six bf16 plane products above.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct H2Scale {              // of one operand tensor: s = 2^e, s2 = 2^(e + 11), inv = 2^-e
+    float s, s2, inv;
+};
+__device__ __forceinline__ H2Scale h2_scale(const unsigned* slot) {
+    const int e = radet_h2_exp(__builtin_nontemporal_load(slot));
+    H2Scale r;
+    r.s = radet_pow2(e); r.s2 = radet_pow2(e + 11); r.inv = radet_pow2(-e);
+    return r;
+}
+// 8 k values of one lane -> the hi and lo operands of v_mfma_f32_32x32x16_f16 (24 VALU operations; split3_bf16: 44)
+__device__ __forceinline__ void split2_f16(const float (&a)[8], const H2Scale& sc, f16x8& hi, f16x8& lo) {
+    u32x4_ h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned hq, lq;
+        radet_split2(a[2 * q], a[2 * q + 1], sc.s, sc.s2, hq, lq);
+        h[q] = hq; l[q] = lq;
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+__device__ __forceinline__ void split2_f16(const f32x4& f0, const f32x4& f1, const H2Scale& sc, f16x8& hi, f16x8& lo) {
+    const float a[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    split2_f16(a, sc, hi, lo);
+}
+// acc0 += hi hi', acc1 += hi lo' + lo hi' (the scaled lo planes carry a factor 2^11: see h2_combine)
+__device__ __forceinline__ void mfma_h2(f32x16& acc0, f32x16& acc1, const f16x8& ah, const f16x8& al, const f16x8& bh,
+                                        const f16x8& bl) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
+}
+// the product in the operands' own units: (acc0 + 2^-11 acc1) 2^-ea 2^-eb (two multiplications: either factor alone is a
+// normal float, their product need not be)
+__device__ __forceinline__ void h2_combine(f32x16& acc0, const f32x16& acc1, float inv_a, float inv_b) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = (fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) * inv_a) * inv_b;
+}
+
+// ---- launchers of the fp16 hi / lo instantiations (conv_h2.hip: their own translation unit, compiled next to conv_igemm.hip)
+bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
+                           bool no_tail_split);
+struct WgradArgs;
+int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStream_t st);

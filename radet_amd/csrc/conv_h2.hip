@@ -1,0 +1,279 @@
+// fp16 hi / lo arithmetic (common.h "h2", round 5): the instantiations of the implicit-GEMM / weight-gradient templates that
+// form fp32-accurate products from TWO fp16 planes per operand -- three v_mfma_f32_32x32x16_f16 per K = 16 step into an
+// accumulator pair, instead of the six bf16 plane products of the round-2 scheme -- plus the all-taps weight gradient on
+// fp16 plane pairs.  A translation unit of its own so that it compiles next to conv_igemm.hip.  gfx950 only.
+// Replaces cuDNN behind radet/models/backbones/resnet.py:260-299, necks/fpn.py:170-221, dense_heads/atss_head.py:118-145.
+#include "common.h"
+#include "../../include/radet_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#include "conv_igemm_kernel.h"
+#include "conv_wgrad_kernel.h"
+
+// ------------------------------------------------------------------------------------------ implicit GEMM
+// tag = 64 | 8 (fp32 operands split in registers, K step 32) [| 32: K-divided 64 x 64 tiles], or 64 | 16 (operands arrive
+// as fp16 plane pairs, K step 32 channels); bit 0: profiling symbol.
+template <int BM, int BN, int WM, int WN, int KIND>      // KIND 0: in-register split, 1: K-divided, 2: plane pairs
+static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, size_t ws_floats, int stages, bool no_tail_split) {
+    ConvArgs a = a_in;
+    const int tiles = igemm_plan<BM, BN>(a, tag, bk, ws_floats, 0, no_tail_split);
+    constexpr int NT = WM * WN * 64;
+#define RADET_H2(TAGV, BKV, NSV) \
+    hipLaunchKernelGGL((conv_igemmg_kernel<BM, BN, WM, WN, TAGV, BKV, NSV>), dim3(tiles, a.sk), dim3(NT), 0, st, a)
+    if constexpr (KIND == 0) {
+        if (stages >= 3) { if (tag & 1) RADET_H2(73, 32, 3); else RADET_H2(72, 32, 3); }
+        else { if (tag & 1) RADET_H2(73, 32, 2); else RADET_H2(72, 32, 2); }
+    } else if constexpr (KIND == 1) {
+        if (bk == 64) { if (tag & 1) RADET_H2(105, 64, 2); else RADET_H2(104, 64, 2); }
+        else { if (tag & 1) RADET_H2(105, 32, 2); else RADET_H2(104, 32, 2); }
+    } else {
+        constexpr int STG = 2 * (BM + BN) * 16 * 4;                  // LDS bytes per stage: two planes x 64 bytes per tile row
+        if constexpr (3 * STG <= 160 * 1024) {
+            if (stages >= 3) { if (tag & 1) RADET_H2(81, 16, 3); else RADET_H2(80, 16, 3); return; }
+        }
+        if (tag & 1) RADET_H2(81, 16, 2); else RADET_H2(80, 16, 2);
+    }
+#undef RADET_H2
+}
+
+bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
+                           bool no_tail_split) {
+    if (tag & 16) {                                                  // plane pairs: the 8-wave tiles
+        switch (choice) {
+            case 5: launch_h2<128, 128, 2, 4, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+            case 6: launch_h2<256, 128, 4, 2, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+            default: return false;
+        }
+    }
+    switch (choice) {
+        case 1: launch_h2<128, 128, 2, 2, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+        case 2: launch_h2<128, 64, 2, 2, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+        case 3: launch_h2<64, 64, 2, 2, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+        case 4: launch_h2<128, 32, 4, 1, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
+        case 7: case 8: launch_h2<64, 64, 2, 2, 1>(a, st, tag, bk, ws_floats, 2, no_tail_split); return true;
+        default: return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, fp16 plane pairs
+// dW[o, tap, c] = sum_m dy[m, o] x[g(m, tap), c] with dy rows [2][ld_dy] and x rows [2][Cin] fp16 (32-channel groups
+// [hi x 32 | lo x 32], written once by the GroupNorm kernels / radet_split_pairs).  conv_wgrad9p_kernel's data path
+// ([4 pixels][16 channels] sub-tiles by LDS-DMA, ds_read_b64_tr_b16 operands) with two planes instead of three and an
+// accumulator PAIR per tap: 18 accumulator blocks do not fit the registers of a wave that owns all nine taps of a 32 x 32
+// block (8 waves = 256 registers each), so a workgroup owns 128 output x 32 input channels and a 32-channel output group is
+// shared by TWO waves, taps 0-4 and 5-8 (160 / 128 accumulator registers).  Per 16-pixel stage: 8 KiB of dy + 18 KiB of x by
+// LDS-DMA, 15 / 12 MFMAs per wave between barriers.
+__global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
+    constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
+    constexpr int CBA = BM / 16, CBB = BC / 16;
+    constexpr int A_PL = BP * BM, B_PL = BP * BC;           // fp16 elements per dy plane tile / per (tap, plane) x tile
+    constexpr int A_Q = A_PL * 2 / 1024;                    // wave loads per dy plane tile: 4
+    constexpr int A_INSTR = 2 * A_Q;                        // 8
+    constexpr int B_INSTR = KT * 2;                         // 18: one wave load per (tap, plane)
+    constexpr int N_INSTR = A_INSTR + B_INSTR;              // 26
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 4
+    static_assert(B_PL * 2 == 1024, "one wave load per x tile");
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][2 * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KT * 2 * B_PL];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = wave & 3, tg = wave >> 2;                // output-channel group, tap group (0: taps 0-4, 1: taps 5-8)
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    // XCD-aware order: the channel tiles of one pixel split run next to each other on ONE XCD (conv_wgrad9p_kernel)
+    int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    // x-tile load bi = tap * 2 + plane: the 8 sub-tiles [4 pixel quads][2 channel blocks] of that tap and plane
+    int brow[PER_WAVE];
+    bool bok[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        bok[k] = false;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int m = p_begin + 4 * (l_blk / CBB) + l_prow;
+            brow[k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+            bok[k] = m < p_end;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
+                const void* src = (bok[k] && brow[k] >= 0)
+                                      ? (const void*)(xh + (size_t)brow[k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2))
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * B_PL]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
+                const int m = p0 + 4 * (blk / CBA) + l_prow;
+                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+                const void* src = (m < p_end && o < a.Cout)
+                                      ? (const void*)(dyh + (size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl)
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int m = p0 + BP + 4 * (l_blk / CBB) + l_prow;
+                brow[k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[k] = m < p_end;
+            }
+        }
+    };
+
+    constexpr int NTAP = 5;                                  // accumulator pairs per wave (tap group 1 leaves the last one idle)
+    f32x16 acc[NTAP], acc1[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acc1[t][r] = 0.f; }
+    const H2Scale sdy = h2_scale(a.dys), sxx = h2_scale(a.xss);
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    const int tap0 = tg * 5, ntap = tg ? 4 : 5;
+    // per-lane LDS byte addresses of the (inline-asm) transposing reads, see conv_wgradh: pixel quad 2 lh (+ 1), channel
+    // sub-tile of the wave's 32 channels + g16, bytes 8 m16 of the sub-tile
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + og * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + g16) * 128 + m16 * 8) +
+                           (unsigned)(tap0 * 2 * B_PL * 2);
+
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        const unsigned ab = a_thr + (unsigned)buf * (2 * A_PL * 2), bb = b_thr + (unsigned)buf * (KT * 2 * B_PL * 2);
+        s16x4v_ al[2], ah[2], bl[2][2], bh[2][2];
+        static_for<0, 2>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * A_PL * 2>(al[pl], ab);
+            lds_read_tr16<pl * A_PL * 2 + CBA * 128>(ah[pl], ab);
+        });
+        static_for<0, 2>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * B_PL * 2>(bl[0][pl], bb);
+            lds_read_tr16<pl * B_PL * 2 + CBB * 128>(bh[0][pl], bb);
+        });
+        f16x8 af[2];
+        static_for<0, NTAP>([&](auto tc_) {
+            constexpr int t = decltype(tc_)::value, pp = t & 1;
+            if (t < ntap) {                                      // uniform per wave
+                if (t + 1 < ntap) {
+                    if constexpr (t + 1 < NTAP) {
+                        static_for<0, 2>([&](auto pc) {
+                            constexpr int pl = decltype(pc)::value;
+                            lds_read_tr16<((t + 1) * 2 + pl) * B_PL * 2>(bl[pp ^ 1][pl], bb);
+                            lds_read_tr16<((t + 1) * 2 + pl) * B_PL * 2 + CBB * 128>(bh[pp ^ 1][pl], bb);
+                        });
+                    }
+                    lds_wait<4>();
+                } else {
+                    lds_wait<0>();
+                }
+                if constexpr (t == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        asm volatile("" : "+v"(al[pl])); asm volatile("" : "+v"(ah[pl]));
+                        af[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(al[pl], ah[pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                }
+                f16x8 bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    asm volatile("" : "+v"(bl[pp][pl])); asm volatile("" : "+v"(bh[pp][pl]));
+                    bf[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(bl[pp][pl], bh[pp][pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
+            const int cb = tid >> 4, cc = tid & 15;
+            const unsigned short* ap = &As[buf][0];
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
+                bsum += radet_pair_value(ap[e], ap[A_PL + e]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum * sdy.inv;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        if (t < ntap) {
+            h2_combine(acc[t], acc1[t], sdy.inv, sxx.inv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + og * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < a.Cout) out[((size_t)o * KT + tap0 + t) * a.Cin + c] = acc[t][r];
+            }
+        }
+    }
+}
+
+// the h2 weight-gradient launches behind radet_conv2d_wgrad_s: flags 0x1000 (fp32 tensors, split in registers: the one-tap
+// tiles; bits 4-5 / 7 / 10-11 select tile / 32-pixel stages / pixel-divided tiles as for the bf16-plane arithmetic) or
+// 0x1000 | 0x200 (fp16 plane pairs: the all-taps kernel above)
+int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStream_t st) {
+    if (flags & 0x200) {
+        if ((a.ld_dy & 31) || (a.Cin & 31) || a.KH != 3 || a.KW != 3) return RADET_ERR_ARG;
+        const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
+        hipLaunchKernelGGL(conv_wgrad9q_kernel, dim3(tiles9), dim3(512), 0, st, a);
+        return radet_check_launch();
+    }
+    const int KT = a.KH * a.KW;
+    if (bm == 64 && (flags & 0xC00)) {
+        const int tiles = ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64) * KT * a.S;
+        if (flags & 0x400) hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 64, 4>), dim3(tiles), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 32, 2>), dim3(tiles), dim3(256), 0, st, a);
+        return radet_check_launch();
+    }
+    const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * KT * a.S;
+#define RADET_WG_H2(BMV, BNV, WMV, WNV) \
+    do { if (a.bp32 && BMV >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3, 32>), dim3(tiles), dim3(256), 0, st, a); \
+         else hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3>), dim3(tiles), dim3(256), 0, st, a); } while (0)
+    if (bm == 32) RADET_WG_H2(32, 128, 1, 4);
+    else if (bm == 64) RADET_WG_H2(64, 64, 2, 2);
+    else if (bn == 64) RADET_WG_H2(128, 64, 2, 2);
+    else RADET_WG_H2(128, 128, 2, 2);
+#undef RADET_WG_H2
+    return radet_check_launch();
+}

@@ -161,7 +161,8 @@ extern "C" int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_
 // ------------------------------------------------------------------------------------------ maxpool
 template <class T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C4,
-                               int Ho, int Wo) {
+                               int Ho, int Wo, unsigned* amax = nullptr) {
+    float am = 0.f;                          // largest |y| stored by this thread (amax: the output's h2 slot, common.h)
     // one thread = TWO horizontally adjacent outputs of one channel quad: their 3 x 3 windows share a column, 15 loads
     // instead of 18 (all unconditional: an out-of-range tap is clamped onto the border pixel, which is inside the window
     // already -- max is idempotent -- instead of skipped: a skipped load is a branch and a wait per tap)
@@ -199,17 +200,26 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
                     m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
                 }
             st4(y, ((size_t)(n * Ho + oy) * Wo + ox + h) * C4 + c, m);
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(m.x), fabsf(m.y))), fmaxf(fabsf(m.z), fabsf(m.w)));
         }
     }
+    if (amax) radet_amax_publish(am, amax);
 }
 
-extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+// _a variants (this one and radet_upsample_add_a / _bwd_a, radet_relu_bwd_a below): the same kernels, which also raise the
+// output tensor's amax slot (4 bytes, device) to the largest magnitude they store -- the scale source of the fp16 hi / lo
+// conv arithmetic (common.h "h2").  The slot is NOT reset here.
+extern "C" int radet_maxpool3x3s2_a(const float* x, float* y, int B, int H, int W, int C, void* y_amax, void* stream) {
     if (C % 4) return RADET_ERR_ARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4, Ho, Wo,
+                       (unsigned*)y_amax);
     return radet_check_launch();
+}
+extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    return radet_maxpool3x3s2_a(x, y, B, H, W, C, nullptr, stream);
 }
 
 extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream) {
@@ -364,8 +374,14 @@ extern "C" int radet_stem_wgrad(const float* img_nchw, const float* ds, float* s
 #define FOLD_TC 32
 // folded weight store: element `col` of row `row` (row length ld): fp32, bf16 (w16 = 1) or bf16 plane triple (w16 = 2:
 // rows of ld / 32 groups [hi | mid | lo] x 32 channels, see common.h; ld % 32 == 0)
-__device__ __forceinline__ void stw(float* p, size_t row, int col, int ld, float v, int w16) {
-    if (w16 == 2) {
+__device__ __forceinline__ void stw(float* p, size_t row, int col, int ld, float v, int w16, float s = 1.f, float s2 = 2048.f) {
+    if (w16 == 3) {                       // fp16 plane pair (common.h "h2"), scaled by the conv's power of two
+        unsigned h, l;
+        radet_split2(v, 0.f, s, s2, h, l);
+        unsigned short* q = reinterpret_cast<unsigned short*>(p) + row * 2 * (size_t)ld + radet_pair_off(col);
+        q[0] = (unsigned short)(h & 0xFFFFu);
+        q[32] = (unsigned short)(l & 0xFFFFu);
+    } else if (w16 == 2) {
         const unsigned h = __float_as_uint(v) & 0xFFFF0000u;
         const float r = v - __uint_as_float(h);
         const unsigned m = __float_as_uint(r) & 0xFFFF0000u;
@@ -383,6 +399,11 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
     __shared__ float tile[FOLD_TO][FOLD_TC * 9 + 1];
     __shared__ float ssc[FOLD_TO];
     const int tid = threadIdx.x;
+    float ps = 1.f, ps2 = 2048.f;           // w16 = 3: the power-of-two scale of this conv's plane pairs (fold_amax_kernel ran before)
+    if (d.w16 == 3) {
+        const int e = radet_h2_exp(*reinterpret_cast<const unsigned*>(d.w_amax));
+        ps = radet_pow2(e); ps2 = radet_pow2(e + 11);
+    }
     if (KT > 9) {   // 7x7 stem: small, keep the simple element-wise path
         const size_t total = (size_t)d.cout * d.cin * KT;
         for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
@@ -393,8 +414,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             float s = 1.f;
             if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
             const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
-            stw(d.wf, oc, c, d.cin, v, d.w16);
-            if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16);
+            stw(d.wf, oc, c, d.cin, v, d.w16, ps, ps2);
+            if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16, ps, ps2);
         }
     } else {
         const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + FOLD_TC - 1) / FOLD_TC;
@@ -432,14 +453,14 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             for (int i = tid; i < no * run; i += 256) {
                 const int oo = i / run, r = i - oo * run;
                 const int t = r / nc, cl = r - t * nc;
-                stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, tile[oo][cl * KT + t] * ssc[oo], d.w16);
+                stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, tile[oo][cl * KT + t] * ssc[oo], d.w16, ps, ps2);
             }
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
                 for (int i = tid; i < no * run; i += 256) {
                     const int oo = i % no, r = i / no;      // r = cl*KT + t
                     const int cl = r / KT, t = r - cl * KT;
-                    stw(d.wft, (size_t)(c0 + cl) * KT + t, d.wft_off + o0 + oo, ld_t, tile[oo][r] * ssc[oo], d.w16);
+                    stw(d.wft, (size_t)(c0 + cl) * KT + t, d.wft_off + o0 + oo, ld_t, tile[oo][r] * ssc[oo], d.w16, ps, ps2);
                 }
             }
         }
@@ -456,8 +477,33 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
     }
 }
 
+// amax slots of the folded weights (RadetConvDesc.w_amax, optional): largest |s[o] w[o][c][t]| of each conv -- the scale of
+// the fp16 hi / lo arithmetic's weight operand (common.h "h2"; wf and wft hold the same values).  Zeroed, then raised by
+// atomicMax (order independent), before fold_kernel writes the plane pairs of the w16 = 3 convs with it.
+__global__ void fold_amax_zero_kernel(const RadetConvDesc* __restrict__ table, int nconv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nconv && table[i].w_amax) *reinterpret_cast<unsigned*>(table[i].w_amax) = 0u;
+}
+__global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __restrict__ table) {
+    const RadetConvDesc d = table[blockIdx.y];
+    if (d.w_amax == nullptr) return;
+    const int K = d.cin * d.kh * d.kw;                         // OIHW: K contiguous weights per output channel
+    float m = 0.f;
+    for (int o = blockIdx.x; o < d.cout; o += gridDim.x) {
+        float s = 1.f;
+        if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+        const float* w = d.w + (size_t)o * K;
+        float mo = 0.f;
+        for (int k = threadIdx.x; k < K; k += 256) mo = fmaxf(mo, fabsf(w[k] * s));       // (the product fold_kernel stores)
+        m = fmaxf(m, mo);
+    }
+    radet_amax_publish(m, reinterpret_cast<unsigned*>(d.w_amax));
+}
+
 extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {
     if (nconv <= 0) return RADET_OK;
+    hipLaunchKernelGGL(fold_amax_zero_kernel, dim3((nconv + 255) / 256), dim3(256), 0, (hipStream_t)stream, table_dev, nconv);
+    hipLaunchKernelGGL(fold_amax_kernel, dim3(32, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     hipLaunchKernelGGL(fold_kernel, dim3(96, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     return radet_check_launch();
 }
@@ -600,6 +646,13 @@ struct GnFwdSet {
     T* y;             // may be null when yp is given
     float* stats;
     __bf16* yp;       // optional second output: y as bf16 plane triples (rows [3][256], common.h) for the conv GEMMs
+    // fp16 hi / lo arithmetic (common.h "h2"): yp holds fp16 plane PAIRS (rows [2][256]) scaled by the power of two of a BOUND
+    // on |y| that every block derives from gamma / beta alone (|zhat| <= sqrt(n - 1) for the n values of a group), written to
+    // yq_amax before any consumer runs; y_amax (fp32 output y) / zhat_amax are raised to the largest |y| / |zhat| seen
+    // (zeroed by the statistics kernel; zhat_amax bounds the backward pass's dz)
+    unsigned* yq_amax;
+    unsigned* y_amax;
+    unsigned* zhat_amax;
 };
 template <class T>
 struct GnFwdArgs {
@@ -612,6 +665,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnFwdArgs<T> args, 
     float* __restrict__ partial = args.p[blockIdx.y].partial;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {            // (the apply kernel, which raises them, starts after this kernel has finished)
+        if (args.p[blockIdx.y].y_amax) *args.p[blockIdx.y].y_amax = 0u;
+        if (args.p[blockIdx.y].zhat_amax) *args.p[blockIdx.y].zhat_amax = 0u;
+    }
     const int col = tid & 63, prow = tid >> 6;
     float s = 0.f, ss = 0.f;
     // 4 pixel rows per iteration, their loads issued together: left to the compiler the loop ran one 16-byte load
@@ -678,9 +735,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
     T* __restrict__ y = args.p[blockIdx.y].y;
     __bf16* __restrict__ yp = args.p[blockIdx.y].yp;
     float* __restrict__ stats = args.p[blockIdx.y].stats;
+    unsigned* const yq_amax = args.p[blockIdx.y].yq_amax;
+    unsigned* const y_amax = args.p[blockIdx.y].y_amax;
+    unsigned* const zhat_amax = args.p[blockIdx.y].zhat_amax;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ float sm[32], sr[32];
+    float qs = 1.f, qs2 = 2048.f;                  // plane pairs: 2^e, 2^(e + 11) of the bound on |y|
+    if (yq_amax) {
+        __shared__ float bnd[8];
+        const float g1 = wave_max(fabsf(gamma[tid])), b1 = wave_max(fabsf(beta[tid]));
+        if ((tid & 63) == 0) { bnd[tid >> 6] = g1; bnd[4 + (tid >> 6)] = b1; }
+        __syncthreads();
+        int nmax = 1;
+        for (int l = 0; l < segs.nseg; ++l) nmax = max(nmax, segs.s[l].Ho * segs.s[l].Wo * 8);
+        const float gmax = fmaxf(fmaxf(bnd[0], bnd[1]), fmaxf(bnd[2], bnd[3]));
+        const float bmax = fmaxf(fmaxf(bnd[4], bnd[5]), fmaxf(bnd[6], bnd[7]));
+        const unsigned bits = __float_as_uint(gmax * sqrtf((float)(nmax - 1)) + bmax);
+        if (blockIdx.x == 0 && tid == 0) *yq_amax = bits;
+        const int e = radet_h2_exp(bits);
+        qs = radet_pow2(e); qs2 = radet_pow2(e + 11);
+    }
+    float ymax = 0.f, zmax = 0.f;
     double s = 0.0, ss = 0.0;
     gn_reduce_partials(partial, c.part_base, c.nchunks_img, &s, &ss);
     if (tid < 32) {
@@ -717,9 +793,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
             r.w = (v.w - mean) * rstd * gm.w + bt.w;
             if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
             if (y) st4(y, (size_t)(c.row0 + p) * 64 + col, r);
-            if (yp) st4_planes(yp, (size_t)(c.row0 + p), 256, col, r);
+            if (yp) {
+                if (yq_amax) st4_pairs(reinterpret_cast<_Float16*>(yp), (size_t)(c.row0 + p), 256, col, r, qs, qs2);
+                else st4_planes(yp, (size_t)(c.row0 + p), 256, col, r);
+            }
+            ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf((v.x - mean) * rstd), fabsf((v.y - mean) * rstd))),
+                         fmaxf(fabsf((v.z - mean) * rstd), fabsf((v.w - mean) * rstd)));
         }
     }
+    if (y_amax) radet_amax_publish(ymax, y_amax);
+    if (zhat_amax) radet_amax_publish(zmax, zhat_amax);
     if (c.chunk_in_img == 0 && tid < 32) {
         // stats layout: [(seg, n)][32][2]; (seg, n) linear id = sum_{l<seg} B + n
         int lin = c.n;
@@ -732,7 +816,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
 template <class T>
 static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T* y, float* stats,
                             float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
-                            int nseg, void* stream, const GnFwdSet<T>* second = nullptr, __bf16* yp = nullptr) {
+                            int nseg, void* stream, const GnFwdSet<T>* second = nullptr, __bf16* yp = nullptr,
+                            unsigned* yq_amax = nullptr, unsigned* y_amax = nullptr, unsigned* zhat_amax = nullptr) {
     if (C != 256 || groups != 32 || (y == nullptr && yp == nullptr)) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
@@ -745,7 +830,7 @@ static int gn_relu_fwd_impl(const T* z, const float* gamma, const float* beta, T
     const int chunks = gn_total_chunks(segs, B);
     hipStream_t st = (hipStream_t)stream;
     GnFwdArgs<T> args;
-    args.p[0] = GnFwdSet<T>{z, partial_ws, gamma, beta, y, stats, yp};
+    args.p[0] = GnFwdSet<T>{z, partial_ws, gamma, beta, y, stats, yp, yq_amax, y_amax, zhat_amax};
     args.p[1] = second ? *second : args.p[0];
     const int sets = second ? 2 : 1;
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, sets), dim3(256), 0, st, args, segs, B);
@@ -802,6 +887,32 @@ extern "C" int radet_gn_relu_fwd_pair_p(const float* z0, const float* gamma0, co
     const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1, (__bf16*)yp1};
     return gn_relu_fwd_impl<float>(z0, gamma0, beta0, y0, stats0, partial_ws0, B, C, groups, eps, relu, seg_desc, nseg,
                                    stream, &second, (__bf16*)yp0);
+}
+
+// fp16 hi / lo arithmetic (common.h "h2"): fp32 in; outputs y (fp32, may be NULL; y_amax, may be NULL, is raised to its largest
+// magnitude) and / or yq (fp16 plane pairs, rows [2][256], may be NULL; yq_amax receives the bound on |y| whose power of two
+// scales them); zhat_amax (may be NULL) is raised to the largest |zhat| -- radet_gn_relu_bwd_q's bound on dz uses it.
+extern "C" int radet_gn_relu_fwd_q(const float* z, const float* gamma, const float* beta, float* y, void* yq, float* stats,
+                                   float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc,
+                                   int nseg, void* stream, void* y_amax, void* yq_amax, void* zhat_amax) {
+    if (yq != nullptr && yq_amax == nullptr) return RADET_ERR_ARG;
+    return gn_relu_fwd_impl<float>(z, gamma, beta, y, stats, partial_ws, B, C, groups, eps, relu, seg_desc, nseg, stream,
+                                   nullptr, (__bf16*)yq, yq ? (unsigned*)yq_amax : nullptr, (unsigned*)y_amax,
+                                   (unsigned*)zhat_amax);
+}
+extern "C" int radet_gn_relu_fwd_pair_q(const float* z0, const float* gamma0, const float* beta0, float* y0, void* yq0,
+                                        float* stats0, float* partial_ws0, void* y_amax0, void* yq_amax0, void* zhat_amax0,
+                                        const float* z1, const float* gamma1, const float* beta1, float* y1, void* yq1,
+                                        float* stats1, float* partial_ws1, void* y_amax1, void* yq_amax1, void* zhat_amax1,
+                                        int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,
+                                        void* stream) {
+    if ((y1 == nullptr && yq1 == nullptr) || (yq0 != nullptr && yq_amax0 == nullptr) || (yq1 != nullptr && yq_amax1 == nullptr))
+        return RADET_ERR_ARG;
+    const GnFwdSet<float> second{z1, partial_ws1, gamma1, beta1, y1, stats1, (__bf16*)yq1, yq1 ? (unsigned*)yq_amax1 : nullptr,
+                                 (unsigned*)y_amax1, (unsigned*)zhat_amax1};
+    return gn_relu_fwd_impl<float>(z0, gamma0, beta0, y0, stats0, partial_ws0, B, C, groups, eps, relu, seg_desc, nseg,
+                                   stream, &second, (__bf16*)yq0, yq0 ? (unsigned*)yq_amax0 : nullptr, (unsigned*)y_amax0,
+                                   (unsigned*)zhat_amax0);
 }
 
 extern "C" int radet_gn_workspace_floats(int B, const int* seg_desc, int nseg) {
@@ -891,10 +1002,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ gpart, T* __restrict__ dz,
                                                            __bf16* __restrict__ dzp, const RadetSegs segs, int B,
-                                                           int relu) {
+                                                           int relu, const unsigned* dy_amax = nullptr,
+                                                           const unsigned* zhat_amax = nullptr, unsigned* dzq_amax = nullptr) {
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ float m1s[32], m2s[32];
+    // fp16 plane pairs (dzq_amax given; common.h "h2"): every block derives the same bound on |dz| from quantities that are
+    // complete before this kernel starts -- |dz| = rstd |g gamma - m1 - zhat m2| <= rstd_max gamma_max dy_amax (2 + zhat_max),
+    // because |m1| <= gamma_max dy_amax and |m2| <= gamma_max dy_amax mean|zhat| <= gamma_max dy_amax -- and scales by its
+    // power of two; block 0 publishes the bound for the GEMMs that read the pairs
+    float qs = 1.f, qs2 = 2048.f;
+    if (dzq_amax) {
+        __shared__ float bnd[8];
+        int ngrp = 0;
+        for (int l = 0; l < segs.nseg; ++l) ngrp += B * 32;
+        float rmax = 0.f;
+        for (int i = tid; i < ngrp; i += 256) rmax = fmaxf(rmax, stats[(size_t)i * 2 + 1]);
+        rmax = wave_max(rmax);
+        const float g1 = wave_max(fabsf(gamma[tid]));
+        if ((tid & 63) == 0) { bnd[tid >> 6] = rmax; bnd[4 + (tid >> 6)] = g1; }
+        __syncthreads();
+        const float rstd_max = fmaxf(fmaxf(bnd[0], bnd[1]), fmaxf(bnd[2], bnd[3]));
+        const float gmax = fmaxf(fmaxf(bnd[4], bnd[5]), fmaxf(bnd[6], bnd[7]));
+        int nmax = 1;
+        for (int l = 0; l < segs.nseg; ++l) nmax = max(nmax, segs.s[l].Ho * segs.s[l].Wo * 8);
+        const float zh = zhat_amax ? __uint_as_float(*zhat_amax) : sqrtf((float)(nmax - 1));
+        const unsigned bits = __float_as_uint(rstd_max * gmax * __uint_as_float(*dy_amax) * (2.0f + zh));
+        if (blockIdx.x == 0 && tid == 0) *dzq_amax = bits;
+        const int e = radet_h2_exp(bits);
+        qs = radet_pow2(e); qs2 = radet_pow2(e + 11);
+    }
     double a = 0.0, b = 0.0;
     gn_reduce_partials(gpart, c.part_base, c.nchunks_img, &a, &b);
     if (tid < 32) {
@@ -941,7 +1078,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             r.z = rstd * (d.z * gm.z - m1 - xh.z * m2);
             r.w = rstd * (d.w * gm.w - m1 - xh.w * m2);
             if (dz) st4(dz, (size_t)(c.row0 + p) * 64 + col, r);
-            if (dzp) st4_planes(dzp, (size_t)(c.row0 + p), 256, col, r);      // plane triples for the dgrad / wgrad GEMMs
+            if (dzp) {                                                         // planes for the dgrad / wgrad GEMMs
+                if (dzq_amax) st4_pairs(reinterpret_cast<_Float16*>(dzp), (size_t)(c.row0 + p), 256, col, r, qs, qs2);
+                else st4_planes(dzp, (size_t)(c.row0 + p), 256, col, r);
+            }
         }
     }
 }
@@ -982,7 +1122,8 @@ template <class T>
 static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const float* gamma,
                             const float* beta, T* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
                             int C, int groups, int relu, const int* seg_desc, int nseg, void* stream,
-                            __bf16* dzp = nullptr) {
+                            __bf16* dzp = nullptr, const unsigned* dy_amax = nullptr, const unsigned* zhat_amax = nullptr,
+                            unsigned* dzq_amax = nullptr) {
     if (C != 256 || groups != 32 || (dz == nullptr && dzp == nullptr)) return RADET_ERR_ARG;
     RadetSegs segs;
     if (nseg < 1 || nseg > RADET_MAX_SEG) return RADET_ERR_ARG;
@@ -999,7 +1140,7 @@ static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const f
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
                        segs, B, relu);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, dzp,
-                       segs, B, relu);
+                       segs, B, relu, dy_amax, zhat_amax, dzq_amax);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(32), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
 }
@@ -1019,6 +1160,19 @@ extern "C" int radet_gn_relu_bwd_p(const float* dy, const float* z, const float*
                                    nseg, stream, (__bf16*)dzp);
 }
 
+// fp16 hi / lo arithmetic: dz as fp32 (may be NULL) and / or fp16 plane pairs dzq (rows [2][256]) scaled by the power of two of
+// a bound on |dz| built from dy_amax (the amax slot of dy, required with dzq), zhat_amax (from radet_gn_relu_fwd_q; NULL: the
+// hard bound sqrt(n - 1)) and the forward statistics; the bound is written to dzq_amax
+extern "C" int radet_gn_relu_bwd_q(const float* dy, const float* z, const float* stats, const float* gamma,
+                                   const float* beta, float* dz, void* dzq, float* dgamma, float* dbeta, float* partial_ws,
+                                   int B, int C, int groups, int relu, const int* seg_desc, int nseg, void* stream,
+                                   const void* dy_amax, const void* zhat_amax, void* dzq_amax) {
+    if (dzq != nullptr && (dy_amax == nullptr || dzq_amax == nullptr)) return RADET_ERR_ARG;
+    return gn_relu_bwd_impl<float>(dy, z, stats, gamma, beta, dz, dgamma, dbeta, partial_ws, B, C, groups, relu, seg_desc,
+                                   nseg, stream, (__bf16*)dzq, (const unsigned*)dy_amax, (const unsigned*)zhat_amax,
+                                   dzq ? (unsigned*)dzq_amax : nullptr);
+}
+
 extern "C" int radet_gn_relu_bwd_h(const void* dy, const void* z, const float* stats, const float* gamma,
                                    const float* beta, void* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
                                    int C, int groups, int relu, const int* seg_desc, int nseg, void* stream) {
@@ -1035,7 +1189,8 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
 // dst[n, oy, ox, :] += src[n, nearest(oy), nearest(ox), :]      (F.interpolate(mode='nearest', size=...))
 template <class T>
 __global__ void upsample_add_kernel(T* __restrict__ dst, const T* __restrict__ src, int B, int Ho, int Wo,
-                                    int Hi, int Wi, int C4, float sy, float sx) {
+                                    int Hi, int Wi, int C4, float sy, float sx, unsigned* amax = nullptr) {
+    float am = 0.f;
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -1049,13 +1204,16 @@ __global__ void upsample_add_kernel(T* __restrict__ dst, const T* __restrict__ s
         float4 d = ld4(dst, i);
         d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
         st4(dst, i, d);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
     }
+    if (amax) radet_amax_publish(am, amax);
 }
 
 // dsrc[n, iy, ix, :] += sum over dst pixels that read (iy, ix)
 template <class T>
 __global__ void upsample_add_bwd_kernel(T* __restrict__ dsrc, const T* __restrict__ ddst, int B, int Ho,
-                                        int Wo, int Hi, int Wi, int C4, float sy, float sx) {
+                                        int Wo, int Hi, int Wi, int C4, float sy, float sx, unsigned* amax = nullptr) {
+    float am = 0.f;
     const size_t total = (size_t)B * Hi * Wi * C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4);
@@ -1076,17 +1234,23 @@ __global__ void upsample_add_bwd_kernel(T* __restrict__ dsrc, const T* __restric
             }
         }
         st4(dsrc, i, a);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
     }
+    if (amax) radet_amax_publish(am, amax);
 }
 
-extern "C" int radet_upsample_add(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C,
-                                  void* stream) {
+extern "C" int radet_upsample_add_a(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                    void* dst_amax, void* stream) {
     if (C % 4) return RADET_ERR_ARG;
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, B, Ho, Wo, Hi,
-                       Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+                       Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo, (unsigned*)dst_amax);
     return radet_check_launch();
+}
+extern "C" int radet_upsample_add(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                  void* stream) {
+    return radet_upsample_add_a(dst, src, B, Ho, Wo, Hi, Wi, C, nullptr, stream);
 }
 
 extern "C" int radet_upsample_add_h(void* dst, const void* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* stream) {
@@ -1098,14 +1262,18 @@ extern "C" int radet_upsample_add_h(void* dst, const void* src, int B, int Ho, i
     return radet_check_launch();
 }
 
-extern "C" int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
-                                      void* stream) {
+extern "C" int radet_upsample_add_bwd_a(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                        void* dsrc_amax, void* stream) {
     if (C % 4) return RADET_ERR_ARG;
     const size_t total = (size_t)B * Hi * Wi * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(upsample_add_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dsrc, ddst, B, Ho,
-                       Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+                       Wo, Hi, Wi, C / 4, (float)Hi / (float)Ho, (float)Wi / (float)Wo, (unsigned*)dsrc_amax);
     return radet_check_launch();
+}
+extern "C" int radet_upsample_add_bwd(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
+                                      void* stream) {
+    return radet_upsample_add_bwd_a(dsrc, ddst, B, Ho, Wo, Hi, Wi, C, nullptr, stream);
 }
 
 extern "C" int radet_upsample_add_bwd_h(void* dsrc, const void* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C,
@@ -1122,20 +1290,45 @@ extern "C" int radet_upsample_add_bwd_h(void* dsrc, const void* ddst, int B, int
 // dx = (dy (+ addend)) * [act > 0]
 template <class T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ addend,
-                                const T* __restrict__ act, T* __restrict__ dx, size_t n4) {
+                                const T* __restrict__ act, T* __restrict__ dx, size_t n4, unsigned* amax = nullptr) {
+    float am = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 v = ld4(dy, i);
         if (addend) { const float4 a = ld4(addend, i); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
         const float4 m = ld4(act, i);
         v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         st4(dx, i, v);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
+    if (amax) radet_amax_publish(am, amax);
 }
-extern "C" int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream) {
+extern "C" int radet_relu_bwd_a(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* dx_amax,
+                                void* stream) {
     if (n % 4) return RADET_ERR_ARG;
     const size_t n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, addend, act, dx, n4);
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, addend, act, dx, n4,
+                       (unsigned*)dx_amax);
+    return radet_check_launch();
+}
+extern "C" int radet_relu_bwd(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* stream) {
+    return radet_relu_bwd_a(dy, addend, act, dx, n, nullptr, stream);
+}
+// largest magnitude of n floats (n % 4 == 0) -> raises *amax (for tensors whose producer does not track it; not reset here)
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* amax) {
+    float am = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    radet_amax_publish(am, amax);
+}
+extern "C" int radet_absmax(const float* x, size_t n, void* amax, void* stream) {
+    if (n % 4 || amax == nullptr) return RADET_ERR_ARG;
+    if (n == 0) return RADET_OK;
+    const size_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, (unsigned*)amax);
     return radet_check_launch();
 }
 extern "C" int radet_relu_bwd_h(const void* dy, const void* addend, const void* act, void* dx, size_t n, void* stream) {
@@ -1208,6 +1401,53 @@ extern "C" int radet_merge_planes(const void* src, float* dst, size_t rows, int 
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(merge_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst, rows,
                        C / 4, dst_ld / 4);
+    return radet_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------ fp32 rows -> fp16 plane pairs
+// dst rows [2][C] fp16 (32-channel groups [hi x 32 | lo x 32], common.h "h2") = src scaled by 2^radet_h2_exp(*src_amax)
+// (src_amax: the amax slot of src -- raised by the kernels that wrote src, or any bound on its largest magnitude); the
+// same bits are copied to dst_amax for the GEMMs that read the pairs.  merge: the inverse (tests / API boundary).
+__global__ void split_pairs_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t rows, int C4, int src_ld4,
+                                   const unsigned* __restrict__ src_amax, unsigned* __restrict__ dst_amax) {
+    const unsigned bits = *src_amax;
+    const int e = radet_h2_exp(bits);
+    const float s = radet_pow2(e), s2 = radet_pow2(e + 11);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *dst_amax = bits;
+    const size_t total = rows * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        st4_pairs(dst, r, C4 * 4, c, reinterpret_cast<const float4*>(src)[r * src_ld4 + c], s, s2);
+    }
+}
+__global__ void merge_pairs_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t rows, int C4, int dst_ld4,
+                                   const unsigned* __restrict__ amax) {
+    const float inv = radet_pow2(-radet_h2_exp(*amax));
+    const size_t total = rows * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C4;
+        const int c = (int)(i - r * C4);
+        reinterpret_cast<float4*>(dst)[r * dst_ld4 + c] = ld4_pairs(src, r, C4 * 4, c, inv);
+    }
+}
+extern "C" int radet_split_pairs(const float* src, void* dst, size_t rows, int C, int src_ld, const void* src_amax,
+                                 void* dst_amax, void* stream) {
+    if (C <= 0 || (C & 31) || (src_ld & 3) || src_ld < C || src_amax == nullptr || dst_amax == nullptr) return RADET_ERR_ARG;
+    if (rows == 0) return RADET_OK;
+    const size_t total = rows * (size_t)(C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split_pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, rows, C / 4,
+                       src_ld / 4, (const unsigned*)src_amax, (unsigned*)dst_amax);
+    return radet_check_launch();
+}
+extern "C" int radet_merge_pairs(const void* src, float* dst, size_t rows, int C, int dst_ld, const void* amax, void* stream) {
+    if (C <= 0 || (C & 31) || (dst_ld & 3) || dst_ld < C || amax == nullptr) return RADET_ERR_ARG;
+    if (rows == 0) return RADET_OK;
+    const size_t total = rows * (size_t)(C / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(merge_pairs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst, rows,
+                       C / 4, dst_ld / 4, (const unsigned*)amax);
     return radet_check_launch();
 }
 

@@ -61,10 +61,13 @@ class Engine:
                  stacked_convs=4, feat=256, math=None, watch=None):
         """params / grads: dict name -> device tensor (reference state-dict names; grads only for
         trainable parameters, same shapes).  math (env RADET_MATH):
-          "fp32" (default)  fp32 tensors and fp32-accurate arithmetic.  The conv GEMMs form their products on the bf16
-                            matrix cores from an exact three-way bf16 split of every fp32 operand (6 of the 9 plane
-                            products, fp32 accumulate: error against fp64 at or below the native fp32 MFMA's, 16x the
-                            MAC rate per plane product); RADET_X3=0 or "fp32-mfma" selects v_mfma_f32_32x32x2_f32;
+          "fp32" (default)  fp32 tensors and fp32-accurate arithmetic.  The conv GEMMs form their products on the 16-bit
+                            matrix cores: every fp32 operand is scaled by an exact power of two (from the tensor's
+                            tracked largest magnitude) and split into two fp16 numbers hi + 2^-11 lo, and
+                            hi hi' + 2^-11 (hi lo' + lo hi') is accumulated in fp32 by three v_mfma_f32_32x32x16_f16 per
+                            K = 16 step (error against fp64 at or below the native fp32 MFMA's, 16x its MAC rate per
+                            plane product).  RADET_X3=bf16 selects the round-2 scheme (exact three-way bf16 split, 6 of
+                            the 9 plane products); RADET_X3=0 or "fp32-mfma" selects v_mfma_f32_32x32x2_f32;
           "fp32-mfma"       the same with the native fp32 matrix instruction;
           "bf16"            conv operands rounded to bf16 on their way into the matrix cores, fp32 accumulate, fp32
                             tensors / GroupNorm / loss / optimizer;
@@ -79,7 +82,9 @@ class Engine:
         # (v_mfma_f32_32x32x16_bf16, fp32 accumulate); head outputs, loss, statistics, weight gradients, master
         # weights and optimizer stay fp32
         self.h16 = math == "bf16-storage"
-        self.x3 = math == "fp32" and os.environ.get("RADET_X3", "1") != "0"
+        x3mode = os.environ.get("RADET_X3", "h2")
+        self.x3 = math == "fp32" and x3mode != "0"
+        self.h2 = self.x3 and x3mode not in ("bf16", "b3")      # fp16 hi / lo arithmetic (3 plane products instead of 6)
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
         # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only
@@ -216,10 +221,15 @@ class Engine:
                 ld = c.wft_ld or c.cout
                 n_wft += c.cin * c.k * c.k * ld
         self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
+        # amax slots of the folded weights (fp16 hi / lo arithmetic): one per conv, written by radet_fold_weights
+        self.w_amax = torch.zeros(len(self.convs), dtype=torch.int32, device=dev)
+        self._w_amax_keys = []
         o_w = o_b = o_t = 0
         towers = (self.cls_tower + self.reg_tower) if self.p3 else []
-        for c in self.convs:
-            c.w16 = 2 if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
+        pkind = "h2" if self.h2 else "b3"
+        for ci, c in enumerate(self.convs):
+            c.w_amax = self.w_amax[ci:ci + 1]
+            c.w16 = (3 if self.h2 else 2) if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
             c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
             c.bias_f = self.bias_arena[o_b:o_b + c.cout]
@@ -231,9 +241,13 @@ class Engine:
                     n = c.cin * c.k * c.k * (c.wft_ld or c.cout)
                     c.wft = self.wft_arena[o_t:o_t + n]
                     o_t += n
-            if c.w16 == 2:            # plane triples: rows (o, tap) x Cin and (c, tap) x Cout (include/radet_hip.h, "planes")
-                c.wf = K.Planes(c.cout * c.k * c.k, c.cin, device=dev)
-                c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev)
+            if c.w16 >= 2:            # planes: rows (o, tap) x Cin and (c, tap) x Cout (include/radet_hip.h, "planes" / "plane pairs")
+                c.wf = K.Planes(c.cout * c.k * c.k, c.cin, device=dev, kind=pkind, amax=c.w_amax)
+                c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev, kind=pkind, amax=c.w_amax)
+            elif self.h2 and c is not self.convs[0]:
+                self._w_amax_keys.append(K.register_amax(c.wf, c.w_amax))
+                if c.need_dgrad and c.wft_shared is None:
+                    self._w_amax_keys.append(K.register_amax(c.wft, c.w_amax))
 
     # ------------------------------------------------------------------ geometry-dependent plan
     # Geometry plans: everything that depends on (B, H, W) -- activation / gradient buffers, conv geometries and their
@@ -241,7 +255,8 @@ class Engine:
     # e.g. training at B = 4 with validation at B = 1 neither reallocates nor re-tunes after the first pass.
     max_plans = int(os.environ.get("RADET_MAX_PLANS", "4"))
     _PLAN_ATTRS = ("B", "H", "W", "stem_hw", "pool_hw", "buf", "plv", "R", "gn_ws", "gn_ws2", "ldesc", "nlvl", "loss_ws",
-                   "losses", "dscales", "slab_arena", "bp_arena", "table", "_table_keepalive", "max_cout", "_pending_wgrad")
+                   "losses", "dscales", "slab_arena", "bp_arena", "table", "_table_keepalive", "max_cout", "_pending_wgrad",
+                   "amax_act", "amax_aux", "_amax_keys")
 
     def _snapshot(self):
         return dict(attrs={k: getattr(self, k) for k in self._PLAN_ATTRS},
@@ -271,7 +286,8 @@ class Engine:
                 # evict the least recently used plan (frees its buffers): nothing on any stream may still be using them
                 # when the caching allocator hands the blocks to the new plan
                 torch.cuda.synchronize()
-                self._plans.popitem(last=False)
+                _, old = self._plans.popitem(last=False)
+                K.unregister_amax(old["attrs"].get("_amax_keys") or [])
             if requested is not None:
                 self._plans[key] = requested
         self.geo_key = key
@@ -285,10 +301,23 @@ class Engine:
         h2, w2 = conv_out_hw(h1, w1, 3, 2, 1)
         self.stem_hw, self.pool_hw = (h1, w1), (h2, w2)
         self.buf = {}
+        # amax slots of the activation / gradient buffers (fp16 hi / lo arithmetic): raised by the kernels that write a
+        # buffer, zeroed at the start of every forward pass; amax_aux: slots their producers reset themselves (GroupNorm)
+        self.amax_act = torch.zeros(1024, dtype=torch.int32, device=dev)
+        self.amax_aux = torch.zeros(64, dtype=torch.int32, device=dev)
+        self._amax_keys = []
+        n_slot = [0, 0]
+
+        def slot(aux=False):
+            i = n_slot[aux]
+            n_slot[aux] += 1
+            return (self.amax_aux if aux else self.amax_act)[i:i + 1]
 
         def new(name, rows, ch, dtype=None):
             t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)
             self.buf[name] = t
+            if self.h2 and t.dtype == torch.float32:
+                self._amax_keys.append(K.register_amax(t, slot(), by_storage=True))
             return t
 
         new("stem", B * h1 * w1, 64)
@@ -341,25 +370,31 @@ class Engine:
         new("P", R, f)
         new("dP", R, f)
         new("dP_tmp", R, f)
+        pkind = "h2" if self.h2 else "b3"
         if self.p3:
-            self.buf["Pp"] = K.Planes(R, f, device=dev)          # P as planes: input of both towers' first conv / wgrad
+            self.buf["Pp"] = K.Planes(R, f, device=dev, kind=pkind)      # P as planes: input of both towers' first conv / wgrad
         for t in ("cls", "reg"):
             for i in range(self.stacked_convs):
                 new(f"{t}.z{i}", R, f)
                 if self.p3 and i < self.stacked_convs - 1:      # read by tower GEMMs only: stored as planes
-                    self.buf[f"{t}.y{i}"] = K.Planes(R, f, device=dev)
+                    self.buf[f"{t}.y{i}"] = K.Planes(R, f, device=dev, kind=pkind)
                 else:
                     new(f"{t}.y{i}", R, f)
+                if self.h2:
+                    self.buf[f"{t}.zhat{i}"] = slot(aux=True)     # largest normalised magnitude (bounds the backward's dz)
                 self.buf[f"{t}.stats{i}"] = torch.empty(len(hw) * B * 64, device=dev)
             new(f"{t}.dy", R, f)
             for nm in (f"{t}.dz0", f"{t}.dz1"):  # two alternating GN-backward outputs: the async wgrad of layer i may still
                 if self.p3:                      # read dz[i & 1] while layer i-1 writes the other one
-                    self.buf[nm] = K.Planes(R, f, device=dev)
+                    self.buf[nm] = K.Planes(R, f, device=dev, kind=pkind)
                 else:
                     new(nm, R, f)
             self.buf[f"{t}.dz"] = self.buf[f"{t}.dz0"]
         for c in self.cls_tower + self.reg_tower:
             c.geom = ConvGeom(self.plv, f, f, 3, 1, 1)
+            if self.p3 and self.h2:
+                # conv_wgrad9q_kernel: 128 output x 32 input channels x 9 taps per workgroup, one workgroup per CU
+                c.geom.nsplit = max(1, min(64, 256 // (-(-f // 128) * (f // 32)), (R + 127) // 128))
         for c in (self.pred_cls, self.pred_reg, self.pred_iou):
             c.geom = ConvGeom(self.plv, f, c.cout, 3, 1, 1)
         new("cls", R, self.num_classes, torch.float32)       # head outputs / their gradients: fp32 (loss is fp32)
@@ -367,6 +402,9 @@ class Engine:
         new("iou", R, 1, torch.float32)
         self.buf["dcls"] = torch.zeros(R, self.cls_pad, device=dev)
         self.buf["dregiou"] = torch.zeros(R, 16, device=dev)
+        if self.h2:
+            for nm in ("dcls", "dregiou"):
+                self._amax_keys.append(K.register_amax(self.buf[nm], slot(), by_storage=True))
         if self.h16:                                         # bf16 copies consumed by the predictors' dgrad / wgrad
             self.buf["dcls16"] = torch.zeros(R, self.cls_pad, device=dev, dtype=torch.bfloat16)
             self.buf["dregiou16"] = torch.zeros(R, self.ri_pad, device=dev, dtype=torch.bfloat16)
@@ -381,6 +419,7 @@ class Engine:
                 c.geom.math = self.math
                 c.geom.h16 = self.h16
                 c.geom.x3 = self.x3
+                c.geom.h2 = self.h2
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         self._plan_wgrad_groups()
         if tune:
@@ -486,6 +525,7 @@ class Engine:
             d.eps = 1e-5
             d.wft_ld, d.wft_off = c.wft_ld, c.wft_off
             d.w16 = c.w16
+            d.w_amax = ptr(c.w_amax) if self.h2 else None
             d.nsplit = c.geom.nsplit if c.geom is not None else 1
             if c.trainable and c.geom is not None:
                 d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
@@ -583,6 +623,8 @@ class Engine:
         B, H, W = self.B, self.H, self.W
         b = self.buf
         self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
+        if self.h2:
+            self.amax_act.zero_()            # every producer of this pass raises its buffer's slot from zero
         K.STAGE = "stem"
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
         K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
@@ -741,6 +783,10 @@ class Engine:
         self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12))
         gn = f"bbox_head.{t}_convs.{i}.gn"
         pl = K._isp(y)                  # the last layer's output feeds the predictor convs: fp32
+        if self.h2:
+            K.gn_relu_fwd_q(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], None if pl else y, y if pl else None,
+                            b[f"{t}.stats{i}"], ws, zhat_amax=b[f"{t}.zhat{i}"])
+            return y
         K.gn_relu_fwd_p(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], None if pl else y, y if pl else None,
                         b[f"{t}.stats{i}"], ws)
         return y
@@ -763,6 +809,12 @@ class Engine:
         gc, gr = f"bbox_head.cls_convs.{i}.gn", f"bbox_head.reg_convs.{i}.gn"
         if self.p3:
             pl = K._isp(yc)             # the last layer's output feeds the predictor convs: fp32
+            if self.h2:
+                K.gn_relu_fwd_pair_q(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], None if pl else yc, yc if pl else None,
+                                                b[f"cls.stats{i}"], self.gn_ws, b[f"cls.zhat{i}"]),
+                                     (zr, p[gr + ".weight"], p[gr + ".bias"], None if pl else yr, yr if pl else None,
+                                      b[f"reg.stats{i}"], self.gn_ws2, b[f"reg.zhat{i}"]))
+                return yc, yr
             K.gn_relu_fwd_pair_p(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], None if pl else yc, yc if pl else None,
                                             b[f"cls.stats{i}"], self.gn_ws),
                                  (zr, p[gr + ".weight"], p[gr + ".bias"], None if pl else yr, yr if pl else None,
@@ -855,6 +907,9 @@ class Engine:
         K.head_loss(b["cls"], b["reg_u"], b["iou"], self.scales_tensor(), gt_boxes, gt_labels, gt_off, p2g, pw, self.ldesc,
                     self.nlvl, self.B, self.num_classes, alpha, gamma, lbw, 1e-6, grad_scale, self.losses, b["dcls"],
                     self.cls_pad, dri, 16, dri.view(-1)[4:], 16, self.dscales, self.loss_ws, labels_out, tgt_out)
+        if self.h2:       # the predictors' dgrad / wgrad scale their dy operand by its largest magnitude
+            K.absmax(b["dcls"], K.amax_slot(b["dcls"]))
+            K.absmax(dri, K.amax_slot(dri))
         if self.h16:      # the predictors' dgrad / wgrad read bf16: reg -> cols 0-3, iou -> col 8 (16-byte aligned)
             K.convert_rows(b["dcls"], b["dcls16"])
             K.convert_rows(dri, b["dregiou16"], ncols=4)
@@ -949,8 +1004,13 @@ class Engine:
                 ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
                 if ev is not None:
                     torch.cuda.current_stream().wait_event(ev)
-                K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
-                                p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], ws)
+                if self.h2:
+                    K.gn_relu_bwd_q(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                    p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], ws,
+                                    zhat_amax=b[f"{t}.zhat{i}"])
+                else:
+                    K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                    p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], ws)
                 x = b[f"{t}.y{i - 1}"] if i > 0 else b["Pp"]
                 wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 if i > 0:
@@ -987,7 +1047,11 @@ class Engine:
                     ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
-                    if self.p3:
+                    if self.p3 and self.h2:
+                        K.gn_relu_bwd_q(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                        p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws,
+                                        zhat_amax=b[f"{t}.zhat{i}"])
+                    elif self.p3:
                         K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
                                         p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
                     else:

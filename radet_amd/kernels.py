@@ -94,6 +94,14 @@ def _igemm_key(t, x):
     tid = t & 0xFF
     if tid == 0:
         return "conv_igemmg_kernel<launcher heuristic>"
+    if t & H2 and (t & P3 or t & X3):
+        if t & P3:
+            tag, bk = 80 | ((t >> 8) & 1), 16
+        else:
+            tag, bk = 72 | ((t >> 8) & 1), 32
+            if tid >= 7:
+                return f"conv_igemmg_kernel<{_TILES[tid]}, {tag | 32}, {64 if tid == 7 else 32}, 2, false>"
+        return f"conv_igemmg_kernel<{_TILES.get(tid, '?')}, {tag}, {bk}, {3 if t & STAGES3 else 2}, false>"
     if t & P3:
         tag, bk = 16 | ((t >> 8) & 1), 16
     elif t & STORE_BF16:
@@ -167,10 +175,21 @@ class ConvGeom:
         self.math = 0                         # 1: bf16 math mode (operands rounded to bf16, fp32 accumulate)
         self.wgrad_flags = 0                  # tile override of the wgrad launcher (set by autotune_wgrad)
         self.h16 = False                      # bf16 tensors in HBM (tuning runs use the matching kernels)
-        self.x3 = False                       # fp32 tensors, igemm products from three bf16 planes per operand (tile flag X3)
+        self._x3 = False                      # fp32 tensors, conv products from 16-bit planes of the operands (tile flag X3) ...
+        self.h2 = False                       # ... two fp16 planes and 3 plane products (tile flag H2) instead of three bf16 / 6
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
         self._ft = self._bt = self._classes = None
         self._cgroup = 0                                   # 0 = not looked at yet, None = no class launch for this geometry
+
+    @property
+    def x3(self):
+        return self._x3
+
+    @x3.setter
+    def x3(self, v):                          # True: the bf16-plane arithmetic; "h2": the fp16 hi / lo arithmetic
+        self._x3 = bool(v)
+        if v == "h2":
+            self.h2 = True
 
     # The geometry keeps its tables alive: _TABLE_CACHE only dedupes them across geometries and may drop its own
     # reference at any time -- a table freed while a launch on a side stream still reads it would be recycled by the
@@ -421,7 +440,7 @@ def autotune(g, need_dgrad=True, reps=None):
         return out
 
     global _TUNE_DIRTY, TUNE_RUNS
-    key = (g._key, g.cin, g.cout, g.math, g.h16) + (("x3",) if getattr(g, "x3", False) else ())
+    key = (g._key, g.cin, g.cout, g.math, g.h16) + (("x3",) if getattr(g, "x3", False) else ()) + _h2key(g)
     if key not in _TUNE_CACHE:
         _TUNE_DIRTY = True
         TUNE_RUNS += 1
@@ -429,6 +448,7 @@ def autotune(g, need_dgrad=True, reps=None):
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         w = (torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05).to(dt)
         y = torch.empty(g.lout.rows, g.cout, device=dev, dtype=dt)
+        tmp_keys = _tune_slots(g, x, w, y)
         fc = cands(g.cin, g.cout, g.lout.rows, g.k * g.k)
         if not g.math and not g.h16:      # forward launches run alone on the device: 3 LDS stages may pay (0x20000)
             fc = fc + [t | STAGES3 for t in fc if (t & 0xFF) < 7]
@@ -436,13 +456,32 @@ def autotune(g, need_dgrad=True, reps=None):
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev, dtype=dt)
+            tmp_keys += _tune_slots(g, dx)
             # (no 3-stage candidates for dgrad: timed alone they win, next to the wgrad streams they lose -- a tune file
             # that allowed them made the step 1 % slower)
             bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
         _TUNE_CACHE[key] = (ft, bt)
+        unregister_amax(tmp_keys)
         if os.environ.get("RADET_TUNE_LOG"):
             print(f"[tune igemm] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={ft:#x} dgrad tile={bt:#x}")
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
+
+
+def _h2key(g):
+    return ("h2",) if (getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not g.h16) else ()
+
+
+def _tune_slots(g, *tensors):
+    """amax slots for the tuner's scratch tensors (fp16 hi / lo arithmetic): measured once, registered by address, so that
+    the timed launches do not each run a stand-alone absmax pass.  Returns the registry keys."""
+    keys = []
+    if _h2key(g):
+        for t in tensors:
+            s = torch.zeros(1, dtype=torch.int32, device=t.device)
+            if t.is_floating_point() and t.dtype == torch.float32:
+                s.fill_(0x42000000)                 # 32.0: above every |element| of the N(0, 1) / N(0, 0.05) scratch operands and
+            keys.append(register_amax(t, s))        # of what the timed convs write from them
+    return keys
 
 
 MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
@@ -454,22 +493,106 @@ STREAMK = 0x100000                        # * w (1..7): stream-K schedule with w
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)
 
 
-P3 = 0x2000000                            # x / w arrive as bf16 plane triples (rows [3][C]); fp32 outputs
+P3 = 0x2000000                            # x / w arrive as plane tensors (bf16 triples, or fp16 pairs with H2); fp32 outputs
 P3_BK8 = 0x4000000                        # ... with a K step of 16 instead of 32 channels
+H2 = 0x8000000                            # fp16 hi / lo arithmetic (with X3 or P3): 3 f16 MFMAs per K = 16 step, needs amax slots
+
+
+# ---------------------------------------------------------------------- amax slots (fp16 hi / lo arithmetic, radet_hip.h)
+# A slot is a 1-element int32 device tensor holding the bit pattern of a float >= every |element| of "its" tensor.  The
+# engine registers the slots of its buffers here (activations by storage, so that row slices of a buffer resolve to the
+# buffer's slot; weights by exact address, they are views of one arena); the conv launchers look the operands' slots up.
+# A tensor without a slot (ad-hoc calls: tests, the autotuner) gets one computed on the spot by a stand-alone pass.
+_AMAX_EXACT = {}
+_AMAX_STORAGE = {}
+
+
+def register_amax(t, slot, by_storage=False):
+    """slot: 1-element int32 tensor.  Returns the registry key (for unregister_amax)."""
+    if by_storage:
+        k = ("s", t.untyped_storage().data_ptr())
+        _AMAX_STORAGE[k[1]] = slot
+    else:
+        k = ("e", t.data_ptr())
+        _AMAX_EXACT[k[1]] = slot
+    return k
+
+
+def unregister_amax(keys):
+    for kind, ptr in keys:
+        (_AMAX_STORAGE if kind == "s" else _AMAX_EXACT).pop(ptr, None)
+    _AMAX_MEMO.clear()
+    _SCALES.clear()
+
+
+_AMAX_MEMO = {}
+
+
+def amax_slot(t, compute=False):
+    """the registered slot of tensor / Planes t (or of the buffer it is a slice of); None, or -- with compute=True -- a
+    fresh slot filled by radet_absmax"""
+    if t is None:
+        return None
+    if _isp(t):
+        return t.amax
+    p = t.data_ptr()
+    s = _AMAX_EXACT.get(p)
+    if s is None:
+        s = _AMAX_MEMO.get(p)
+        if s is None and _AMAX_STORAGE:
+            s = _AMAX_STORAGE.get(t.untyped_storage().data_ptr())
+            if s is not None:
+                _AMAX_MEMO[p] = s
+    if s is None and compute:
+        s = torch.zeros(1, dtype=torch.int32, device=t.device)
+        absmax(t, s)
+    return s
+
+
+def absmax(t, slot):
+    """raise `slot` to the largest magnitude of the fp32 tensor t (contiguous, numel % 4 == 0)"""
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    _lib.call("radet_absmax", _ptr(t), C.c_size_t(t.numel()), _ptr(slot), _stream())
+
+
+_SCALES = _LRU(4096)
+
+
+def _scales(x, w, y, x1=None, w1=None, y1=None, need=True):
+    """RadetScales for a launch (cached per slot combination).  need: the x / w slots are required (h2 arithmetic): missing
+    ones are computed on the spot; otherwise only the output slot matters and None is returned when there is none."""
+    sx, sw, sy = amax_slot(x, need), amax_slot(w, need), amax_slot(y)
+    sx1, sw1, sy1 = amax_slot(x1, need), amax_slot(w1, need), amax_slot(y1)
+    if not need and sy is None and sy1 is None:
+        return None
+    key = tuple(0 if t is None else t.data_ptr() for t in (sx, sw, sy, sx1, sw1, sy1))
+    ent = _SCALES.get(key)
+    if ent is None:
+        sc = _lib.RadetScales(*[None if v == 0 else v for v in key])
+        ent = _SCALES[key] = (C.byref(sc), sc, (sx, sw, sy, sx1, sw1, sy1))       # (the struct and the slots stay alive with it)
+    return ent[0]
 
 
 class Planes:
-    """A [rows, C] fp32 tensor stored as bf16 plane triples: `t` is a bf16 tensor [rows, 3 * C] whose row r holds
-    hi | mid | lo with hi + mid + lo == the fp32 value exactly (include/radet_hip.h, "planes").  Only the conv GEMMs read it."""
+    """A [rows, C] fp32 tensor in the operand format of the conv GEMMs (include/radet_hip.h).  kind "b3": bf16 plane triples,
+    `t` is a bf16 tensor [rows, 3 * C] whose row r holds hi | mid | lo with hi + mid + lo == the fp32 value exactly.
+    kind "h2": fp16 plane pairs, `t` is an fp16 tensor [rows, 2 * C] (32-channel groups [hi | lo]) of the values scaled by
+    the power of two of `amax` (a 1-element int32 tensor: the tensor's amax slot).  Only the conv GEMMs read it."""
 
-    def __init__(self, rows, C, device=None, t=None):
-        self.rows, self.C = int(rows), int(C)
-        self.t = t if t is not None else torch.empty(self.rows, 3 * self.C, device=device, dtype=torch.bfloat16)
+    def __init__(self, rows, C, device=None, t=None, kind="b3", amax=None):
+        self.rows, self.C, self.kind = int(rows), int(C), kind
+        if t is None:
+            t = (torch.empty(self.rows, 2 * self.C, device=device, dtype=torch.float16) if kind == "h2"
+                 else torch.empty(self.rows, 3 * self.C, device=device, dtype=torch.bfloat16))
+        self.t = t
+        self.amax = amax
+        if kind == "h2" and amax is None:
+            self.amax = torch.zeros(1, dtype=torch.int32, device=t.device)
 
     def __getitem__(self, sl):
         assert isinstance(sl, slice) and sl.step in (None, 1)
         v = self.t[sl]
-        return Planes(v.shape[0], self.C, t=v)
+        return Planes(v.shape[0], self.C, t=v, kind=self.kind, amax=self.amax)
 
     def data_ptr(self):
         return self.t.data_ptr()
@@ -480,8 +603,8 @@ class Planes:
         return out
 
     @staticmethod
-    def from_float(x):
-        p = Planes(x.shape[0], x.shape[1], device=x.device)
+    def from_float(x, kind="b3"):
+        p = Planes(x.shape[0], x.shape[1], device=x.device, kind=kind)
         split_planes(x, p)
         return p
 
@@ -494,15 +617,28 @@ def _ptr_any(t):
     return _ptr(t.t) if _isp(t) else _ptr(t)
 
 
-def split_planes(src, dst):
-    """dst (Planes) = exact bf16 plane split of the 2-D fp32 tensor src (row stride may exceed the width)"""
+def split_planes(src, dst, src_amax=None):
+    """dst (Planes) = plane split of the 2-D fp32 tensor src (row stride may exceed the width): exact bf16 triples, or fp16
+    pairs scaled by the power of two of src's amax slot (src_amax, else the registered one, else computed here)"""
     assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1 and dst.C == src.shape[1]
+    if dst.kind == "h2":
+        sa = src_amax if src_amax is not None else amax_slot(src)
+        if sa is None:
+            sa = torch.zeros(1, dtype=torch.int32, device=src.device)
+            absmax(src.contiguous(), sa)
+        _lib.call("radet_split_pairs", src.data_ptr(), _ptr(dst.t), C.c_size_t(src.shape[0]), src.shape[1], src.stride(0),
+                  _ptr(sa), _ptr(dst.amax), _stream())
+        return
     _lib.call("radet_split_planes", C.c_void_p(src.data_ptr()), _ptr(dst.t), C.c_size_t(src.shape[0]), src.shape[1],
               src.stride(0), _stream())
 
 
 def merge_planes(src, dst):
     assert dst.dim() == 2 and dst.dtype == torch.float32 and dst.stride(1) == 1 and src.C == dst.shape[1]
+    if src.kind == "h2":
+        _lib.call("radet_merge_pairs", _ptr(src.t), dst.data_ptr(), C.c_size_t(dst.shape[0]), dst.shape[1], dst.stride(0),
+                  _ptr(src.amax), _stream())
+        return
     _lib.call("radet_merge_planes", _ptr(src.t), C.c_void_p(dst.data_ptr()), C.c_size_t(dst.shape[0]), dst.shape[1],
               dst.stride(0), _stream())
 
@@ -514,10 +650,10 @@ def _is16(t):
 def _tile(g, tile, default, x=None, y=None):
     """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
     t = (tile or default) | (MATH_BF16 if g.math else 0)
-    if _isp(x):
-        return (t & ~(MATH_BF16 | 0x200)) | P3          # plane operands: 0x200 (the fp32 paths' K-step bit) has no meaning here
+    if _isp(x):                                          # plane operands: 0x200 (the fp32 paths' K-step bit) has no meaning here
+        return (t & ~(MATH_BF16 | 0x200)) | P3 | (H2 if x.kind == "h2" else 0)
     if getattr(g, "x3", False) and not g.math and not _is16(x):
-        t |= X3
+        t |= X3 | (H2 if getattr(g, "h2", False) else 0)
     if _is16(x):
         t = (t & ~MATH_BF16) | STORE_BF16 | (OUT_F32 if (y is not None and y.dtype == torch.float32) else 0)
     return t
@@ -528,10 +664,12 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
     ws = splitk_ws() if splitk else None
     table = g.fwd_table
 
+    sc = _scales(x, wf, y, need=bool(tile & H2))
+
     def launch():
-        _lib.call("radet_conv2d_igemm", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
+        _lib.call("radet_conv2d_igemm_s", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
                   g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
-                  _stream())
+                  _stream(), sc)
     _timed(lambda: _igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g))
 
 
@@ -573,7 +711,7 @@ def autotune_wgrad(g, reps=None):
     dev = torch.device("cuda", torch.cuda.current_device())
     reps = reps or TUNE_REPS
     global _TUNE_DIRTY, TUNE_RUNS
-    key = (g._key, g.cin, g.cout, g.math, g.h16, "w") + (("x3",) if getattr(g, "x3", False) else ())
+    key = (g._key, g.cin, g.cout, g.math, g.h16, "w") + (("x3",) if getattr(g, "x3", False) else ()) + _h2key(g)
     if key not in _WTUNE_CACHE:
         _TUNE_DIRTY = True
         TUNE_RUNS += 1
@@ -598,6 +736,7 @@ def autotune_wgrad(g, reps=None):
         dt = torch.bfloat16 if g.h16 else torch.float32
         dy = torch.randn(M, g.cout, device=dev).to(dt)
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
+        tmp_keys = _tune_slots(g, dy, x)
         slabs = torch.empty(max(c[1] for c in cands) * g.cout * kk * g.cin, device=dev)
         for fl, S in cands:
             g.wgrad_flags, g.nsplit = fl, S
@@ -620,6 +759,7 @@ def autotune_wgrad(g, reps=None):
             if best is None or cost < best[0]:
                 best = (cost, fl, S)
         _WTUNE_CACHE[key] = best[1:]
+        unregister_amax(tmp_keys)
         if os.environ.get("RADET_TUNE_LOG"):
             print(f"[tune wgrad] M={M} {g.cin}->{g.cout} k{g.k}s{g.stride}: heuristic S={s0} -> flags={best[1]:#x} S={best[2]} "
                   f"({best[0] * 1e3:.1f} us incl. slab cost)")
@@ -631,9 +771,10 @@ def conv_fwd_pair(g, a, b, relu=False, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     t, table = _tile(g, tile, g.fwd_tile, a["x"], a["y"]), g.fwd_table
+    sc = _scales(a["x"], a["w"], a["y"], b["x"], b["w"], b["y"], need=bool(t & H2))
     _timed(lambda: _igemm_key(t, a["x"]), 4.0 * g.lout.rows * g.cout * g.cin * g.k * g.k,
-           lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lout.rows, g.cin, g.cout, g.k, g.k,
-                             int(relu), t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2))
+           lambda: _lib.call("radet_conv2d_igemm_pair_s", *q(a), *q(b), _ptr(table), g.lout.rows, g.cin, g.cout, g.k, g.k,
+                             int(relu), t, _ptr(ws), C.c_size_t(ws.numel()), _stream(), sc), _conv_bytes(g, 2))
 
 
 def conv_dgrad_pair(g, a, b, tile=0):
@@ -642,9 +783,10 @@ def conv_dgrad_pair(g, a, b, tile=0):
     ws = splitk_ws()
     q = lambda d: [_ptr_any(d.get(k)) for k in ("x", "w", "bias", "addend", "mask", "y")]  # noqa: E731
     t, table = _tile(g, tile, g.bwd_tile, a["x"], a["y"]), g.bwd_table
+    sc = _scales(a["x"], a["w"], a["y"], b["x"], b["w"], b["y"], need=bool(t & H2))
     _timed(lambda: _igemm_key(t, a["x"]), 4.0 * g.lin.rows * g.cout * g.cin * g.k * g.k,
-           lambda: _lib.call("radet_conv2d_igemm_pair", *q(a), *q(b), _ptr(table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
-                             t, _ptr(ws), C.c_size_t(ws.numel()), _stream()), _conv_bytes(g, 2), kind="dgrad")
+           lambda: _lib.call("radet_conv2d_igemm_pair_s", *q(a), *q(b), _ptr(table), g.lin.rows, g.cout, g.cin, g.k, g.k, 0,
+                             t, _ptr(ws), C.c_size_t(ws.numel()), _stream(), sc), _conv_bytes(g, 2), kind="dgrad")
 
 
 def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
@@ -667,12 +809,15 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
 
 
 def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows):
+    # (a K that cannot be split into planes -- the 16-channel padded gradient of the reg / iou predictors -- runs on the
+    # native fp32 MFMA inside the launcher and needs no operand slots)
+    sc = _scales(dy, wft, dx, need=bool(tile & H2) and (_isp(dy) or kc % 32 == 0))
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
         grp = _strided_dgrad_group(g)
         if grp is not None:
-            _lib.call("radet_conv2d_igemm_classes", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx),
+            _lib.call("radet_conv2d_igemm_classes_s", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx),
                       _ptr(grp["table"]), _ptr(grp["out_rows"]), grp["tap_ids"], grp["ntaps"], grp["start"], grp["ncls"],
-                      g.k * g.k, grp["M"], kc, g.cin, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
+                      g.k * g.k, grp["M"], kc, g.cin, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
         for c in _strided_dgrad_classes(g):
             if grp is not None and not c["zero"]:
                 continue
@@ -682,18 +827,23 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
             # rows that receive no tap at all only need the epilogue: one 16-deep stage over an all-(-1) table (a K-divided
             # tile needs 32 / 64 channels per stage: the plain 64 x 64 tile instead, no split-K)
             ct = ((tile & ~0xF0FF) | 3) if (c["zero"] and (tile & 0xFF) >= 7) else tile
-            _lib.call("radet_conv2d_igemm_taps", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
+            _lib.call("radet_conv2d_igemm_taps_s", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx), _ptr(c["table"]),
                       _ptr(c["out_rows"]), c["tap_ids"], c["ntaps"], g.k * g.k, c["rows"],
                       (32 if _is16(dy) else 16) if c["zero"] else kc, g.cin,
-                      ct, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
+                      ct, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
         return
-    _lib.call("radet_conv2d_igemm", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
-              g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream())
+    _lib.call("radet_conv2d_igemm_s", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
+              g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
 
 
 def _wgrad_key(g, dy, co):
     if _isp(dy):
-        return "conv_wgrad9p_kernel"
+        return "conv_wgrad9q_kernel" if dy.kind == "h2" else "conv_wgrad9p_kernel"
+    if getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not _is16(dy):
+        tf = (g.wgrad_flags >> 4) & 3
+        tile = {0: "launcher tile", 1: "128, 128", 2: "64, 64", 3: "128, 64"}[tf] if co > 32 else "32, 128"
+        kd = ", 64 px / 4 waves" if g.wgrad_flags & 0x400 else (", 32 px / 2 waves" if g.wgrad_flags & 0x800 else "")
+        return f"conv_wgradg_kernel<{tile}> (fp16 hi/lo in registers{', 32 px' if g.wgrad_flags & 0x80 else ''}{kd})"
     nine = g.k == 3 and g.cin % 32 == 0 and co >= 256 and g.lout.rows >= 16384 and not (g.wgrad_flags & 0x40)
     mode = "bf16 storage" if _is16(dy) else ("bf16 math" if g.math else ("planes in registers" if getattr(g, "x3", False) else "fp32 MFMA"))
     if nine:
@@ -717,9 +867,21 @@ def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
 def _conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     co = g.cout if cout is None else cout
     if _isp(dy):
-        assert _isp(x)
+        assert _isp(x) and x.kind == dy.kind
+        if dy.kind == "h2":
+            _lib.call("radet_conv2d_wgrad_s", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table),
+                      g.lout.rows, g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x1000 | 0x200, _stream(),
+                      _scales(dy, x, None))
+            return
         _lib.call("radet_conv2d_wgrad", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
                   g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x200 | (g.wgrad_flags & 0x40), _stream())
+        return
+    if getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not _is16(dy):
+        # fp16 hi / lo arithmetic on fp32 tensors: one-tap tiles only (an accumulator pair per tap does not fit the all-taps
+        # tile); 0x40 keeps the launcher away from it for the geometries the tuner has not seen
+        _lib.call("radet_conv2d_wgrad_s", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
+                  g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x1000 | 0x40 | g.wgrad_flags, _stream(),
+                  _scales(dy, x, None))
         return
     _lib.call("radet_conv2d_wgrad", _ptr(dy), _ptr(x), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
               g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit,
@@ -783,7 +945,10 @@ def convert_rows(src, dst, ncols=None, src_off=0, dst_off=0):
 
 
 def maxpool(x, y, B, H, W, Cch):
-    _lib.call(_h("radet_maxpool3x3s2", x), _ptr(x), _ptr(y), B, H, W, Cch, _stream())
+    if _is16(x):
+        _lib.call("radet_maxpool3x3s2_h", _ptr(x), _ptr(y), B, H, W, Cch, _stream())
+        return
+    _lib.call("radet_maxpool3x3s2_a", _ptr(x), _ptr(y), B, H, W, Cch, _ptr(amax_slot(y)), _stream())
 
 
 def maxpool_bwd_relu(s, dpool, ds, B, H, W, Cch):
@@ -836,6 +1001,36 @@ def gn_relu_fwd_pair_p(levels, a, b, eps=1e-5, relu=True):
               int(relu), d, n, _stream())
 
 
+def gn_relu_fwd_q(levels, z, gamma, beta, y, yq, stats, ws, zhat_amax=None, eps=1e-5, relu=True):
+    """fp16 hi / lo arithmetic: fp32 z -> y (fp32 tensor or None; its registered amax slot is raised) and / or yq (Planes of
+    kind "h2" or None: scaled by a bound on |y|, written to yq.amax); zhat_amax: slot raised to the largest |zhat|"""
+    d, n = _gn_desc(levels)
+    _lib.call("radet_gn_relu_fwd_q", _ptr(z), _ptr(gamma), _ptr(beta), _ptr(y), _ptr_any(yq), _ptr(stats), _ptr(ws), levels.B,
+              256, 32, eps, int(relu), d, n, _stream(), _ptr(amax_slot(y)), _ptr(yq.amax) if yq is not None else None,
+              _ptr(zhat_amax))
+
+
+def gn_relu_fwd_pair_q(levels, a, b, eps=1e-5, relu=True):
+    """a / b = (z, gamma, beta, y or None, yq (Planes "h2") or None, stats, ws, zhat_amax or None)"""
+    d, n = _gn_desc(levels)
+
+    def q(t):
+        z, gm, bt, y, yq, stats, ws, zh = t
+        return [_ptr(z), _ptr(gm), _ptr(bt), _ptr(y), _ptr_any(yq), _ptr(stats), _ptr(ws), _ptr(amax_slot(y)),
+                _ptr(yq.amax) if yq is not None else None, _ptr(zh)]
+    _lib.call("radet_gn_relu_fwd_pair_q", *q(a), *q(b), levels.B, 256, 32, eps, int(relu), d, n, _stream())
+
+
+def gn_relu_bwd_q(levels, dy, z, stats, gamma, beta, dz, dzq, dgamma, dbeta, ws, zhat_amax=None, dy_amax=None, relu=True):
+    """like gn_relu_bwd with dz as fp32 (or None) and / or Planes "h2" dzq (scaled by a bound built from dy's amax slot --
+    dy_amax, else the registered one, else computed here -- and zhat_amax; the bound goes to dzq.amax)"""
+    d, n = _gn_desc(levels)
+    da = dy_amax if dy_amax is not None else (amax_slot(dy, compute=True) if dzq is not None else None)
+    _lib.call("radet_gn_relu_bwd_q", _ptr(dy), _ptr(z), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(dz), _ptr_any(dzq),
+              _ptr(dgamma), _ptr(dbeta), _ptr(ws), levels.B, 256, 32, int(relu), d, n, _stream(), _ptr(da), _ptr(zhat_amax),
+              _ptr(dzq.amax) if dzq is not None else None)
+
+
 def gn_relu_bwd_p(levels, dy, z, stats, gamma, beta, dz, dzp, dgamma, dbeta, ws, relu=True):
     """like gn_relu_bwd with dz as fp32 (or None) and / or Planes dzp (or None)"""
     d, n = _gn_desc(levels)
@@ -850,15 +1045,25 @@ def gn_relu_bwd(levels, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws, relu=T
 
 
 def upsample_add(dst, src, B, ho, wo, hi, wi, ch):
-    _lib.call(_h("radet_upsample_add", dst), _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _stream())
+    if _is16(dst):
+        _lib.call("radet_upsample_add_h", _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _stream())
+        return
+    _lib.call("radet_upsample_add_a", _ptr(dst), _ptr(src), B, ho, wo, hi, wi, ch, _ptr(amax_slot(dst)), _stream())
 
 
 def upsample_add_bwd(dsrc, ddst, B, ho, wo, hi, wi, ch):
-    _lib.call(_h("radet_upsample_add_bwd", dsrc), _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _stream())
+    if _is16(dsrc):
+        _lib.call("radet_upsample_add_bwd_h", _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _stream())
+        return
+    _lib.call("radet_upsample_add_bwd_a", _ptr(dsrc), _ptr(ddst), B, ho, wo, hi, wi, ch, _ptr(amax_slot(dsrc)), _stream())
 
 
 def relu_bwd(dy, addend, act, dx):
-    _lib.call(_h("radet_relu_bwd", dy), _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _stream())
+    if _is16(dy):
+        _lib.call("radet_relu_bwd_h", _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _stream())
+        return
+    _lib.call("radet_relu_bwd_a", _ptr(dy), _ptr(addend), _ptr(act), _ptr(dx), C.c_size_t(dx.numel()), _ptr(amax_slot(dx)),
+              _stream())
 
 
 def nchw_to_nhwc(x, y, B, ch, H, W):
@@ -869,6 +1074,9 @@ def nchw_to_nhwc(x, y, B, ch, H, W):
         convert_rows(tmp.view(-1, ch), y.view(-1, ch))
         return
     _lib.call("radet_nchw_to_nhwc", _ptr(x), _ptr(y), B, ch, H, W, _stream())
+    sl = amax_slot(y)
+    if sl is not None and y.numel() % 4 == 0:          # data entering an engine buffer from outside: its amax slot follows
+        absmax(y, sl)
 
 
 def nhwc_to_nchw(x, y, B, ch, H, W):

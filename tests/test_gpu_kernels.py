@@ -59,15 +59,18 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("math", [0, 1, 2], ids=["fp32mfma", "bf16math", "fp32x3"])
+@pytest.mark.parametrize("math", [0, 1, 2, 3], ids=["fp32mfma", "bf16math", "fp32x3", "fp32h2"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(K, case, math):
     """math=1: operands rounded (RNE) to bf16 inside the kernel, fp32 accumulate -- the reference is the exact
     convolution of the pre-rounded tensors, so the tolerance stays at fp32-accumulation level.
     math=2 (the default fp32 arithmetic): fp32 operands split exactly into three bf16 planes, 6 of the 9 plane products
-    on the bf16 matrix cores -- held to the SAME fp64 reference and tolerance as the native fp32 MFMA path (math=0)."""
+    on the bf16 matrix cores -- held to the SAME fp64 reference and tolerance as the native fp32 MFMA path (math=0).
+    math=3 (the default fp32 arithmetic since round 5): fp32 operands scaled by a power of two and split into two fp16 planes,
+    3 plane products on the f16 matrix cores (the operands' amax slots are computed on the spot here) -- same reference and
+    tolerance again."""
     B, Cin, Cout, H, W, k, s, tile = case
-    x3, math = math == 2, math & 1
+    x3, math = {2: True, 3: "h2"}.get(math, False), math & 1 if math < 2 else 0
     g = torch.Generator().manual_seed(sum(case))
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -124,9 +127,10 @@ KDIV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("arith", [True, "h2"], ids=["bf16x3", "fp16x2"])
 @pytest.mark.parametrize("kd", [7, 8], ids=["4-kgroups", "2-kgroups"])
 @pytest.mark.parametrize("case", KDIV_CASES)
-def test_k_divided_tiles(K, case, kd):
+def test_k_divided_tiles(K, case, kd, arith):
     """The 64 x 64 tiles whose four waves divide the K step (tile 7: four 16-channel k-groups of a 64-channel stage, every
     wave accumulates the whole tile; tile 8: two k-groups x two column halves of a 32-channel stage) and add their partial
     tiles through LDS; and the pixel-divided one-tap wgrad (flags 0x400 / 0x800).  Same fp64 reference and tolerance as
@@ -147,7 +151,7 @@ def test_k_divided_tiles(K, case, kd):
     dev = "cuda"
     lv = K.Levels([(H, W)], B)
     geom = K.ConvGeom(lv, Cin, Cout, k, s, pad)
-    geom.x3 = True
+    geom.x3 = arith
     tile = kd | (sk << 12)
     xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
     y = torch.full((B * Ho * Wo, Cout), float("nan"), device=dev)
@@ -176,7 +180,7 @@ def test_k_divided_tiles(K, case, kd):
         assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S
 
 
-@pytest.mark.parametrize("x3", [False, True], ids=["fp32mfma", "fp32x3"])
+@pytest.mark.parametrize("x3", [False, True, "h2"], ids=["fp32mfma", "fp32x3", "fp32h2"])
 @pytest.mark.parametrize("shape", [
     # B, Cin, Cout, H, W, tile
     (2, 128, 128, 18, 22, 0),
@@ -288,6 +292,223 @@ def test_fp32_from_bf16_planes_is_as_accurate_as_the_fp32_mfma(K):
     for native, planes in zip(errs[False], errs[True]):
         assert planes <= 1.25 * native + 1e-9, errs
         assert planes < 1e-5
+
+
+def _conv_errs(K, x4, w4, dy4, mode, tile=0x202, wflags=None):
+    """(forward, dgrad, wgrad) error of one 3x3 conv against fp64, relative to the largest reference magnitude"""
+    B, C, H, W = x4.shape
+    Co = w4.shape[0]
+    ref_y = F.conv2d(x4.double(), w4.double(), padding=1)
+    ref_gx = torch.nn.grad.conv2d_input(x4.shape, w4.double(), dy4.double(), padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(x4.double(), w4.shape, dy4.double(), padding=1)
+    lv = K.Levels([(H, W)], B)
+    g = K.ConvGeom(lv, C, Co, 3, 1, 1)
+    g.x3 = mode
+    xr, dyr, wf = to_rows(x4).cuda(), to_rows(dy4).cuda(), fold_w(w4).cuda()
+    wft = w4.permute(1, 2, 3, 0).reshape(C, 9, Co).contiguous().cuda()
+    y, dx = torch.empty(lv.rows, Co, device="cuda"), torch.empty(lv.rows, C, device="cuda")
+    K.conv_fwd(g, xr, wf, None, y, tile=tile)
+    K.conv_dgrad(g, dyr, wft, dx, tile=tile)
+    if wflags is not None:
+        g.wgrad_flags, g.nsplit = wflags, 4
+    slabs = torch.empty(g.nsplit, Co, 9, C, device="cuda")
+    K.conv_wgrad(g, dyr, xr, slabs)
+    gw = slabs.double().sum(0).reshape(Co, 3, 3, C).permute(0, 3, 1, 2)
+    return (rel_err(from_rows(y, B, H, W), ref_y), rel_err(from_rows(dx, B, H, W), ref_gx), rel_err(gw, ref_gw)), (y, dx, slabs)
+
+
+def test_fp32_from_fp16_pairs_is_as_accurate_as_the_fp32_mfma(K):
+    """The default fp32 arithmetic (round 5): every operand is scaled by an exact power of two (from its amax slot) and split
+    into two fp16 numbers hi + 2^-11 lo; hi hi' + 2^-11 (hi lo' + lo hi') is accumulated in fp32 by three f16 MFMAs per
+    K = 16 step.  Acceptance gate: error against an fp64 convolution <= 1.25 x the native v_mfma_f32_32x32x2_f32 path's and
+    < 1e-5 -- forward, dgrad and wgrad, every tile family -- on the tower shape AND on operands whose magnitudes span 2^24
+    inside one tensor, gradients scaled by 2^-20, rows of zeros; exact under power-of-two scalings (the scale follows the
+    operand); bit-identical from run to run."""
+    B, C, H, W = 2, 256, 40, 40
+    gen = torch.Generator().manual_seed(9)
+
+    def lognormal(shape, lo, hi):
+        return torch.randn(shape, generator=gen) * torch.exp2(torch.empty(shape).uniform_(lo, hi, generator=gen))
+
+    cases = {
+        "gaussian": (torch.randn(B, C, H, W, generator=gen), torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5,
+                     torch.randn(B, C, H, W, generator=gen)),
+        "relu activations": (torch.randn(B, C, H, W, generator=gen).clamp_min(0), torch.randn(C, C, 3, 3, generator=gen) * 0.02,
+                             torch.randn(B, C, H, W, generator=gen)),
+        "log-uniform 2^+-12": (lognormal((B, C, H, W), -12, 12), lognormal((C, C, 3, 3), -12, 12) / (C * 9) ** 0.5,
+                               lognormal((B, C, H, W), -12, 12)),
+        "dy 2^-20": (torch.randn(B, C, H, W, generator=gen), torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5,
+                     torch.randn(B, C, H, W, generator=gen) * 2.0 ** -20),
+    }
+    zr = torch.randn(B, C, H, W, generator=gen)
+    zr[:, :, ::3] = 0                                          # rows of zeros (and whole zero channels of dy)
+    zd = torch.randn(B, C, H, W, generator=gen)
+    zd[:, ::2] = 0
+    cases["zero rows"] = (zr, torch.randn(C, C, 3, 3, generator=gen) / (C * 9) ** 0.5, zd)
+    for name, (x4, w4, dy4) in cases.items():
+        for tile, wfl in ((0x202, 0x40 | (1 << 4)), (1, 0x40 | (3 << 4)), (3, 0xC0 | (2 << 4)), (7, 0x40 | (2 << 4) | 0x400),
+                          (8, 0x40 | (2 << 4) | 0x800)):
+            # the native instruction on the same tile and the same pixel splits (the summation structure is part of the error;
+            # the K-divided tiles and the 128 x 64 weight-gradient tile exist for the plane arithmetics only: 64 x 64 there)
+            native, _ = _conv_errs(K, x4, w4, dy4, False, tile=tile if (tile & 0xFF) < 7 else 3,
+                                   wflags=(wfl & ~0xC00) if ((wfl >> 4) & 3) != 3 else 0x40 | (2 << 4))
+            errs, outs = _conv_errs(K, x4, w4, dy4, "h2", tile=tile, wflags=wfl)
+            for e_n, e_h, what in zip(native, errs, ("fwd", "dgrad", "wgrad")):
+                assert e_h <= 1.25 * e_n + 1e-9, (name, hex(tile), what, e_h, e_n)
+                assert e_h < 1e-5, (name, hex(tile), what, e_h)
+            _, outs2 = _conv_errs(K, x4, w4, dy4, "h2", tile=tile, wflags=wfl)
+            assert all(torch.equal(a, b) for a, b in zip(outs, outs2)), (name, hex(tile))      # run-to-run bit identity
+        # power-of-two linearity: the operands' scales follow them exactly
+        _, (y1, dx1, s1) = _conv_errs(K, x4, w4, dy4, "h2")
+        _, (y2, dx2, s2) = _conv_errs(K, x4 * 4, w4 * 0.5, dy4 * 2.0 ** -7, "h2")
+        assert torch.equal(y2, y1 * 2) and torch.equal(dx2, dx1 * 2.0 ** -8) and torch.equal(s2, s1 * 2.0 ** -5), name
+    # an all-zero operand (amax slot 0: no scaling) and a tensor of one huge / one tiny magnitude
+    x0 = torch.zeros(1, 64, 8, 8)
+    w0 = torch.randn(64, 64, 3, 3, generator=gen)
+    (e, _, _), (y, _, _) = _conv_errs(K, x0, w0, torch.zeros(1, 64, 8, 8), "h2", tile=3)
+    assert float(y.abs().max()) == 0.0
+    for mag in (2.0 ** 100, 2.0 ** -100):
+        errs, _ = _conv_errs(K, torch.randn(1, 64, 8, 8, generator=gen) * mag, w0, torch.randn(1, 64, 8, 8, generator=gen) / mag,
+                             "h2", tile=3)
+        assert max(errs) < 1e-5, (mag, errs)
+
+
+PAIR_CASES = [
+    # B, Cin, Cout, H, W, k, tile
+    (2, 256, 256, 30, 40, 3, 5),            # 128 x 128, 8 waves
+    (2, 256, 256, 30, 40, 3, 6),            # 256 x 128, 8 waves
+    (1, 128, 128, 17, 23, 3, 5),            # ragged last M tile, image-border taps
+    (1, 512, 256, 15, 20, 3, 0x3005),       # forced split-K = 3
+    (4, 256, 256, 80, 80, 3, 0x20006),      # 3 LDS stages, tail split
+    (1, 1024, 256, 15, 20, 1, 0x2005),      # 1 x 1, forced split-K = 2
+    (2, 64, 128, 20, 24, 1, 5),
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_plane_pair_operand_conv(K, case):
+    """radet_conv2d_igemm_s with x / w as fp16 plane pairs (tile_override 0x2000000 | 0x8000000): the pair split represents
+    every element to 2^-22 relative, and the conv is held to the same fp64 reference and tolerance as the fp32 paths (forward
+    with bias + residual + ReLU, dgrad with mask); 3x3 cases also run the plane-pair all-taps wgrad (conv_wgrad9q_kernel)
+    incl. its bias column sums."""
+    B, Cin, Cout, H, W, k, tile = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    y_ref = F.conv2d(x.double(), w.double(), bias.double(), padding=pad)
+    res = torch.randn(B, Cout, H, W, generator=g)
+    out_ref = F.relu(y_ref + res.double())
+    dy = torch.randn(B, Cout, H, W, generator=g) * 1e-3
+    gx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=pad)
+    dev = "cuda"
+    lv = K.Levels([(H, W)], B)
+    geom = K.ConvGeom(lv, Cin, Cout, k, 1, pad)
+    xr = to_rows(x).to(dev)
+    xp = K.Planes.from_float(xr, kind="h2")
+    assert xp.t.dtype == torch.float16 and xp.t.shape == (lv.rows, 2 * Cin)
+    assert int(xp.amax) == int(xr.abs().max().view(torch.int32))          # the slot holds the bit pattern of the largest |x|
+    back = xp.to_float()
+    assert float(((back - xr).abs() / xr.abs().clamp_min(float(xr.abs().max()) * 2.0 ** -26)).max()) <= 2.0 ** -22
+    wp = K.Planes.from_float(fold_w(w).reshape(Cout * k * k, Cin).to(dev), kind="h2")
+    y = torch.empty(lv.rows, Cout, device=dev)
+    K.conv_fwd(geom, xp, wp, bias.to(dev), y, addend=to_rows(res).to(dev), relu=True, tile=tile)
+    assert rel_err(from_rows(y, B, H, W), out_ref) < 1e-5
+    dyr = to_rows(dy).to(dev)
+    dyp = K.Planes.from_float(dyr, kind="h2")
+    wtp = K.Planes.from_float(w.permute(1, 2, 3, 0).reshape(Cin * k * k, Cout).contiguous().to(dev), kind="h2")
+    dx = torch.empty(lv.rows, Cin, device=dev)
+    mask = to_rows(torch.randn(B, Cin, H, W, generator=g)).to(dev)
+    K.conv_dgrad(geom, dyp, wtp, dx, mask=mask, tile=tile)
+    gx_m = gx * (from_rows(mask.cpu(), B, H, W) > 0)
+    assert rel_err(from_rows(dx, B, H, W), gx_m) < 1e-5
+    if k == 3:
+        gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=pad)
+        for S in (1, 5):                                      # (the last split is ragged)
+            geom.nsplit = S
+            slabs = torch.full((S, Cout, 9, Cin), float("nan"), device=dev)
+            bp = torch.full((S, Cout), float("nan"), device=dev)
+            K.conv_wgrad(geom, dyp, xp, slabs, bp)
+            gw_mine = slabs.sum(0).reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+            assert rel_err(gw_mine, gw) < 2e-5, S
+            assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S
+
+
+def test_plane_pair_outputs_of_groupnorm_and_fold(K):
+    """GroupNorm + ReLU forward / backward with plane-PAIR outputs (radet_gn_relu_fwd_q / _bwd_q): the pairs reproduce the fp32
+    outputs to 2^-22 of every element (2^-24 of the bound for the smallest ones), the bound written to the amax slot really
+    bounds the tensor, the tracked slots (fp32 output, |zhat|) hold the exact maxima, and the statistics / parameter
+    gradients are those of the fp32 kernels bit for bit."""
+    dev = "cuda"
+    lv = K.Levels([(12, 16), (6, 8), (3, 4)], 2)
+    R = lv.rows
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(R, 256, generator=g) * 3 + 0.5).to(dev)
+    gam, bet = (torch.rand(256, generator=g) + 0.5).to(dev), (torch.randn(256, generator=g) * 0.1).to(dev)
+    stats, stats2 = torch.empty(len(lv) * lv.B * 64, device=dev), torch.empty(len(lv) * lv.B * 64, device=dev)
+    ws = torch.empty(K.gn_ws_floats(lv), device=dev)
+    y = torch.empty_like(z)
+    K.gn_relu_fwd(lv, z, gam, bet, y, stats, ws)
+
+    def close(planes, ref):
+        got = planes.to_float()
+        bound = torch.tensor(int(planes.amax), dtype=torch.int32).view(torch.float32).item()
+        assert bound >= float(ref.abs().max()), (bound, float(ref.abs().max()))
+        tol = ref.abs() * 2.0 ** -22 + bound * 2.0 ** -36
+        assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() / tol).max())
+
+    yq, y2 = K.Planes(R, 256, device=dev, kind="h2"), torch.empty_like(z)
+    ya, zh = torch.zeros(1, dtype=torch.int32, device=dev), torch.full((1,), 77, dtype=torch.int32, device=dev)
+    key = K.register_amax(y2, ya)
+    K.gn_relu_fwd_q(lv, z, gam, bet, y2, yq, stats2, ws, zhat_amax=zh)
+    K.unregister_amax([key])
+    assert torch.equal(y2, y) and torch.equal(stats2, stats)
+    close(yq, y)
+    assert int(ya) == int(y.abs().max().view(torch.int32))
+    zhat = torch.cat([((z[r0:r1].view(lv.B, -1, 32, 8) - m[:, None, :, None]) * r[:, None, :, None]).abs().reshape(-1)
+                      for (r0, r1), m, r in ((lv.level_rows(l), stats.view(-1, 32, 2)[l * lv.B:(l + 1) * lv.B, :, 0],
+                                              stats.view(-1, 32, 2)[l * lv.B:(l + 1) * lv.B, :, 1]) for l in range(len(lv)))])
+    assert abs(torch.tensor(int(zh), dtype=torch.int32).view(torch.float32).item() - float(zhat.max())) <= 1e-5 * float(zhat.max())
+    # pair launch
+    zb = torch.randn(R, 256, generator=g).to(dev)
+    yb, yqb = torch.empty_like(z), K.Planes(R, 256, device=dev, kind="h2")
+    stats_b, ws_b = torch.empty_like(stats), torch.empty_like(ws)
+    K.gn_relu_fwd_pair_q(lv, (z, gam, bet, None, yq, stats, ws, zh), (zb, gam, bet, yb, yqb, stats_b, ws_b, None))
+    K.gn_relu_fwd(lv, zb, gam, bet, y2, stats_b, ws_b)
+    close(yq, y)
+    close(yqb, y2)
+    assert torch.equal(yb, y2)
+    # backward
+    dy = (torch.randn(R, 256, generator=g) * 1e-4).to(dev)
+    dz, dg, db = torch.empty_like(z), torch.empty(256, device=dev), torch.empty(256, device=dev)
+    K.gn_relu_bwd(lv, dy, z, stats, gam, bet, dz, dg, db, ws)
+    for zslot in (zh, None):                                   # tracked |zhat| bound, and the hard sqrt(n - 1) one
+        dzq, dg2, db2 = K.Planes(R, 256, device=dev, kind="h2"), torch.empty(256, device=dev), torch.empty(256, device=dev)
+        K.gn_relu_bwd_q(lv, dy, z, stats, gam, bet, None, dzq, dg2, db2, ws, zhat_amax=zslot)
+        close(dzq, dz)
+        assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    # folded weights as plane pairs (RadetConvDesc.w16 = 3) against the fp32 fold, through the engine's descriptor table
+    from radet_amd import _lib
+    Co, Ci = 64, 96
+    w = torch.randn(Co, Ci, 3, 3, generator=g).to(dev)
+    bn = [t.to(dev) for t in (torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g), torch.randn(Co, generator=g),
+                              torch.rand(Co, generator=g) + 0.5)]
+    wf32, wft32, bias_f = torch.empty(Co * 9 * Ci, device=dev), torch.empty(Ci * 9 * Co, device=dev), torch.empty(Co, device=dev)
+    slots = torch.zeros(2, dtype=torch.int32, device=dev)
+    wfq = K.Planes(Co * 9, Ci, device=dev, kind="h2", amax=slots[1:2])
+    wftq = K.Planes(Ci * 9, Co if Co % 32 == 0 else 64, device=dev, kind="h2", amax=slots[1:2])
+    arr = (_lib.RadetConvDesc * 2)()
+    for d, (a, b, w16, sl) in zip(arr, ((wf32, wft32, 0, slots[0:1]), (wfq.t, wftq.t, 3, slots[1:2]))):
+        d.w, d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (C.c_void_p(t.data_ptr()) for t in (w, *bn))
+        d.wf, d.wft, d.bias_f = C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(bias_f.data_ptr())
+        d.cout, d.cin, d.kh, d.kw, d.eps, d.nsplit, d.w16 = Co, Ci, 3, 3, 1e-5, 1, w16
+        d.w_amax = C.c_void_p(sl.data_ptr())
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    K.fold_weights(table, 2)
+    assert int(slots[0]) == int(slots[1]) == int(wf32.abs().max().view(torch.int32))
+    close(wfq, wf32.view(Co * 9, Ci))
+    close(wftq, wft32.view(Ci * 9, Co))
 
 
 @pytest.mark.parametrize("tile", [64, 128])

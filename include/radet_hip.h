@@ -47,8 +47,8 @@ typedef struct RadetConvDesc {
     int w16;               /* 1: wf / wft are bf16 buffers (bf16-storage mode); 2: bf16 plane triples (rows [3][Cin] resp.
                               [3][wft_ld], see "planes" below); 3: fp16 plane pairs (rows [2][Cin] resp. [2][wft_ld], see
                               "plane pairs" below; needs w_amax); bias_f stays fp32 */
-    float* w_amax;         /* 4 bytes or NULL: amax slot of the folded weights (largest |wf|, bit pattern; written by
-                              radet_fold_weights) -- the weight operand's scale in the fp16 hi / lo arithmetic */
+    float* w_amax;         /* 64 words or NULL: amax slot (see RadetScales) of the folded weights, largest |wf|; zeroed and raised
+                              by radet_fold_weights -- the weight operand's scale in the fp16 hi / lo arithmetic */
 } RadetConvDesc;
 
 /* ---- amax slots (round 5, "fp16 hi / lo arithmetic").  The default fp32 conv arithmetic forms fp32-accurate products
@@ -57,12 +57,16 @@ typedef struct RadetConvDesc {
  * bf16 plane products of 0x1000000 (the dropped lo lo' term is <= 2^-24 relative; x = 2^-e (hi + 2^-11 lo) to 2^-23
  * relative for every element within 2^-27 of the tensor's largest).  fp16 has 5 exponent bits, so every operand tensor is
  * scaled by an exact power of two 2^e that puts its largest magnitude into [2^14, 2^15).  e comes from the tensor's "amax
- * slot": 4 bytes of device memory holding the bit pattern of a non-negative float that is >= every |element| (the largest
- * magnitude, or any bound on it), e = 141 - biased_exponent(slot) (0 for a zero slot).  Slots are maintained by the
- * kernels that WRITE a tensor: they raise the slot with atomicMax on the bit pattern (order independent, hence
- * deterministic) -- conv epilogues (RadetScales.y_amax), the _a variants of the elementwise kernels, radet_absmax -- or
- * store a bound they can derive before writing (GroupNorm: radet_gn_relu_fwd_q / _bwd_q).  The caller zeroes a slot
- * before the first kernel of a step that raises it.  Host struct of device pointers: */
+ * slot": RADET_AMAX_WORDS = 64 32-bit words, 128 bytes apart (radet_amax_slot_words() = 2048 words = 8 KiB per slot, the
+ * rest unused), of device memory whose LARGEST word is the bit pattern of a
+ * non-negative float that is >= every |element| (the largest magnitude, or any bound on it), e = 141 - biased_exponent(slot)
+ * (0 for a zero slot).  Slots are maintained by the kernels that WRITE a tensor: they raise one of the 64 words (chosen by
+ * workgroup and wave: thousands of waves raising ONE address serialise) with atomicMax on the bit pattern -- order
+ * independent, hence deterministic -- in conv epilogues (RadetScales.y_amax), the _a variants of the elementwise kernels and
+ * radet_absmax; or they store a bound they can derive before writing into word 0 (GroupNorm: radet_gn_relu_fwd_q / _bwd_q,
+ * radet_split_pairs; the other words must be zero).  The caller zeroes a slot before the first kernel of a step that
+ * raises it.  Host struct of device pointers (each to a 64-word slot): */
+#define RADET_AMAX_WORDS 64
 typedef struct RadetScales {
     const void* x_amax;    /* slot of the GEMM's x operand (dgrad: dy; wgrad: dy) */
     const void* w_amax;    /* slot of the w operand (RadetConvDesc.w_amax; wgrad: the slot of x) */
@@ -290,6 +294,7 @@ int radet_upsample_add_bwd_a(float* dsrc, const float* ddst, int B, int Ho, int 
                              void* stream);
 int radet_relu_bwd_a(const float* dy, const float* addend, const float* act, float* dx, size_t n, void* dx_amax, void* stream);
 int radet_absmax(const float* x, size_t n, void* amax, void* stream);
+int radet_amax_slot_words(void);   /* 32-bit words to allocate (and zero) per amax slot */
 /* GroupNorm + ReLU with plane outputs: y / dz as fp32 (may be NULL) and / or as planes (yp / dzp, may be NULL) */
 int radet_gn_relu_fwd_p(const float* z, const float* gamma, const float* beta, float* y, void* yp, float* stats,
                         float* partial_ws, int B, int C, int groups, float eps, int relu, const int* seg_desc, int nseg,

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradet_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("RADET_LIB", "libradet_hip.so"))
 
 _p = C.c_void_p
 _i = C.c_int
@@ -59,6 +59,7 @@ SIGNATURES = {
     "radet_upsample_add_bwd_a": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "radet_relu_bwd_a": (_i, [_p, _p, _p, _p, _sz, _p, _p]),
     "radet_absmax": (_i, [_p, _sz, _p, _p]),
+    "radet_amax_slot_words": (_i, []),
     "radet_pred3x3_patch": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "radet_conv2d_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "radet_conv2d_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

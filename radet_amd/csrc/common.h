@@ -188,10 +188,36 @@ __device__ __forceinline__ float4 ld4_pairs(const _Float16* p, size_t row, int C
     r.w = radet_pair_value((unsigned short)(h.y >> 16), (unsigned short)(l.y >> 16)) * inv_s;
     return r;
 }
-// largest magnitude seen by this wave -> the tensor's amax slot (bit patterns of non-negative floats order like unsigned
-// integers; atomicMax is order independent, so the slot's final value -- and with it every scale derived from it -- is
-// the same in every run).  One atomic per wave.
-__device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {
+// An amax slot is RADET_AMAX_WORDS (64) words = 256 bytes; its value is the LARGEST of the words.  Bit patterns of
+// non-negative floats order like unsigned integers and atomicMax is order independent, so the slot's final value -- and with
+// it every scale derived from it -- is the same in every run.  Why 64 words: the ~3000 waves of a launch's first round finish
+// together and each raises the slot once; on ONE address these device-scope atomics serialise (measured: a fixed +35 us per
+// launch on the 76 800-row layer1 convs; 64 words in two cache lines: still +10-16 us), spread by (workgroup, wave) over 64
+// words in 64 different 128-byte lines they do not (+0.5-3 us, tools/bench_h2.py).  A wave also looks before the
+// read-modify-write: the words only grow, and after the first arrivals almost every wave finds its maximum covered.
+#ifndef RADET_AMAX_WORDS
+#define RADET_AMAX_WORDS 64
+#endif
+#ifndef RADET_AMAX_STRIDE
+#define RADET_AMAX_STRIDE 32           // distance between the words of a slot, in words: one 128-byte line per word (see above)
+#endif
+__device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {        // largest magnitude seen by this wave
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        unsigned* w = slot + ((blockIdx.x * 8u + (threadIdx.x >> 6)) & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE;
+        const unsigned bits = __float_as_uint(m);
+        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w, bits);
+    }
 }
+// the slot's value; call with all 64 lanes of the wave active (every lane loads one word).  Wave-uniform.
+__device__ __forceinline__ unsigned radet_amax_read(const unsigned* slot) {
+    unsigned v = slot[(threadIdx.x & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned u = (unsigned)__shfl_xor((int)v, o, 64);
+        v = u > v ? u : v;
+    }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// a producer that KNOWS the value (a bound computed before writing): word 0, the other words stay zero
+__device__ __forceinline__ void radet_amax_store(unsigned* slot, unsigned bits) { slot[0] = bits; }

@@ -444,7 +444,7 @@ struct H2Scale {              // of one operand tensor: s = 2^e, s2 = 2^(e + 11)
     float s, s2, inv;
 };
 __device__ __forceinline__ H2Scale h2_scale(const unsigned* slot) {
-    const int e = radet_h2_exp(__builtin_nontemporal_load(slot));
+    const int e = radet_h2_exp(radet_amax_read(slot));          // (all lanes active: kernel prologue)
     H2Scale r;
     r.s = radet_pow2(e); r.s2 = radet_pow2(e + 11); r.inv = radet_pow2(-e);
     return r;

@@ -1117,8 +1117,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         a.it_per_split = nK;
         splitk_ws_floats = 0;
     }
-    if (tag & 64) {
-        if (skw) return RADET_ERR_ARG;
+    if (tag & 64) {                                            // (stream-K bits are ignored, as for the bf16-plane arithmetic)
         if (!radet_launch_igemm_h2(choice, a, st, tag, bk, splitk_ws_floats, stages3, radet_switches().no_tail_split))
             return RADET_ERR_ARG;
         return radet_check_launch();

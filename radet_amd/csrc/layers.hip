@@ -399,9 +399,11 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
     __shared__ float tile[FOLD_TO][FOLD_TC * 9 + 1];
     __shared__ float ssc[FOLD_TO];
     const int tid = threadIdx.x;
-    float ps = 1.f, ps2 = 2048.f;           // w16 = 3: the power-of-two scale of this conv's plane pairs (fold_amax_kernel ran before)
+    float wmax = 0.f;                       // largest |folded weight| this thread stores -> d.w_amax (fp32 / bf16 stores; the plane
+                                            // pairs of w16 = 3 need the maximum BEFORE they are written: fold_amax_kernel)
+    float ps = 1.f, ps2 = 2048.f;           // w16 = 3: the power-of-two scale of this conv's plane pairs
     if (d.w16 == 3) {
-        const int e = radet_h2_exp(*reinterpret_cast<const unsigned*>(d.w_amax));
+        const int e = radet_h2_exp(radet_amax_read(reinterpret_cast<const unsigned*>(d.w_amax)));
         ps = radet_pow2(e); ps2 = radet_pow2(e + 11);
     }
     if (KT > 9) {   // 7x7 stem: small, keep the simple element-wise path
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             float s = 1.f;
             if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
             const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
+            wmax = fmaxf(wmax, fabsf(v));
             stw(d.wf, oc, c, d.cin, v, d.w16, ps, ps2);
             if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16, ps, ps2);
         }
@@ -453,7 +456,9 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             for (int i = tid; i < no * run; i += 256) {
                 const int oo = i / run, r = i - oo * run;
                 const int t = r / nc, cl = r - t * nc;
-                stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, tile[oo][cl * KT + t] * ssc[oo], d.w16, ps, ps2);
+                const float v = tile[oo][cl * KT + t] * ssc[oo];
+                wmax = fmaxf(wmax, fabsf(v));
+                stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, v, d.w16, ps, ps2);
             }
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             }
         }
     }
+    if (d.w_amax && d.w16 != 3) radet_amax_publish(wmax, reinterpret_cast<unsigned*>(d.w_amax));     // (uniform branch)
     if (blockIdx.x == 0 && d.bias_f) {
         for (int o = tid; o < d.cout; o += 256) {
             float b = 0.f;
@@ -479,14 +485,14 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
 
 // amax slots of the folded weights (RadetConvDesc.w_amax, optional): largest |s[o] w[o][c][t]| of each conv -- the scale of
 // the fp16 hi / lo arithmetic's weight operand (common.h "h2"; wf and wft hold the same values).  Zeroed, then raised by
-// atomicMax (order independent), before fold_kernel writes the plane pairs of the w16 = 3 convs with it.
-__global__ void fold_amax_zero_kernel(const RadetConvDesc* __restrict__ table, int nconv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nconv && table[i].w_amax) *reinterpret_cast<unsigned*>(table[i].w_amax) = 0u;
+// atomicMax (order independent): by fold_kernel as it stores fp32 / bf16 weights, by the pass below for the convs whose
+// weights are stored as plane pairs (w16 = 3: the scale has to be known before the first store).
+__global__ void fold_amax_zero_kernel(const RadetConvDesc* __restrict__ table, int nconv) {      // one wave per conv
+    if (table[blockIdx.x].w_amax) reinterpret_cast<unsigned*>(table[blockIdx.x].w_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
 }
 __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
-    if (d.w_amax == nullptr) return;
+    if (d.w_amax == nullptr || d.w16 != 3) return;             // (the other convs' slots are raised by fold_kernel itself)
     const int K = d.cin * d.kh * d.kw;                         // OIHW: K contiguous weights per output channel
     float m = 0.f;
     for (int o = blockIdx.x; o < d.cout; o += gridDim.x) {
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __r
 
 extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {
     if (nconv <= 0) return RADET_OK;
-    hipLaunchKernelGGL(fold_amax_zero_kernel, dim3((nconv + 255) / 256), dim3(256), 0, (hipStream_t)stream, table_dev, nconv);
+    hipLaunchKernelGGL(fold_amax_zero_kernel, dim3(nconv), dim3(RADET_AMAX_WORDS), 0, (hipStream_t)stream, table_dev, nconv);
     hipLaunchKernelGGL(fold_amax_kernel, dim3(32, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     hipLaunchKernelGGL(fold_kernel, dim3(96, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     return radet_check_launch();
@@ -665,9 +671,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnFwdArgs<T> args, 
     float* __restrict__ partial = args.p[blockIdx.y].partial;
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) {            // (the apply kernel, which raises them, starts after this kernel has finished)
-        if (args.p[blockIdx.y].y_amax) *args.p[blockIdx.y].y_amax = 0u;
-        if (args.p[blockIdx.y].zhat_amax) *args.p[blockIdx.y].zhat_amax = 0u;
+    if (blockIdx.x == 0 && tid < RADET_AMAX_WORDS) {   // (the apply kernel, which raises them, starts after this kernel has finished)
+        if (args.p[blockIdx.y].y_amax) args.p[blockIdx.y].y_amax[tid * RADET_AMAX_STRIDE] = 0u;
+        if (args.p[blockIdx.y].zhat_amax) args.p[blockIdx.y].zhat_amax[tid * RADET_AMAX_STRIDE] = 0u;
     }
     const int col = tid & 63, prow = tid >> 6;
     float s = 0.f, ss = 0.f;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnFwdArgs<T> args, 
         const float gmax = fmaxf(fmaxf(bnd[0], bnd[1]), fmaxf(bnd[2], bnd[3]));
         const float bmax = fmaxf(fmaxf(bnd[4], bnd[5]), fmaxf(bnd[6], bnd[7]));
         const unsigned bits = __float_as_uint(gmax * sqrtf((float)(nmax - 1)) + bmax);
-        if (blockIdx.x == 0 && tid == 0) *yq_amax = bits;
+        if (blockIdx.x == 0 && tid == 0) radet_amax_store(yq_amax, bits);
         const int e = radet_h2_exp(bits);
         qs = radet_pow2(e); qs2 = radet_pow2(e + 11);
     }
@@ -1026,9 +1032,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         const float gmax = fmaxf(fmaxf(bnd[4], bnd[5]), fmaxf(bnd[6], bnd[7]));
         int nmax = 1;
         for (int l = 0; l < segs.nseg; ++l) nmax = max(nmax, segs.s[l].Ho * segs.s[l].Wo * 8);
-        const float zh = zhat_amax ? __uint_as_float(*zhat_amax) : sqrtf((float)(nmax - 1));
-        const unsigned bits = __float_as_uint(rstd_max * gmax * __uint_as_float(*dy_amax) * (2.0f + zh));
-        if (blockIdx.x == 0 && tid == 0) *dzq_amax = bits;
+        const float zh = zhat_amax ? __uint_as_float(radet_amax_read(zhat_amax)) : sqrtf((float)(nmax - 1));
+        const unsigned bits = __float_as_uint(rstd_max * gmax * __uint_as_float(radet_amax_read(dy_amax)) * (2.0f + zh));
+        if (blockIdx.x == 0 && tid == 0) radet_amax_store(dzq_amax, bits);
         const int e = radet_h2_exp(bits);
         qs = radet_pow2(e); qs2 = radet_pow2(e + 11);
     }
@@ -1323,6 +1329,7 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t n4, unsigned* 
     }
     radet_amax_publish(am, amax);
 }
+extern "C" int radet_amax_slot_words(void) { return RADET_AMAX_WORDS * RADET_AMAX_STRIDE; }
 extern "C" int radet_absmax(const float* x, size_t n, void* amax, void* stream) {
     if (n % 4 || amax == nullptr) return RADET_ERR_ARG;
     if (n == 0) return RADET_OK;
@@ -1410,10 +1417,10 @@ extern "C" int radet_merge_planes(const void* src, float* dst, size_t rows, int 
 // same bits are copied to dst_amax for the GEMMs that read the pairs.  merge: the inverse (tests / API boundary).
 __global__ void split_pairs_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, size_t rows, int C4, int src_ld4,
                                    const unsigned* __restrict__ src_amax, unsigned* __restrict__ dst_amax) {
-    const unsigned bits = *src_amax;
+    const unsigned bits = radet_amax_read(src_amax);
     const int e = radet_h2_exp(bits);
     const float s = radet_pow2(e), s2 = radet_pow2(e + 11);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *dst_amax = bits;
+    if (blockIdx.x == 0 && threadIdx.x == 0) radet_amax_store(dst_amax, bits);
     const size_t total = rows * (size_t)C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / C4;
@@ -1423,7 +1430,7 @@ __global__ void split_pairs_kernel(const float* __restrict__ src, _Float16* __re
 }
 __global__ void merge_pairs_kernel(const _Float16* __restrict__ src, float* __restrict__ dst, size_t rows, int C4, int dst_ld4,
                                    const unsigned* __restrict__ amax) {
-    const float inv = radet_pow2(-radet_h2_exp(*amax));
+    const float inv = radet_pow2(-radet_h2_exp(radet_amax_read(amax)));
     const size_t total = rows * (size_t)C4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / C4;

@@ -222,13 +222,13 @@ class Engine:
                 n_wft += c.cin * c.k * c.k * ld
         self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
         # amax slots of the folded weights (fp16 hi / lo arithmetic): one per conv, written by radet_fold_weights
-        self.w_amax = torch.zeros(len(self.convs), dtype=torch.int32, device=dev)
+        self.w_amax = K.new_amax(dev, len(self.convs))
         self._w_amax_keys = []
         o_w = o_b = o_t = 0
         towers = (self.cls_tower + self.reg_tower) if self.p3 else []
         pkind = "h2" if self.h2 else "b3"
         for ci, c in enumerate(self.convs):
-            c.w_amax = self.w_amax[ci:ci + 1]
+            c.w_amax = self.w_amax[ci]
             c.w16 = (3 if self.h2 else 2) if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
             c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
@@ -303,15 +303,15 @@ class Engine:
         self.buf = {}
         # amax slots of the activation / gradient buffers (fp16 hi / lo arithmetic): raised by the kernels that write a
         # buffer, zeroed at the start of every forward pass; amax_aux: slots their producers reset themselves (GroupNorm)
-        self.amax_act = torch.zeros(1024, dtype=torch.int32, device=dev)
-        self.amax_aux = torch.zeros(64, dtype=torch.int32, device=dev)
+        self.amax_act = K.new_amax(dev, 768)
+        self.amax_aux = K.new_amax(dev, 32)
         self._amax_keys = []
         n_slot = [0, 0]
 
         def slot(aux=False):
             i = n_slot[aux]
             n_slot[aux] += 1
-            return (self.amax_aux if aux else self.amax_act)[i:i + 1]
+            return (self.amax_aux if aux else self.amax_act)[i]
 
         def new(name, rows, ch, dtype=None):
             t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)

@@ -477,7 +477,7 @@ def _tune_slots(g, *tensors):
     keys = []
     if _h2key(g):
         for t in tensors:
-            s = torch.zeros(1, dtype=torch.int32, device=t.device)
+            s = new_amax(t.device)
             if t.is_floating_point() and t.dtype == torch.float32:
                 s.fill_(0x42000000)                 # 32.0: above every |element| of the N(0, 1) / N(0, 0.05) scratch operands and
             keys.append(register_amax(t, s))        # of what the timed convs write from them
@@ -499,16 +499,30 @@ H2 = 0x8000000                            # fp16 hi / lo arithmetic (with X3 or 
 
 
 # ---------------------------------------------------------------------- amax slots (fp16 hi / lo arithmetic, radet_hip.h)
-# A slot is a 1-element int32 device tensor holding the bit pattern of a float >= every |element| of "its" tensor.  The
+# A slot is AMAX_WORDS (64) int32 words of device memory; its value -- the LARGEST word, read as the bit pattern of a float -- is
+# >= every |element| of "its" tensor (64 words: thousands of waves raise a slot at once, include/radet_hip.h).  The
 # engine registers the slots of its buffers here (activations by storage, so that row slices of a buffer resolve to the
 # buffer's slot; weights by exact address, they are views of one arena); the conv launchers look the operands' slots up.
 # A tensor without a slot (ad-hoc calls: tests, the autotuner) gets one computed on the spot by a stand-alone pass.
+AMAX_WORDS = 64
 _AMAX_EXACT = {}
 _AMAX_STORAGE = {}
 
 
+def new_amax(device, n=None):
+    """a zeroed slot (int32 [radet_amax_slot_words()]), or n of them ([n, words])"""
+    global AMAX_WORDS
+    AMAX_WORDS = _lib.load().radet_amax_slot_words()
+    return torch.zeros((AMAX_WORDS,) if n is None else (n, AMAX_WORDS), dtype=torch.int32, device=device)
+
+
+def amax_value(slot):
+    """the float a slot stands for (host synchronisation: tests / debugging)"""
+    return float(slot.max().view(torch.float32))
+
+
 def register_amax(t, slot, by_storage=False):
-    """slot: 1-element int32 tensor.  Returns the registry key (for unregister_amax)."""
+    """slot: [64] int32 tensor (new_amax).  Returns the registry key (for unregister_amax)."""
     if by_storage:
         k = ("s", t.untyped_storage().data_ptr())
         _AMAX_STORAGE[k[1]] = slot
@@ -544,7 +558,7 @@ def amax_slot(t, compute=False):
             if s is not None:
                 _AMAX_MEMO[p] = s
     if s is None and compute:
-        s = torch.zeros(1, dtype=torch.int32, device=t.device)
+        s = new_amax(t.device)
         absmax(t, s)
     return s
 
@@ -577,7 +591,7 @@ class Planes:
     """A [rows, C] fp32 tensor in the operand format of the conv GEMMs (include/radet_hip.h).  kind "b3": bf16 plane triples,
     `t` is a bf16 tensor [rows, 3 * C] whose row r holds hi | mid | lo with hi + mid + lo == the fp32 value exactly.
     kind "h2": fp16 plane pairs, `t` is an fp16 tensor [rows, 2 * C] (32-channel groups [hi | lo]) of the values scaled by
-    the power of two of `amax` (a 1-element int32 tensor: the tensor's amax slot).  Only the conv GEMMs read it."""
+    the power of two of `amax` (the tensor's amax slot, see new_amax).  Only the conv GEMMs read it."""
 
     def __init__(self, rows, C, device=None, t=None, kind="b3", amax=None):
         self.rows, self.C, self.kind = int(rows), int(C), kind
@@ -587,7 +601,7 @@ class Planes:
         self.t = t
         self.amax = amax
         if kind == "h2" and amax is None:
-            self.amax = torch.zeros(1, dtype=torch.int32, device=t.device)
+            self.amax = new_amax(t.device)
 
     def __getitem__(self, sl):
         assert isinstance(sl, slice) and sl.step in (None, 1)
@@ -624,7 +638,7 @@ def split_planes(src, dst, src_amax=None):
     if dst.kind == "h2":
         sa = src_amax if src_amax is not None else amax_slot(src)
         if sa is None:
-            sa = torch.zeros(1, dtype=torch.int32, device=src.device)
+            sa = new_amax(src.device)
             absmax(src.contiguous(), sa)
         _lib.call("radet_split_pairs", src.data_ptr(), _ptr(dst.t), C.c_size_t(src.shape[0]), src.shape[1], src.stride(0),
                   _ptr(sa), _ptr(dst.amax), _stream())

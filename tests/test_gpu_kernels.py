@@ -408,7 +408,7 @@ def test_plane_pair_operand_conv(K, case):
     xr = to_rows(x).to(dev)
     xp = K.Planes.from_float(xr, kind="h2")
     assert xp.t.dtype == torch.float16 and xp.t.shape == (lv.rows, 2 * Cin)
-    assert int(xp.amax) == int(xr.abs().max().view(torch.int32))          # the slot holds the bit pattern of the largest |x|
+    assert K.amax_value(xp.amax) == float(xr.abs().max())               # the slot holds the bit pattern of the largest |x|
     back = xp.to_float()
     assert float(((back - xr).abs() / xr.abs().clamp_min(float(xr.abs().max()) * 2.0 ** -26)).max()) <= 2.0 ** -22
     wp = K.Planes.from_float(fold_w(w).reshape(Cout * k * k, Cin).to(dev), kind="h2")
@@ -453,23 +453,23 @@ def test_plane_pair_outputs_of_groupnorm_and_fold(K):
 
     def close(planes, ref):
         got = planes.to_float()
-        bound = torch.tensor(int(planes.amax), dtype=torch.int32).view(torch.float32).item()
+        bound = K.amax_value(planes.amax)
         assert bound >= float(ref.abs().max()), (bound, float(ref.abs().max()))
         tol = ref.abs() * 2.0 ** -22 + bound * 2.0 ** -36
         assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() / tol).max())
 
     yq, y2 = K.Planes(R, 256, device=dev, kind="h2"), torch.empty_like(z)
-    ya, zh = torch.zeros(1, dtype=torch.int32, device=dev), torch.full((1,), 77, dtype=torch.int32, device=dev)
+    ya, zh = K.new_amax(dev), K.new_amax(dev).fill_(77)
     key = K.register_amax(y2, ya)
     K.gn_relu_fwd_q(lv, z, gam, bet, y2, yq, stats2, ws, zhat_amax=zh)
     K.unregister_amax([key])
     assert torch.equal(y2, y) and torch.equal(stats2, stats)
     close(yq, y)
-    assert int(ya) == int(y.abs().max().view(torch.int32))
+    assert K.amax_value(ya) == float(y.abs().max())
     zhat = torch.cat([((z[r0:r1].view(lv.B, -1, 32, 8) - m[:, None, :, None]) * r[:, None, :, None]).abs().reshape(-1)
                       for (r0, r1), m, r in ((lv.level_rows(l), stats.view(-1, 32, 2)[l * lv.B:(l + 1) * lv.B, :, 0],
                                               stats.view(-1, 32, 2)[l * lv.B:(l + 1) * lv.B, :, 1]) for l in range(len(lv)))])
-    assert abs(torch.tensor(int(zh), dtype=torch.int32).view(torch.float32).item() - float(zhat.max())) <= 1e-5 * float(zhat.max())
+    assert abs(K.amax_value(zh) - float(zhat.max())) <= 1e-5 * float(zhat.max())
     # pair launch
     zb = torch.randn(R, 256, generator=g).to(dev)
     yb, yqb = torch.empty_like(z), K.Planes(R, 256, device=dev, kind="h2")
@@ -495,18 +495,18 @@ def test_plane_pair_outputs_of_groupnorm_and_fold(K):
     bn = [t.to(dev) for t in (torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g), torch.randn(Co, generator=g),
                               torch.rand(Co, generator=g) + 0.5)]
     wf32, wft32, bias_f = torch.empty(Co * 9 * Ci, device=dev), torch.empty(Ci * 9 * Co, device=dev), torch.empty(Co, device=dev)
-    slots = torch.zeros(2, dtype=torch.int32, device=dev)
-    wfq = K.Planes(Co * 9, Ci, device=dev, kind="h2", amax=slots[1:2])
-    wftq = K.Planes(Ci * 9, Co if Co % 32 == 0 else 64, device=dev, kind="h2", amax=slots[1:2])
+    slots = K.new_amax(dev, 2)
+    wfq = K.Planes(Co * 9, Ci, device=dev, kind="h2", amax=slots[1])
+    wftq = K.Planes(Ci * 9, Co, device=dev, kind="h2", amax=slots[1])
     arr = (_lib.RadetConvDesc * 2)()
-    for d, (a, b, w16, sl) in zip(arr, ((wf32, wft32, 0, slots[0:1]), (wfq.t, wftq.t, 3, slots[1:2]))):
+    for d, (a, b, w16, sl) in zip(arr, ((wf32, wft32, 0, slots[0]), (wfq.t, wftq.t, 3, slots[1]))):
         d.w, d.bn_gamma, d.bn_beta, d.bn_mean, d.bn_var = (C.c_void_p(t.data_ptr()) for t in (w, *bn))
         d.wf, d.wft, d.bias_f = C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(bias_f.data_ptr())
         d.cout, d.cin, d.kh, d.kw, d.eps, d.nsplit, d.w16 = Co, Ci, 3, 3, 1e-5, 1, w16
         d.w_amax = C.c_void_p(sl.data_ptr())
     table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
     K.fold_weights(table, 2)
-    assert int(slots[0]) == int(slots[1]) == int(wf32.abs().max().view(torch.int32))
+    assert K.amax_value(slots[0]) == K.amax_value(slots[1]) == float(wf32.abs().max())
     close(wfq, wf32.view(Co * 9, Ci))
     close(wftq, wft32.view(Ci * 9, Co))
 

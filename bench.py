@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 IMG_H, IMG_W, PER_GPU_BATCH = 480, 640, 4
 TRAIN_FLOP_PER_IMG = 341.1e9      # conv MACs fwd + dgrad + wgrad (frozen stem/layer1), x2
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 / _f16, dense
+# issued 16-bit MACs per algorithmic fp32 MAC of the default fp32 arithmetic (3: fp16 hi / lo planes; 6 with RADET_X3=bf16)
+ISSUED_PER_MAC = 6.0 if os.environ.get("RADET_X3", "h2") in ("bf16", "b3") else 3.0
 
 
 INFER_FLOP_PER_IMG = 120.96e9      # forward conv MACs x 2 of one 640x480 image (backbone + FPN + head)
@@ -38,7 +40,9 @@ INFER_FLOP_PER_IMG = 120.96e9      # forward conv MACs x 2 of one 640x480 image 
 
 class ClockSampler:
     """Shader clock and socket power of the visible GPU, read with `rocm-smi --showclocks --showpower` (~80 ms per call) in a
-    background thread while a region runs; medians of the samples taken under load."""
+    background thread while a region runs; medians of the samples taken under load.  Only ever started AFTER the timed
+    region (every sample starts a Python interpreter, which competes with the launch loop for the host's cores), on rank 0
+    of single-GPU runs."""
 
     def __init__(self):
         import threading
@@ -186,8 +190,8 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
     Per kernel instantiation: launches per step, average duration in the step, algorithmic flops, share of the summed
     conv-GEMM time.  `roofline` = the instantiation with the LARGEST share, in the step and alone on the device (every
     distinct launch of it replayed by itself); `roofline_all_conv_gemms` = all of them together; `roofline_tower_forward` =
-    the grouped head-tower forward launch (the kernel the previous rounds reported).  The plane arithmetics issue 6 bf16
-    MACs per algorithmic fp32 MAC: `achieved` is priced in issued bf16 flop against the dense bf16 MFMA peak, the
+    the grouped head-tower forward launch (the kernel the previous rounds reported).  The plane arithmetics issue 3 f16 (default)
+    or 6 bf16 MACs per algorithmic fp32 MAC: `achieved` is priced in issued 16-bit flop against the dense f16 / bf16 MFMA peak, the
     fp32-equivalent rate is next to it."""
     fam = {}
     for ev in events:
@@ -201,12 +205,16 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
             return None
         return int(k.split("<")[1].split(">")[0].split(", ")[4])
 
-    def planes(k):                          # launches whose products are formed from bf16 planes (6 bf16 MACs per fp32 MAC)
-        t = igemm_tag(k)
-        return (t is not None and (t & 24) != 0) or "pred3x3" in k or ("wgrad" in k and ("planes" in k or "9p" in k))
+    def planes(k):                          # issued 16-bit MACs per algorithmic fp32 MAC: 3 (two fp16 planes per operand), 6 (three
+        t = igemm_tag(k)                    # bf16 planes), or 0 (native fp32 MFMA)
+        if (t is not None and (t & 64)) or ("wgrad" in k and ("fp16" in k or "9q" in k)):
+            return 3.0
+        if (t is not None and (t & 24) != 0) or "pred3x3" in k or ("wgrad" in k and ("planes" in k or "9p" in k)):
+            return 6.0
+        return 0.0
 
     def entry(k, f, alone=False):
-        mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if planes(k) else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        mult, peak = (planes(k), BF16_MFMA_PEAK_TFLOPS) if planes(k) else (1.0, FP32_MFMA_PEAK_TFLOPS)
         if math in ("bf16", "bf16-storage") and not k.startswith("stem"):    # one issued bf16 MAC per algorithmic MAC
             mult, peak = 1.0, BF16_MFMA_PEAK_TFLOPS
         tf = f["flops"] / (f["ms"] * 1e-3) / 1e12
@@ -255,7 +263,7 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
                     "their tiles interleave), so a launch's duration covers other launches' work too; `alone` = the same launches "
                     "one at a time.  The step runs at the socket power limit (1.36 kW, ~2.2 GHz: profiles/round3_clock_power.txt); "
                     "`peak` is the 2.4 GHz figure.")
-    mult_all = 6.0 if x3 else 1.0
+    mult_all = (3.0 if getattr(rt.engine, "h2", False) else 6.0) if x3 else 1.0
     peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
     if math in ("bf16", "bf16-storage"):
         mult_all, peak_all = 1.0, BF16_MFMA_PEAK_TFLOPS
@@ -323,7 +331,8 @@ def stage_table(events, steps, mult, peak):
             "note": "from the HIP events of the instrumented pass (conv GEMM launches only: GroupNorm / loss / pooling / optimizer "
                     "kernels are not in it); wall = first start .. last end of the row's launches inside one step, averaged over "
                     "the steps; the stem runs on the fp32 MFMA pipe (priced against 157.3 TFLOP/s), everything else against "
-                    "the pipe of the step's arithmetic (x6 issued bf16 MACs / 2500 for the default fp32 mode)"}
+                    "the pipe of the step's arithmetic (x3 issued f16 MACs / 2500 for the default fp32 mode; x6 bf16 MACs with "
+                    "RADET_X3=bf16)"}
 
 
 def _child(argv, timeout=900):
@@ -367,8 +376,8 @@ def extras(args):
         out["bs16"] = {
             "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"], "per_gpu_batch": 16,
             "host_enqueue_ms_per_step": d.get("host_enqueue_ms_per_step"),
-            "step_level": {"achieved": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * 6, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * 6 / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "step_level": {"achieved": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * ISSUED_PER_MAC, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(d["value"] * TRAIN_FLOP_PER_IMG / 1e12 * ISSUED_PER_MAC / BF16_MFMA_PEAK_TFLOPS, 4)},
             "clock_power": d.get("clock_power"),
             "note": "same fp32 step at the reference config's samples_per_gpu = 16 (configs/bop/r50_ycbv_pbr.py:85), "
                     "`python bench.py --batch 16`; secondary -- the headline is BASELINE's bs 4"}
@@ -395,6 +404,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-mfma-line", action="store_true", help="skip the native-f32-MFMA comparison measurement")
+    ap.add_argument("--no-clock-sampler", action="store_true", help="skip the rocm-smi clock / power window after the timed region")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (inference config 4, R101 config 5, synthetic trained-like weights)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH,
@@ -407,6 +417,22 @@ def main():
                          "rounded to bf16 into the matrix cores, fp32 accumulate / storage / optimizer (secondary line)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started plainly: become the launcher -- N worker processes through torch.distributed.run
+        # (one rank per GPU, rendezvous on 127.0.0.1), started as a CHILD before this process has touched the GPU, rank 0's JSON
+        # line relayed.  (What the reference's tools/train.py:117-124 leaves to its launcher + init_dist.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{"):
+                print(ln, flush=True)
+        sys.exit(r.returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -459,9 +485,6 @@ def main():
         if first is None:
             first = out_l.clone()
     sync()
-    sampler = ClockSampler() if rank == 0 else None
-    if sampler is not None:
-        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out_l = rt.train_step(img, tg)
@@ -489,15 +512,16 @@ def main():
         torch.cuda.synchronize()
         dt_ev = time.perf_counter() - t1
         K.EVENTS = None
+    sampler = ClockSampler() if (rank == 0 and world == 1 and not args.no_clock_sampler) else None
     if sampler is not None:
-        # the timed region of a default run lasts 0.2 s = two or three rocm-smi reads: keep the same step running for ~1.5 s more
-        # (untimed) so that the medians rest on >= 15 samples; both windows are reported
+        # clock / power of the steady state: the same step kept running for ~1.5 s (untimed, after everything that is timed)
+        # while rocm-smi is polled from a thread
+        sampler.__enter__()
         t_keep0 = time.perf_counter()
-        if world == 1:
-            while time.perf_counter() - t_keep0 < 1.5:
-                for _ in range(10):
-                    rt.train_step(img, tg)
-                torch.cuda.synchronize()
+        while time.perf_counter() - t_keep0 < 1.5:
+            for _ in range(10):
+                rt.train_step(img, tg)
+            torch.cuda.synchronize()
         t_keep1 = time.perf_counter()
         sampler.__exit__()
     assert np.isfinite(losses).all(), f"non-finite losses {losses}"
@@ -553,14 +577,21 @@ def main():
                             "note": "each rank's own wall time of the K timed steps (its synchronize + the closing barrier included); a "
                                     "straggler shows as min << max"}
         if sampler is not None:
-            out["clock_power"] = sampler.report(t0, t_end, "the timed region")
-            if world == 1:
-                out["clock_power"]["sustained"] = sampler.report(t_keep0, t_keep1, "~1.5 s of the same step right after the timed region")
+            out["clock_power"] = sampler.report(t_keep0, t_keep1, "~1.5 s of the same step right after the timed region")
         if comm is not None:
             out["comm"] = comm
         x3 = bool(rt.engine.x3)
         if args.math.startswith("fp32"):
+            h2 = bool(getattr(rt.engine, "h2", False))
             out["config"]["arithmetic"] = (
+                "f32 tensors, f32-accurate conv GEMMs: every f32 operand is scaled by an exact power of two (from the tensor's "
+                "largest magnitude, tracked by the kernel that writes it) and split into two f16 numbers hi + 2^-11 lo (in "
+                "registers; the head towers' activations / gradients / weights once, by the kernel that produces them); "
+                "hi hi' + 2^-11 (hi lo' + lo hi') goes through three v_mfma_f32_32x32x16_f16 per K = 16 step with f32 accumulation "
+                "(error vs f64 <= that of v_mfma_f32_32x32x2_f32 incl. operands spanning 2^24 inside a tensor: "
+                "tests/test_gpu_kernels.py::test_fp32_from_fp16_pairs_is_as_accurate_as_the_fp32_mfma, DESIGN.md); "
+                "RADET_X3=bf16 = the 6-product bf16-plane scheme of rounds 2-4, `--math fp32-mfma` / RADET_X3=0 = native f32 MFMA"
+                if h2 else
                 "f32 tensors, f32-accurate conv GEMMs: every f32 operand is split exactly into three bf16 planes (in "
                 "registers; the head towers' activations / gradients / weights once, by the kernel that produces them), "
                 "6 of the 9 plane products go through v_mfma_f32_32x32x16_bf16 with f32 accumulation "
@@ -587,7 +618,23 @@ def main():
             except Exception as e:      # the headline line must not depend on the comparison run
                 out["fp32_mfma_native"] = {"error": repr(e)[:200]}
         if world == 1 and args.math == "fp32" and args.weights == "init" and not args.no_extras:
-            out.update(extras(args))
+            ex = extras(args)
+            out.update(ex)
+            # the secondary numbers once more inside `config` (numbers only): the driver's record keeps `config` verbatim
+            sec = {}
+            for key, fields in (("infer", ("value",)), ("r101", ("ms_per_step", "value")), ("bf16_storage", ("value", "ms_per_step")),
+                                ("bs16", ("value", "ms_per_step")), ("synthetic_trained_like_weights", ("value",))):
+                for fld in fields:
+                    v = ex.get(key, {}).get(fld)
+                    if isinstance(v, (int, float)):
+                        sec[f"{key}_{fld}"] = v
+            v = ex.get("infer", {}).get("step_level", {}).get("frac")
+            if isinstance(v, (int, float)):
+                sec["infer_frac"] = v
+            if isinstance(out.get("fp32_mfma_native", {}).get("value"), (int, float)):
+                sec["fp32_mfma_native_value"] = out["fp32_mfma_native"]["value"]
+            sec["host_enqueue_ms"] = out["host_enqueue_ms_per_step"]
+            out["config"]["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

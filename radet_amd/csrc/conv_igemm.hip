@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
     const int tc = id % tilesC;
     const int tap = id / tilesC;
     const int o0 = to * BM, c0 = tc * BN;
-    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
+    const int* tab_tap = a.rowtab ? a.rowtab + (size_t)tap * a.Mp : nullptr;
 
     const int p_begin = split * a.chunks_per_split * 16;    // chunks_per_split counts 16-pixel chunks
     int p_end = p_begin + a.chunks_per_split * 16;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
         if (bi >= 0 && bi < B_INSTR) {
             const int blk = bi * 8 + l_blk;
             const int m = p_begin + 4 * (blk / CBB) + l_prow;
-            brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];         // unconditional (clamped) load, masked at use
+            brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;   // unconditional (clamped) load, masked at use
             bok[k] = m < p_end;
         }
     }
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int blk = (ins - A_INSTR) * 8 + l_blk;
                 const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
-                brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];
+                brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;
                 bok[k] = m < p_end;
             }
         }
@@ -1015,7 +1015,10 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         if (Cin % 32 != 0) return RADET_ERR_ARG;               // 16 channel pairs per K step at least
         Cin /= 2;                                              // K is counted in channel pairs (4-byte units) from here on
     }
-    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || gather_table == nullptr || KH * KW > 16) return RADET_ERR_ARG;
+    // (gather_table may be NULL for a 1 x 1 / stride 1 conv whose input and output rows coincide: GEMM row m reads row m)
+    if (Cin % 16 != 0 || Cin <= 0 || Cout <= 0 || M <= 0 || KH * KW > 16 ||
+        (gather_table == nullptr && (KH * KW != 1 || out_rows != nullptr || cls != nullptr)))
+        return RADET_ERR_ARG;
     ConvArgs a;
     a.io = h16 ? (((tile_override >> 16) & 1) ? 2 : 1) : 0;
     a.out_rows = out_rows;
@@ -1220,7 +1223,7 @@ static int wgrad_impl(const float* dy, const float* x, float* slabs, float* dbia
                       int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream, const RadetScales* sc) {
     // dy rows must be 16-byte aligned and hold whole float4s for every real channel (pad small heads with zeros)
     if (Cin % 4 != 0 || S < 1 || ld_dy < Cout || (ld_dy & 3) || ((Cout + 3) / 4) * 4 > ld_dy || M <= 0 ||
-        gather_table == nullptr)
+        (gather_table == nullptr && KH * KW != 1))
         return RADET_ERR_ARG;
     if ((flags & 2) && ((Cout + 7) / 8) * 8 > ld_dy) return RADET_ERR_ARG;   // whole 8-channel groups per dy row
     WgradArgs a;
@@ -1325,7 +1328,7 @@ extern "C" int radet_conv2d_wgrad_group(const RadetWgradJob* jobs, int njobs, in
     int total = 0;
     for (int i = 0; i < njobs; ++i) {
         const RadetWgradJob& j = jobs[i];
-        if (j.Cin % 4 != 0 || j.S < 1 || j.ld_dy < j.Cout || (j.ld_dy & 3) || j.M <= 0 || j.gather_table == nullptr ||
+        if (j.Cin % 4 != 0 || j.S < 1 || j.ld_dy < j.Cout || (j.ld_dy & 3) || j.M <= 0 || (j.gather_table == nullptr && j.KH * j.KW != 1) ||
             j.Cout % bm != 0 || j.Cin % bm != 0)
             return RADET_ERR_ARG;
         WgradArgs& a = g.p[i];

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     for (int k = 0; k < A_PW; ++k) {
         const int r = (wave + NW * k) * RPI + lrow;
         akq[k] = 4 * ((lane % F4) ^ ((r / RPB) % F4));
-        arow[k] = (nK > 0 && wave + NW * k < A_INSTR) ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : -1;
+        // (no table: a 1 x 1 / stride 1 conv, GEMM row m reads input row m -- one dependent global load less in the prologue)
+        arow[k] = (nK > 0 && wave + NW * k < A_INSTR)
+                      ? (a.rowtab ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : (m0 + r < a.M ? m0 + r : -1)) : -1;
     }
 #pragma unroll
     for (int k = 0; k < B_PW; ++k) {
@@ -201,10 +203,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         if (cmaj) {
             if (++ld_tap == KTt) { ld_tap = 0; ld_c0 += BK; }
             wtap = a.tap_ids[tbase + ld_tap];
+            if (a.rowtab) {
 #pragma unroll
-            for (int k = 0; k < A_PW; ++k)
-                if (A_FULL || wave + NW * k < A_INSTR)
-                    arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + NW * k) * RPI + lrow];
+                for (int k = 0; k < A_PW; ++k)
+                    if (A_FULL || wave + NW * k < A_INSTR)
+                        arow[k] = a.rowtab[(size_t)ld_tap * a.Mp + m0 + (wave + NW * k) * RPI + lrow];
+            }
             return;                     // (abase follows in refresh_abase(), right before the next stage's first piece)
         }
         ld_c0 += BK;

@@ -292,7 +292,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     const int tc = id % tilesC;
     const int tap = id / tilesC;
     const int o0 = to * BM, c0 = tc * BN;
-    const int* tab_tap = a.rowtab + (size_t)tap * a.Mp;
+    const int* tab_tap = a.rowtab ? a.rowtab + (size_t)tap * a.Mp : nullptr;     // (null: 1 x 1 / stride 1, pixel m reads row m)
 
     const int p_begin = split * a.chunks_per_split * 16;
     int p_end = p_begin + a.chunks_per_split * 16;
@@ -308,7 +308,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
         bok[k] = false;
         if (bi >= 0 && bi < B_INSTR) {
             const int m = p_begin + bi * RB + (lane * 4) / BN;
-            brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];         // unconditional (clamped) load; rows >= p_end are masked at use
+            brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;   // unconditional (clamped) load; rows >= p_end are masked at use
             bok[k] = m < p_end;
         }
     }
@@ -345,7 +345,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
             if (ins >= A_INSTR && ins < N_INSTR) {
                 // unconditional (clamped) load; rows >= p_end are masked at use
                 const int m = p0 + BP + (ins - A_INSTR) * RB + (lane * 4) / BN;
-                brow[k] = tab_tap[m < a.Mp ? m : a.Mp - 1];
+                brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;
                 bok[k] = m < p_end;
             }
         }

@@ -369,7 +369,12 @@ class Engine:
         self.R = R
         new("P", R, f)
         new("dP", R, f)
-        new("dP_tmp", R, f)
+        # gradients w.r.t. P5 / P6 with the stride-2 convs' contributions added: one buffer (and one amax slot) EACH -- the
+        # weight-gradient GEMM that reads the first one runs asynchronously, and a slot shared with the second buffer could be
+        # raised under it (the operand scale, hence the low bits of the result, would depend on the streams' timing)
+        for lvl in (2, 3):
+            r0, r1 = self.plv.level_rows(lvl)
+            new(f"dP_tmp{lvl}", r1 - r0, f)
         pkind = "h2" if self.h2 else "b3"
         if self.p3:
             self.buf["Pp"] = K.Planes(R, f, device=dev, kind=pkind)      # P as planes: input of both towers' first conv / wgrad
@@ -1115,14 +1120,14 @@ class Engine:
         P = b["P"]
         lr = [self.plv.level_rows(i) for i in range(5)]
         sl = lambda t, i: t[lr[i][0]:lr[i][1]]  # noqa: E731
-        tmp = b["dP_tmp"]
+        tmp2, tmp3 = b["dP_tmp2"], b["dP_tmp3"]
         # P7 = conv4(P6); P6 = conv3(P5)
         c4, c3 = self.fpn[4], self.fpn[3]
         self._wgrad_async(c4.geom, sl(dP, 4), sl(P, 3), c4.slabs, c4.dbias_partials, conv=c4)
-        K.conv_dgrad(c4.geom, sl(dP, 4), c4.wft, sl(tmp, 3), addend=sl(dP, 3))
-        self._wgrad_async(c3.geom, sl(tmp, 3), sl(P, 2), c3.slabs, c3.dbias_partials, conv=c3)
-        K.conv_dgrad(c3.geom, sl(tmp, 3), c3.wft, sl(tmp, 2), addend=sl(dP, 2))
-        srcs = [sl(dP, 0), sl(dP, 1), sl(tmp, 2)]
+        K.conv_dgrad(c4.geom, sl(dP, 4), c4.wft, tmp3, addend=sl(dP, 3))
+        self._wgrad_async(c3.geom, tmp3, sl(P, 2), c3.slabs, c3.dbias_partials, conv=c3)
+        K.conv_dgrad(c3.geom, tmp3, c3.wft, tmp2, addend=sl(dP, 2))
+        srcs = [sl(dP, 0), sl(dP, 1), tmp2]
         for i in range(3):
             c = self.fpn[i]
             self._wgrad_async(c.geom, srcs[i], b[f"lat{i}"], c.slabs, c.dbias_partials, conv=c)

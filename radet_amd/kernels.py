@@ -137,6 +137,7 @@ def _conv_bytes(g, groups=1):
     return 4.0 * groups * (g.lin.rows * g.cin + g.cout * g.k * g.k * g.cin + g.lout.rows * g.cout)
 
 STRIDED_DGRAD_CLASSES = True   # parity-class dgrad for strided convs (False = one dense launch)
+IDENTITY_NO_TABLE = os.environ.get("RADET_IDENTITY_TABLE", "0") != "1"   # 1 x 1 / stride 1 convs run without a gather table
 
 
 def _gather_table(key, B, k, so, sr, off, div, desc, nseg, rows):
@@ -195,7 +196,15 @@ class ConvGeom:
     # reference at any time -- a table freed while a launch on a side stream still reads it would be recycled by the
     # caching allocator and overwritten under that launch.
     @property
+    def identity(self):
+        """1 x 1 / stride 1 / no padding: GEMM row m reads row m (input and output levels coincide) -- no gather table, the
+        launchers take NULL and save the dependent table load in every workgroup's prologue"""
+        return self.k == 1 and self.stride == 1 and self.pad == 0 and IDENTITY_NO_TABLE
+
+    @property
     def fwd_table(self):
+        if self.identity:
+            return None
         if self._ft is None:
             self._ft = _gather_table(("f",) + self._key, self.B, self.k, self.stride, 1, -self.pad, 1, self.fwd_desc,
                                      self.nseg, self.lout.rows)
@@ -203,6 +212,8 @@ class ConvGeom:
 
     @property
     def bwd_table(self):
+        if self.identity:
+            return None
         if self._bt is None:
             self._bt = _gather_table(("b",) + self._key, self.B, self.k, 1, -1, self.pad, self.stride, self.bwd_desc,
                                      self.nseg, self.lin.rows)
@@ -522,14 +533,26 @@ def amax_value(slot):
 
 
 def register_amax(t, slot, by_storage=False):
-    """slot: [64] int32 tensor (new_amax).  Returns the registry key (for unregister_amax)."""
+    """slot: a new_amax() tensor.  Returns the registry key (for unregister_amax).  The entry is only honoured while `t` is
+    alive: the registry is keyed by device address, and the caching allocator hands a dead tensor's address to the next one."""
+    import weakref
     if by_storage:
         k = ("s", t.untyped_storage().data_ptr())
-        _AMAX_STORAGE[k[1]] = slot
+        _AMAX_STORAGE[k[1]] = (slot, weakref.ref(t))
     else:
         k = ("e", t.data_ptr())
-        _AMAX_EXACT[k[1]] = slot
+        _AMAX_EXACT[k[1]] = (slot, weakref.ref(t))
     return k
+
+
+def _live(table, ptr):
+    ent = table.get(ptr)
+    if ent is None:
+        return None
+    if ent[1]() is None:                    # the registered tensor is gone: whoever lives at this address now is someone else
+        del table[ptr]
+        return None
+    return ent
 
 
 def unregister_amax(keys):
@@ -550,13 +573,14 @@ def amax_slot(t, compute=False):
     if _isp(t):
         return t.amax
     p = t.data_ptr()
-    s = _AMAX_EXACT.get(p)
-    if s is None:
-        s = _AMAX_MEMO.get(p)
-        if s is None and _AMAX_STORAGE:
-            s = _AMAX_STORAGE.get(t.untyped_storage().data_ptr())
-            if s is not None:
-                _AMAX_MEMO[p] = s
+    ent = _live(_AMAX_EXACT, p)
+    if ent is None:
+        ent = _live(_AMAX_MEMO, p)
+        if ent is None and _AMAX_STORAGE:
+            ent = _live(_AMAX_STORAGE, t.untyped_storage().data_ptr())
+            if ent is not None:
+                _AMAX_MEMO[p] = ent         # (a row slice of a registered buffer: remembered by its own address)
+    s = ent[0] if ent is not None else None
     if s is None and compute:
         s = new_amax(t.device)
         absmax(t, s)

@@ -94,8 +94,10 @@ def test_two_ranks_one_gpu_train_step(tmp_path):
 
 
 @pytest.mark.timeout(900)
-def test_bench_script_two_ranks_on_one_gpu():
-    """bench.py's own N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank),
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
+def test_bench_script_two_ranks_on_one_gpu(launcher):
+    """bench.py's own N > 1 path, launched the way the driver launches it (torch.distributed.run, one process per rank) and as a
+    plain `python bench.py --gpus 2` (the script then starts the workers itself, before it touches the GPU),
     with the two ranks sharing cuda:0 over gloo (test hooks RADET_BENCH_SHARE_GPU / RADET_BENCH_BACKEND): the barrier +
     synchronize bracketing, the MAX over ranks, the per-rank step times, the traced bucket exchange (`comm`) and the one JSON
     line on rank 0 -- the code the 8-GPU RCCL run executes, minus RCCL itself."""
@@ -105,6 +107,9 @@ def test_bench_script_two_ranks_on_one_gpu():
     env = dict(os.environ, RADET_BENCH_SHARE_GPU="1", RADET_BENCH_BACKEND="gloo", GPU_MAX_HW_QUEUES="8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    if launcher == "plain":
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=REPO)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-400:], r.stderr[-1500:])

@@ -25,8 +25,11 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
         if (stages >= 3) { if (tag & 1) RADET_H2(73, 32, 3); else RADET_H2(72, 32, 3); }
         else { if (tag & 1) RADET_H2(73, 32, 2); else RADET_H2(72, 32, 2); }
     } else if constexpr (KIND == 1) {
-        if (bk == 64) { if (tag & 1) RADET_H2(105, 64, 2); else RADET_H2(104, 64, 2); }
-        else { if (tag & 1) RADET_H2(105, 32, 2); else RADET_H2(104, 32, 2); }
+        // (untagged symbols only: the K-divided tiles serve the backbone / neck, the profiling tag marks the head towers)
+        if (bk == 64) RADET_H2(104, 64, 2);                          // 32 KiB per stage: two stages, two workgroups per CU
+        else if (stages >= 4) RADET_H2(104, 32, 4);                  // 16 KiB per stage: loads up to three stages ahead
+        else if (stages == 3) RADET_H2(104, 32, 3);
+        else RADET_H2(104, 32, 2);
     } else {
         constexpr int STG = 2 * (BM + BN) * 16 * 4;                  // LDS bytes per stage: two planes x 64 bytes per tile row
         if constexpr (3 * STG <= 160 * 1024) {
@@ -51,7 +54,7 @@ bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int ta
         case 2: launch_h2<128, 64, 2, 2, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
         case 3: launch_h2<64, 64, 2, 2, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
         case 4: launch_h2<128, 32, 4, 1, 0>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
-        case 7: case 8: launch_h2<64, 64, 2, 2, 1>(a, st, tag, bk, ws_floats, 2, no_tail_split); return true;
+        case 7: case 8: launch_h2<64, 64, 2, 2, 1>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
         default: return false;
     }
 }

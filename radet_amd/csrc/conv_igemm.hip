@@ -1094,7 +1094,8 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     // split-K for launches that cannot fill 256 CUs twice over (low-M stages): each split keeps >= 8 K stages
     const int nK = KH * KW * (Cin / bk);
     int sk = 1;
-    const int stages3 = ((tile_override >> 17) & 1) ? 3 : 2;   // 0x20000: 3 LDS stages (launches that run alone)
+    // 0x20000: 3 LDS stages (launches that run alone); 0x40000: 4 (the fp16 hi / lo K-divided tile 8 only)
+    const int stages3 = ((tile_override >> 18) & 1) ? 4 : (((tile_override >> 17) & 1) ? 3 : 2);
     const int skw = cls ? 0 : (tile_override >> 20) & 7;     // 0x100000 * w: stream-K, w workgroups per CU
     const int sk_force = skw ? 1 : (tile_override >> 12) & 0xF;
     const long tiles = igemm_tiles(a.M, Cout, choice) * a.groups;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     constexpr int KD = KW ? BK / 16 : 1;                                  // k-groups per stage
     constexpr int WNK = NW / KD;                                          // column groups of waves
     constexpr int TMA = KW ? BM / 32 : TM, TNA = KW ? BN / (32 * WNK) : TN;      // accumulator blocks of a wave
-    static_assert(!KW || (X3 && !SK && NW == 4 && KD * WNK == NW && TM == 1 && TN == 1 && TMA * TNA == KD && NSTG == 2),
+    static_assert(!KW || (X3 && !SK && NW == 4 && KD * WNK == NW && TM == 1 && TN == 1 && TMA * TNA == KD && NSTG >= 2 && NSTG <= 4),
                   "K-divided tile: one 32 x 32 block per wave after the reduction");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     static_assert(!P3 || BK == 16, "plane rows are laid out in 32-channel groups: one group per K stage");
@@ -391,13 +391,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         }
         f32x4 fa[2][2][TMA], fb[2][2][TNA];              // [fragment set][k half][block]
         constexpr int NRD = 2 * (TMA + TNA);
-        // fragment read r of buffer BUF into fragment set PP: A blocks, then B blocks, k half 0 then 1
-        auto read_one = [&](auto bufc, auto ppc, auto rc) {
-            constexpr int BUF = decltype(bufc)::value, PP = decltype(ppc)::value, r = decltype(rc)::value;
-            constexpr int AO = BUF * BM * BK * 4, BO = BUF * BN * BK * 4, RO = 32 * BK * 4;
+        // fragment read r of stage buffer `buf` (run time: NSTG buffers in rotation) into fragment set PP (compile time: the
+        // sets alternate): A blocks, then B blocks, k half 0 then 1
+        auto read_one = [&](int buf, auto ppc, auto rc) {
+            constexpr int PP = decltype(ppc)::value, r = decltype(rc)::value;
+            constexpr int RO = 32 * BK * 4;
             constexpr int h = r / (TMA + TNA), e = r % (TMA + TNA);
-            if constexpr (e < TMA) lds_read128<AO + e * RO>(fa[PP][h][e], kaa[h]);
-            else lds_read128<BO + (e - TMA) * RO>(fb[PP][h][e - TMA], kba[h]);
+            if constexpr (e < TMA) lds_read128<e * RO>(fa[PP][h][e], kaa[h] + (unsigned)(buf * (BM * BK * 4)));
+            else lds_read128<(e - TMA) * RO>(fb[PP][h][e - TMA], kba[h] + (unsigned)(buf * (BN * BK * 4)));
         };
         auto pin = [&](auto ppc) {
             constexpr int PP = decltype(ppc)::value;
@@ -410,11 +411,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
                 for (int j = 0; j < TNA; ++j) asm volatile("" : "+v"(fb[PP][h][j]));
             }
         };
-        // two stages, several workgroups per CU: loads of stage it + 1 at the head of stage it, the fragment reads of
-        // stage it + 1 right behind the barrier that publishes it
-        auto stage_kw = [&](auto bufc, auto ppc, int it) {
-            constexpr int BUF = decltype(bufc)::value, PP = decltype(ppc)::value;
-            if (it + 1 < nK) issue_stage(BUF ^ 1);
+        // NSTG stages, several workgroups per CU: loads of stage it + NSTG - 1 at the head of stage it (into the buffer stage
+        // it - 1 has left), the fragment reads of stage it + 1 right behind the barrier that publishes it.  With more than two
+        // stages a stage waits for everything but the NSTG - 2 newest stages' loads (in-order return; round 5: the K-divided
+        // tiles are bound by the L2 -> LDS latency of their stages, profiles/round3_pmc_stalls.txt)
+        auto stage_kw = [&](int buf, auto ppc, int it) {
+            constexpr int PP = decltype(ppc)::value;
+            if (it + NSTG - 1 < nK) issue_stage(buf + NSTG - 1 >= NSTG ? buf - 1 : buf + NSTG - 1);
             lds_wait<0>();
             pin(ppc);
             if constexpr (H2) {
@@ -439,16 +442,22 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
                 for (int j = 0; j < TNA; ++j) mfma_x3(acc[i][j], ah[i], am[i], al[i], bh[j], bm[j], bl[j]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         };
-        if (nK > 0) static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rc); });
+        static_assert(NSTG == 2 || LOADS > 0, "deep K-divided pipelines count on every wave owning the same loads per stage");
+        int buf = 0;
+        auto next_buf = [&]() { buf = buf + 1 == NSTG ? 0 : buf + 1; };
+        if (nK > 0) static_for<0, NRD>([&](auto rc) { read_one(0, std::integral_constant<int, 0>{}, rc); });
         for (int it = 0; it < nK; it += 2) {
-            stage_kw(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, it);
+            stage_kw(buf, std::integral_constant<int, 0>{}, it);
+            next_buf();
             if (it + 1 < nK) {
-                static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, rc); });
-                stage_kw(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, it + 1);
-                if (it + 2 < nK) static_for<0, NRD>([&](auto rc) { read_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rc); });
+                static_for<0, NRD>([&](auto rc) { read_one(buf, std::integral_constant<int, 1>{}, rc); });
+                stage_kw(buf, std::integral_constant<int, 1>{}, it + 1);
+                next_buf();
+                if (it + 2 < nK) static_for<0, NRD>([&](auto rc) { read_one(buf, std::integral_constant<int, 0>{}, rc); });
             }
         }
     } else if constexpr (P3) {

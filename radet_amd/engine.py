@@ -139,6 +139,7 @@ class Engine:
             t = (self.TOWER_TAG_FWD & ~0x100) | (K.STAGES3 if fp32 else 0)
         return t | (0x100 if tag else 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
+    _pfx_ready = None    # (image key, buffer set, event) of a frozen prefix computed ahead of its step (prefetch_prefix)
 
     def _tower_launch(self, fn, *args, **kw):
         ev = self.tower_events
@@ -256,7 +257,7 @@ class Engine:
     max_plans = int(os.environ.get("RADET_MAX_PLANS", "4"))
     _PLAN_ATTRS = ("B", "H", "W", "stem_hw", "pool_hw", "buf", "plv", "R", "gn_ws", "gn_ws2", "ldesc", "nlvl", "loss_ws",
                    "losses", "dscales", "slab_arena", "bp_arena", "table", "_table_keepalive", "max_cout", "_pending_wgrad",
-                   "amax_act", "amax_aux", "_amax_keys")
+                   "amax_act", "amax_aux", "_amax_keys", "amax_pfx", "_pfx_shapes", "_pfx_sets", "_pfx_active", "_pfx_ready")
 
     def _snapshot(self):
         return dict(attrs={k: getattr(self, k) for k in self._PLAN_ATTRS},
@@ -313,15 +314,35 @@ class Engine:
             n_slot[aux] += 1
             return (self.amax_aux if aux else self.amax_act)[i]
 
-        def new(name, rows, ch, dtype=None):
+        # Frozen prefix (stem, max-pool, frozen stages): its outputs do not depend on the parameters the step updates, so the
+        # prefix of the NEXT batch may run during this step's backward pass (prefetch_prefix).  Its buffers exist twice then
+        # (the backward pass still reads this step's set), and their amax slots live in an arena per set that is zeroed by
+        # the prefix pass itself, not at the head of the forward pass.
+        self.amax_pfx = [K.new_amax(dev, 128), None]
+        self._pfx_shapes = {}
+        self._pfx_sets = [{}, None]
+        self._pfx_active, self._pfx_ready = 0, None
+        n_pfx = [0]
+
+        def new(name, rows, ch, dtype=None, prefix=False):
             t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)
             self.buf[name] = t
+            if prefix:
+                self._pfx_shapes[name] = (rows, ch, t.dtype)
+                self._pfx_sets[0][name] = t
             if self.h2 and t.dtype == torch.float32:
-                self._amax_keys.append(K.register_amax(t, slot(), by_storage=True))
+                if prefix:
+                    assert n_pfx[0] < self.amax_pfx[0].shape[0], "frozen prefix: more buffers than amax slots"
+                    sl_ = self.amax_pfx[0][n_pfx[0]]
+                    n_pfx[0] += 1
+                else:
+                    sl_ = slot()
+                self._amax_keys.append(K.register_amax(t, sl_, by_storage=True))
             return t
 
-        new("stem", B * h1 * w1, 64)
-        new("pool", B * h2 * w2, 64)
+        frozen_prefix = not self.stem.trainable
+        new("stem", B * h1 * w1, 64, prefix=frozen_prefix)
+        new("pool", B * h2 * w2, 64, prefix=frozen_prefix)
         if self.stem.trainable:           # frozen_stages = -1: gradients w.r.t. the pooled map and the stem's pre-activation
             new("d_pool", B * h2 * w2, 64)
             new("d_stem", B * h1 * w1, 64)
@@ -331,17 +352,18 @@ class Engine:
             for b, blk in enumerate(blocks):
                 pfx = f"l{li + 1}.{b}"
                 blk["lin"] = lv
+                fz = frozen_prefix and not blk["train"] and all(not bb["train"] for st in self.stages[:li] for bb in st)
                 blk["c1"].geom = ConvGeom(lv, blk["c1"].cin, blk["c1"].cout, 1, 1, 0)
                 blk["c2"].geom = ConvGeom(lv, blk["c2"].cin, blk["c2"].cout, 3, blk["stride"], 1)
                 lo = blk["c2"].geom.lout
                 blk["c3"].geom = ConvGeom(lo, blk["c3"].cin, blk["c3"].cout, 1, 1, 0)
                 if blk["ds"] is not None:
                     blk["ds"].geom = ConvGeom(lv, blk["ds"].cin, blk["ds"].cout, 1, blk["stride"], 0)
-                    new(pfx + ".idt", lo.rows, blk["ds"].cout)
+                    new(pfx + ".idt", lo.rows, blk["ds"].cout, prefix=fz)
                 blk["lout"] = lo
-                new(pfx + ".o1", lv.rows, blk["c1"].cout)
-                new(pfx + ".o2", lo.rows, blk["c2"].cout)
-                new(pfx + ".out", lo.rows, blk["c3"].cout)
+                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz)
+                new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz)
+                new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz)
                 if blk["train"]:
                     new(pfx + ".d_o1", lv.rows, blk["c1"].cout)
                     new(pfx + ".d_o2", lo.rows, blk["c2"].cout)
@@ -566,6 +588,8 @@ class Engine:
         vf, vt = self._part_version(0, nf), self._part_version(nf, n) + (self._param_epoch,)
         do_f = nf > 0 and vf != self._folded[0]
         do_t = nf < n and vt != self._folded[1]
+        if do_f:
+            self._pfx_ready = None            # a prefix prefetched with the previous frozen weights is stale
         tail = self.table[nf * C.sizeof(_lib.RadetConvDesc):]
         if do_t and self.use_streams and nf > 0 and os.environ.get("RADET_FOLD_SIDE", "1") != "0":
             side = self._side()
@@ -624,36 +648,108 @@ class Engine:
         K.unfold_grads(self.table, len(self.convs), self.max_cout)
 
     # ------------------------------------------------------------------ forward
-    def backbone_forward(self, img):
+    def _block_forward(self, blk, pfx, x, b):
+        blk["x"] = x
+        o1, o2, out = b[pfx + ".o1"], b[pfx + ".o2"], b[pfx + ".out"]
+        K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
+        K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
+        if blk["ds"] is not None:
+            idt = b[pfx + ".idt"]
+            K.conv_fwd(blk["ds"].geom, x, blk["ds"].wf, blk["ds"].bias_f, idt)
+        else:
+            idt = x
+        K.conv_fwd(blk["c3"].geom, o2, blk["c3"].wf, blk["c3"].bias_f, out, addend=idt, relu=True)
+        return out
+
+    def _n_frozen_stages(self):
+        n = 0
+        while n < len(self.stages) and not self.stages[n][0]["train"]:
+            n += 1
+        return n
+
+    def _prefix_forward(self, img, which):
+        """Stem -> max-pool -> frozen stages of `img` into buffer set `which`, on the current stream.  Returns the set."""
         B, H, W = self.B, self.H, self.W
-        b = self.buf
-        self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
+        b = self._pfx_sets[which]
         if self.h2:
-            self.amax_act.zero_()            # every producer of this pass raises its buffer's slot from zero
+            self.amax_pfx[which].zero_()     # every producer of this pass raises its buffer's slot from zero
         K.STAGE = "stem"
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
         K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
         x = b["pool"]
-        outs = []
-        for li, blocks in enumerate(self.stages):
+        for li in range(self._n_frozen_stages()):
+            K.STAGE = f"layer{li + 1}"
+            for bi, blk in enumerate(self.stages[li]):
+                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b)
+        return b
+
+    @staticmethod
+    def _img_key(img, geo):
+        return (img.data_ptr(), img._version, tuple(img.shape), geo)
+
+    def prefetch_prefix(self, next_img):
+        """Run the frozen prefix of the NEXT step's batch now, on the tower-chain stream (idle once the head's backward pass is
+        through), next to the rest of this step's backward pass: the frozen stem / stages do not depend on the parameters this
+        step updates (resnet.py:572-588, frozen_stages).  The next backbone_forward(next_img) picks the result up if it is called
+        with the same tensor (same storage, same version counter, same geometry) and computes the prefix itself otherwise --
+        bit-identical either way.  No-op when nothing is frozen, without streams, or for another geometry."""
+        if self.stem.trainable or not self.use_streams or next_img is None or self.geo_key is None:
+            return False
+        if tuple(next_img.shape) != (self.B, 3, self.H, self.W) or not next_img.is_contiguous():
+            return False
+        other = 1 - self._pfx_active
+        if self._pfx_sets[other] is None:                      # second buffer set + slot arena, on first use
+            self._pfx_sets[other] = {}
+            if self.h2:
+                self.amax_pfx[other] = K.new_amax(self.dev, 128)
+            for i, (name, (rows, ch, dt)) in enumerate(self._pfx_shapes.items()):
+                t = torch.empty(rows, ch, device=self.dev, dtype=dt)
+                self._pfx_sets[other][name] = t
+                if self.h2 and dt == torch.float32:
+                    self._amax_keys.append(K.register_amax(t, self.amax_pfx[other][i], by_storage=True))
+        cs = self._chain_stream()
+        self._fork(cs)                                         # (the frozen convs' folded weights are complete on this stream)
+        stage = K.STAGE
+        with torch.cuda.stream(cs):
+            self._prefix_forward(next_img, other)
+            ev = self._event()
+            ev.record()
+        K.STAGE = stage
+        self._pfx_ready = (self._img_key(next_img, self.geo_key), other, ev)
+        return True
+
+    def backbone_forward(self, img):
+        b = self.buf
+        self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
+        if self.h2:
+            self.amax_act.zero_()            # every producer of this pass raises its buffer's slot from zero
+        nf = self._n_frozen_stages() if not self.stem.trainable else 0
+        rdy, self._pfx_ready = self._pfx_ready, None
+        if not self.stem.trainable and rdy is not None and rdy[0] == self._img_key(img, self.geo_key):
+            torch.cuda.current_stream().wait_event(rdy[2])    # prefetched during the previous step's backward pass
+            self._pfx_active = rdy[1]
+            pb = self._pfx_sets[self._pfx_active]
+        elif not self.stem.trainable:
+            pb = self._prefix_forward(img, self._pfx_active)
+        else:
+            K.STAGE = "stem"
+            K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], self.B, self.H, self.W)
+            K.maxpool(b["stem"], b["pool"], self.B, self.stem_hw[0], self.stem_hw[1], 64)
+            pb = b
+        if not self.stem.trainable:
+            b.update(pb)                     # the names of the prefix buffers resolve to the set this step uses
+        x = pb["pool"] if nf == 0 else pb[f"l{nf}.{len(self.stages[nf - 1]) - 1}.out"]
+        outs = [pb[f"l{li + 1}.{len(self.stages[li]) - 1}.out"] for li in range(nf)]
+        for li in range(nf, len(self.stages)):
+            blocks = self.stages[li]
             K.STAGE = f"layer{li + 1}"
             if blocks[0]["train"]:
                 self._await_fold()            # trainable weights are being folded on the side stream
             for bi, blk in enumerate(blocks):
-                pfx = f"l{li + 1}.{bi}"
-                blk["x"] = x
-                o1, o2, out = b[pfx + ".o1"], b[pfx + ".o2"], b[pfx + ".out"]
-                K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
-                K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
-                if blk["ds"] is not None:
-                    idt = b[pfx + ".idt"]
-                    K.conv_fwd(blk["ds"].geom, x, blk["ds"].wf, blk["ds"].bias_f, idt)
-                else:
-                    idt = x
-                K.conv_fwd(blk["c3"].geom, o2, blk["c3"].wf, blk["c3"].bias_f, out, addend=idt, relu=True)
-                x = out
+                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b)
             outs.append(x)
         return outs  # C2..C5 row buffers
+
 
     def neck_forward(self, feats):
         K.STAGE = "neck"

@@ -100,7 +100,8 @@ def _igemm_key(t, x):
         else:
             tag, bk = 72 | ((t >> 8) & 1), 32
             if tid >= 7:
-                return f"conv_igemmg_kernel<{_TILES[tid]}, {tag | 32}, {64 if tid == 7 else 32}, 2, false>"
+                nst = 2 if tid == 7 else (4 if t & STAGES4 else (3 if t & STAGES3 else 2))
+                return f"conv_igemmg_kernel<{_TILES[tid]}, {(tag | 32) & ~1}, {64 if tid == 7 else 32}, {nst}, false>"
         return f"conv_igemmg_kernel<{_TILES.get(tid, '?')}, {tag}, {bk}, {3 if t & STAGES3 else 2}, false>"
     if t & P3:
         tag, bk = 16 | ((t >> 8) & 1), 16
@@ -437,6 +438,9 @@ def autotune(g, need_dgrad=True, reps=None):
         if getattr(g, "x3", False) and not g.math and not g.h16 and n > 32:
             # K-divided 64 x 64 tiles (the waves share the operand splits): K steps of 64 / 32 channels
             c += ([7] if kdim % 64 == 0 else []) + ([8] if kdim % 32 == 0 else [])
+            if _h2key(g) and kdim % 32 == 0 and KW_DEEP:
+                # fp16 hi / lo arithmetic: tile 8 with loads two / three stages ahead (16 KiB of LDS per stage)
+                c += [8 | STAGES3, 8 | STAGES4]
         out = list(c)
         for t in c:
             bm = 64 if (t & 0xFF) in (3, 7, 8) else 128
@@ -462,7 +466,7 @@ def autotune(g, need_dgrad=True, reps=None):
         tmp_keys = _tune_slots(g, x, w, y)
         fc = cands(g.cin, g.cout, g.lout.rows, g.k * g.k)
         if not g.math and not g.h16:      # forward launches run alone on the device: 3 LDS stages may pay (0x20000)
-            fc = fc + [t | STAGES3 for t in fc if (t & 0xFF) < 7]
+            fc = fc + [t | STAGES3 for t in fc if (t & 0xFF) < 7 and not t & (STAGES3 | STAGES4)]
         ft = best_of(lambda t: conv_fwd(g, x, w, None, y, relu=True, tile=t), fc)
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
@@ -476,6 +480,9 @@ def autotune(g, need_dgrad=True, reps=None):
         if os.environ.get("RADET_TUNE_LOG"):
             print(f"[tune igemm] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={ft:#x} dgrad tile={bt:#x}")
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
+
+
+KW_DEEP = os.environ.get("RADET_KW_DEEP", "1") != "0"
 
 
 def _h2key(g):
@@ -499,6 +506,7 @@ MATH_BF16 = 0x400      # tile_override bit of the implicit-GEMM entry points
 
 
 STAGES3 = 0x20000                         # 3 LDS stages in the fp32 implicit-GEMM kernel (forward launches)
+STAGES4 = 0x40000                         # 4 LDS stages (fp16 hi / lo arithmetic, K-divided tile 8)
 X3 = 0x1000000                            # fp32 tensors, products from three bf16 planes per operand on the bf16 matrix cores
 STREAMK = 0x100000                        # * w (1..7): stream-K schedule with w persistent workgroups per CU (fp32 tags)
 STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output from bf16 inputs (predictor heads)

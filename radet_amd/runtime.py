@@ -347,9 +347,11 @@ class DetectorRuntime:
         return self.engine.loss(tg["boxes"], tg["labels"], tg["off"], tg["p2g"], tg["pw"], grad_scale=grad_scale,
                                 labels_out=labels_out, tgt_out=tgt_out, **hp)
 
-    def backward(self, bucket_hook=None):
+    def backward(self, bucket_hook=None, next_img=None):
         """Reverse program. After each parameter group's wgrads are done its slabs are reduced /
-        un-folded into the gradient arena and `bucket_hook(bucket)` may start its all-reduce."""
+        un-folded into the gradient arena and `bucket_hook(bucket)` may start its all-reduce.  next_img: the NEXT step's
+        batch, if the caller already has it -- its frozen prefix (stem, frozen stages) then runs next to this backward pass
+        (Engine.prefetch_prefix)."""
         e = self.engine
         if not self._replicas_synced:
             # the reference's DDP wrap broadcasts rank 0's parameters at construction (apis/train.py:73-81); here that is
@@ -369,6 +371,8 @@ class DetectorRuntime:
         bk = {b["prefix"]: b for b in self.buckets}
         per_block = {(b["blocks"][0], b["blocks"][1]): b for b in self.buckets if "blocks" in b}   # keyed by the run's FIRST block
         dP = e.head_backward()
+        if next_img is not None and bucket_hook is None:
+            e.prefetch_prefix(next_img)         # on the tower-chain stream, idle from here on (single-GPU runs)
         unfold(bk["bbox_head."])
         d_feats = e.neck_backward(dP)
         unfold(bk["neck."])
@@ -383,6 +387,10 @@ class DetectorRuntime:
                 unfold(bk[pf])
         e.backbone_backward(d_feats, after_stage=after, block_ends=set(per_block))
         e.join_side()                           # gradients complete on the current stream from here on
+        if next_img is not None and bucket_hook is not None:
+            # data-parallel runs: the tower-chain stream carries the gradient exchange during the backward pass, so the prefix
+            # follows the last bucket there (next to the exposed end of the exchange, the clip and AdamW)
+            e.prefetch_prefix(next_img)
 
     def _unfold_bucket(self, bucket, bucket_hook=None):
         """Reduce / un-fold the weight-gradient slabs of one bucket's convs into the gradient arena."""
@@ -476,10 +484,14 @@ class DetectorRuntime:
         return rep
 
     # ------------------------------------------------------------------ data-parallel train step
-    def train_step(self, img, tg, lr=None):
+    def train_step(self, img, tg, lr=None, next_img=None):
         """One optimisation step. With torch.distributed initialised (backend nccl = RCCL) gradients
         are summed across ranks per bucket on a side stream while the backward of earlier layers is
-        still running; the mean (1/world) is folded into the fused clip+AdamW kernel."""
+        still running; the mean (1/world) is folded into the fused clip+AdamW kernel.
+        next_img: the batch of the NEXT call, if it is already on the device (a data loader one batch ahead): the frozen part
+        of its forward pass (stem + frozen stages, `frozen_stages` of resnet.py:572-588) is then computed during this step's
+        backward pass and picked up by the next call when it is given the same tensor; results are bit-identical to calls
+        without it."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if self.reducer is not None and self.reducer.trace is not None:
             self._ev_begin = torch.cuda.Event(enable_timing=True)
@@ -507,14 +519,14 @@ class DetectorRuntime:
             if tr:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()                     # (after forward + loss: the exchange can only overlap the backward pass)
-            self.backward(self.reducer.bucket_ready)
+            self.backward(self.reducer.bucket_ready, next_img=next_img)
             if tr:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()                     # end of the backward pass on the main stream
                 self.__dict__.setdefault("comm_marks", []).append((self._ev_begin, ev0, ev1, len(self.reducer.trace)))
             self.reducer.finish()
         else:
-            self.backward()
+            self.backward(next_img=next_img)
         self.optimizer_step(lr=lr, grad_div=float(world))
         if self.loss_weights is not None:       # reported values carry the configured loss weights, like the reference's
             return self.engine.losses * self.loss_weights

@@ -102,6 +102,51 @@ def test_train_step_is_deterministic():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_frozen_prefix_prefetch_is_bit_identical():
+    """train_step(img, tg, next_img=...) computes the frozen stem + layer1 of the next batch during this step's backward pass
+    (Engine.prefetch_prefix; frozen_stages of resnet.py:572-588).  Four steps over alternating batches, with a hand-over that
+    matches (picked up), one that does not (another tensor than announced: recomputed) and one where the announced tensor was
+    overwritten in place in between (version counter: recomputed) -- losses of every step, parameters and AdamW state equal
+    the unpipelined run bit for bit."""
+    import os
+    import bench
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    batches = []
+    for r in range(2):
+        img, boxes, labels, p2g, pw = bench.make_batch(r, 2, torch.device("cuda"))
+        batches.append((img, boxes, labels, p2g, pw))
+    outs = []
+    for prefetch in (False, True):
+        cfg = Config.fromfile(os.path.join(root, "configs", "bop", "r50_ycbv_pbr.py"))
+        cfg.model["pretrained"] = None
+        torch.manual_seed(0)
+        det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        rt = det.runtime()
+        rt.init_optimizer()
+        imgs = [b[0].clone() for b in batches]
+        tgs = [rt.pack_targets([torch.from_numpy(x) for x in b[1]], [torch.from_numpy(x) for x in b[2]], list(b[3]), list(b[4]))
+               for b in batches]
+        losses, picked = [], []
+        # step 0 announces batch 1 (picked up), step 1 announces batch 0 but step 2 is given batch 1 (recomputed), step 2 announces
+        # batch 0, which is then overwritten in place with its own values (new version: recomputed), step 3 runs on it
+        order = [(0, 1), (1, 0), (1, 0), (0, None)]
+        for i, (cur, nxt) in enumerate(order):
+            if i == 3:
+                imgs[0].copy_(batches[0][0])
+            before = rt.engine._pfx_ready is not None
+            losses.append(rt.train_step(imgs[cur], tgs[cur], next_img=imgs[nxt] if (prefetch and nxt is not None) else None).clone())
+            picked.append(before)
+        torch.cuda.synchronize()
+        if prefetch:
+            assert picked == [False, True, True, True]               # a hand-over was pending at the head of steps 1-3 ...
+            assert rt.engine._pfx_sets[1] is not None                # ... and the second buffer set exists
+        outs.append((torch.stack(losses).cpu(), rt.flat.params.clone().cpu(), rt.opt_state["m"].clone().cpu()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+
+
 def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
     """The default fp32 arithmetic (products from three bf16 planes on the bf16 matrix cores) and the native fp32 MFMA
     run the same forward + loss + backward on the headline batch.  Yardstick: the native arithmetic against ITSELF with

@@ -45,8 +45,8 @@ def main():
         keys = [K.register_amax(x, slots[0]), K.register_amax(w, slots[1])]
         row = [f"M={g.lout.rows:6d} {Cin:4d}->{Cout:4d} k{k}"]
         if what == "fwd":
-            for tile in (1, 2, 3, 7, 8):
-                if tile == 7 and Cin % 64:
+            for tile in (1, 2, 3, 7, 8, 8 | 0x20000, 8 | 0x40000):
+                if (tile & 0xFF) == 7 and Cin % 64:
                     row.append("      -      ")
                     continue
                 g.x3, g.h2 = True, False
@@ -64,7 +64,7 @@ def main():
                 thd = timeit(lambda: zf(dummy))
                 thz = timeit(lambda: zf(slots[2]))
                 K.unregister_amax([ky])
-                row.append(f"t{tile}: {t3:5.1f} {th:5.1f} {tha:5.1f} [{thd:5.1f} {thz:5.1f}]")
+                row.append(f"t{tile & 0xFF}{chr(97 + (tile >> 17))}: {t3:5.1f} {th:5.1f} {tha:5.1f} [{thd:5.1f} {thz:5.1f}]")
         else:
             dy = torch.randn(g.lout.rows, Cout, device=dev)
             K.absmax(dy, slots[2])

@@ -405,8 +405,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-mfma-line", action="store_true", help="skip the native-f32-MFMA comparison measurement")
     ap.add_argument("--no-clock-sampler", action="store_true", help="skip the rocm-smi clock / power window after the timed region")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not hand the next batch to train_step (its frozen prefix then runs at the head of its own step)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="hand the next batch to train_step: its frozen stem + layer1 then run during this step's backward pass "
+                         "(measured neutral on one GPU: the backward pass is throughput-bound, DESIGN.md; off by default)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (inference config 4, R101 config 5, synthetic trained-like weights)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH,
@@ -479,7 +480,7 @@ def main():
     # the next step's batch is known one step ahead (a data loader prefetches it): its frozen stem + layer1 run during the
     # current step's backward pass (runtime.train_step, next_img).  Synthetic data: the same resident batch every step, so
     # "next" is the same tensor -- the prefix is nevertheless computed once per step, into the buffer set the step after uses.
-    nxt = None if args.no_prefetch else img
+    nxt = img if args.prefetch else None
 
     def sync():
         if world > 1:

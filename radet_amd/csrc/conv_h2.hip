@@ -252,14 +252,231 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, one tap, fp16 plane pairs
+// conv_wgradh_kernel's data path (the bf16-storage one-tap kernel: [4 pixels][16 channels] sub-tiles by LDS-DMA,
+// ds_read_b64_tr_b16 operands, 32 pixels = two K = 16 MFMA steps per stage) for operands that arrive as fp16 plane pairs: per
+// (block pair, K step) the three plane products of mfma_h2 into an accumulator pair, no operand work in the loop.  For the
+// backbone / neck weight gradients, whose fp32 operands are split into pairs once per tensor (radet_split_pairs on the
+// weight-gradient stream) instead of once per use in registers: the in-register one-tap kernel needs 8 ds_read_b32 per
+// 8-pixel fragment and 24 VALU operations per fragment, this one 2 transposing reads and none.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
+    constexpr int BP = 32, NW = 4;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int CBA = BM / 16, CBB = BN / 16;             // 16-channel sub-tile columns
+    constexpr int A_PL = BP * BM, B_PL = BP * BN;           // fp16 elements per plane tile
+    constexpr int A_Q = A_PL * 2 / 1024, B_Q = B_PL * 2 / 1024;     // wave loads per plane tile
+    constexpr int A_INSTR = 2 * A_Q, B_INSTR = 2 * B_Q;
+    constexpr int N_INSTR = A_INSTR + B_INSTR;
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][2 * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2 * B_PL];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int KT = a.KH * a.KW;
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = (a.Cin + BN - 1) / BN;
+    const int tilesPerSplit = tilesO * tilesC * KT;
+    int id = blockIdx.x;
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO;
+    id /= tilesO;
+    const int tc = id % tilesC;
+    const int tap = id / tilesC;
+    const int o0 = to * BM, c0 = tc * BN;
+    const int* tab_tap = a.rowtab ? a.rowtab + (size_t)tap * a.Mp : nullptr;
+
+    const int p_begin = split * a.chunks_per_split * 16;    // chunks_per_split counts 16-pixel chunks
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    // writer side: lane -> (sub-tile, pixel row, 8-channel half) of every wave load it issues
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    int brow[PER_WAVE];                                     // gather rows of the NEXT stage (x-tile loads)
+    bool bok[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        brow[k] = -1;
+        bok[k] = false;
+        if (bi >= 0 && bi < B_INSTR) {
+            const int blk = (bi % B_Q) * 8 + l_blk;
+            const int m = p_begin + 4 * (blk / CBB) + l_prow;
+            brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;       // unconditional (clamped) load, masked at use
+            bok[k] = m < p_end;
+        }
+    }
+    auto issue_stage = [&](int it, int buf) {                 // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int bi = ins - A_INSTR;
+                const int pl = bi / B_Q, blk = (bi % B_Q) * 8 + l_blk;
+                const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
+                const void* src = (bok[k] && brow[k] >= 0 && c < a.Cin)
+                                      ? (const void*)(xh + (size_t)brow[k] * 2 * a.Cin + radet_pair_off(c) + 32 * pl)
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < A_INSTR) {
+                const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
+                const int m = p0 + 4 * (blk / CBA) + l_prow;
+                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+                const void* src = (m < p_end && o < a.Cout)
+                                      ? (const void*)(dyh + (size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl)
+                                      : (const void*)(radet_zero_page + lane * 4);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins >= A_INSTR && ins < N_INSTR) {
+                const int blk = ((ins - A_INSTR) % B_Q) * 8 + l_blk;
+                const int m = p0 + BP + 4 * (blk / CBB) + l_prow;
+                brow[k] = tab_tap ? tab_tap[m < a.Mp ? m : a.Mp - 1] : m;
+                bok[k] = m < p_end;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { acc[i][j][t] = 0.f; acc1[i][j][t] = 0.f; }
+    const H2Scale sdy = h2_scale(a.dys), sxx = h2_scale(a.xss);
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    // per-lane LDS byte addresses of the transposing reads (sub-tile row 2 * lh of a 4-row group, channel sub-tile of the
+    // wave tile + g16, bytes 8 * m16 of the sub-tile), see conv_wgradh_kernel
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + wm * TM * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + wn * TN * 2 + g16) * 128 + m16 * 8);
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        {
+            const unsigned ab = a_thr + (unsigned)buf * (2 * A_PL * 2), bb = b_thr + (unsigned)buf * (2 * B_PL * 2);
+            s16x4v_ al[2][2][TM], ah[2][2][TM], bl[2][2][TN], bh[2][2][TN];       // [fragment set][plane][block]
+            auto read_ks = [&](auto ksc, int pp) {
+                constexpr int ks = decltype(ksc)::value;
+                static_for<0, 2>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    static_for<0, TM>([&](auto ic) {
+                        constexpr int off = pl * A_PL * 2 + ((4 * ks) * CBA + decltype(ic)::value * 2) * 128;
+                        lds_read_tr16<off>(al[pp][pl][decltype(ic)::value], ab);
+                        lds_read_tr16<off + CBA * 128>(ah[pp][pl][decltype(ic)::value], ab);
+                    });
+                    static_for<0, TN>([&](auto jc) {
+                        constexpr int off = pl * B_PL * 2 + ((4 * ks) * CBB + decltype(jc)::value * 2) * 128;
+                        lds_read_tr16<off>(bl[pp][pl][decltype(jc)::value], bb);
+                        lds_read_tr16<off + CBB * 128>(bh[pp][pl][decltype(jc)::value], bb);
+                    });
+                });
+            };
+            // (the next K step's reads go out ahead of this one's MFMAs only while they fit lgkmcnt's 4 bits)
+            constexpr bool AHEAD = 4 * (TM + TN) <= 15;
+            read_ks(std::integral_constant<int, 0>{}, 0);
+            static_for<0, BP / 16>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value, pp = AHEAD ? (ks & 1) : 0;
+                if constexpr (AHEAD && ks + 1 < BP / 16) {
+                    read_ks(std::integral_constant<int, ks + 1>{}, pp ^ 1);
+                    lds_wait<AHEAD ? 4 * (TM + TN) : 0>();
+                } else {
+                    lds_wait<0>();
+                }
+                f16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        asm volatile("" : "+v"(al[pp][pl][i])); asm volatile("" : "+v"(ah[pp][pl][i]));
+                        af[pl][i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(al[pp][pl][i], ah[pp][pl][i], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        asm volatile("" : "+v"(bl[pp][pl][j])); asm volatile("" : "+v"(bh[pp][pl][j]));
+                        bf[pl][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(bl[pp][pl][j], bh[pp][pl][j], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mfma_h2(acc[i][j], acc1[i][j], af[0][i], af[1][i], bf[0][j], bf[1][j]);
+                if constexpr (!AHEAD && ks + 1 < BP / 16) read_ks(std::integral_constant<int, ks + 1>{}, 0);
+            });
+        }
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
+            const int cb = tid >> 4, cc = tid & 15;
+            const unsigned short* ap = &As[buf][0];
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
+                bsum += radet_pair_value(ap[e], ap[A_PL + e]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum * sdy.inv;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            h2_combine(acc[i][j], acc1[i][j], sdy.inv, sxx.inv);
+            const int c = c0 + (wn * TN + j) * 32 + li;
+            if (c >= a.Cin) continue;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int o = o0 + (wm * TM + i) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (o >= a.Cout) continue;
+                out[((size_t)o * KT + tap) * a.Cin + c] = acc[i][j][t];
+            }
+        }
+}
+
 // the h2 weight-gradient launches behind radet_conv2d_wgrad_s: flags 0x1000 (fp32 tensors, split in registers: the one-tap
 // tiles; bits 4-5 / 7 / 10-11 select tile / 32-pixel stages / pixel-divided tiles as for the bf16-plane arithmetic) or
 // 0x1000 | 0x200 (fp16 plane pairs: the all-taps kernel above)
 int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStream_t st) {
     if (flags & 0x200) {
-        if ((a.ld_dy & 31) || (a.Cin & 31) || a.KH != 3 || a.KW != 3) return RADET_ERR_ARG;
-        const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
-        hipLaunchKernelGGL(conv_wgrad9q_kernel, dim3(tiles9), dim3(512), 0, st, a);
+        if ((a.ld_dy & 31) || (a.Cin & 31)) return RADET_ERR_ARG;
+        if (a.KH == 3 && a.KW == 3 && !(flags & 0x40)) {               // all nine taps per workgroup
+            const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
+            hipLaunchKernelGGL(conv_wgrad9q_kernel, dim3(tiles9), dim3(512), 0, st, a);
+            return radet_check_launch();
+        }
+        // one tap per workgroup (0x40, or not a 3 x 3): bits 4-5 = 1: 128 x 128 tile, otherwise 64 x 64
+        const int KTq = a.KH * a.KW;
+        if (((flags >> 4) & 3) == 1) {
+            const int tiles = ((a.Cout + 127) / 128) * ((a.Cin + 127) / 128) * KTq * a.S;
+            hipLaunchKernelGGL((conv_wgradq_kernel<128, 128, 2, 2>), dim3(tiles), dim3(256), 0, st, a);
+        } else {
+            const int tiles = ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64) * KTq * a.S;
+            hipLaunchKernelGGL((conv_wgradq_kernel<64, 64, 2, 2>), dim3(tiles), dim3(256), 0, st, a);
+        }
         return radet_check_launch();
     }
     const int KT = a.KH * a.KW;

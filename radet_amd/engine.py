@@ -457,6 +457,9 @@ class Engine:
                 if c.trainable and c.geom is not None and c.cout > 64 and c.cin > 64 and not c.grouped \
                         and c not in self.cls_tower and c not in self.reg_tower:
                     K.autotune_wgrad(c.geom)
+        for c in self.convs:                  # backbone / neck weight gradients on plane pairs: the one-tap pair kernel with the
+            if c.geom is not None and hasattr(c.geom, "wgrad_pair_flags") and c not in self.cls_tower + self.reg_tower:
+                c.geom.wgrad_pair_flags = 0x40 | (c.geom.wgrad_flags & 0x30)        # tuned tile class (128 x 128, else 64 x 64)
         # wgrad slabs / bias partials + descriptor table
         n_slab = sum(c.geom.nsplit * c.wsize for c in self.convs if c.trainable)
         n_bp = sum(c.geom.nsplit * c.cout for c in self.convs if c.trainable)
@@ -818,14 +821,51 @@ class Engine:
         ev.record(side)
         torch.cuda.current_stream().wait_event(ev)
 
+    # Backbone / neck weight gradients on fp16 plane pairs (round 5): dy and x are split into pairs ONCE per tensor by
+    # radet_split_pairs on the weight-gradient stream (off the dgrad chain, into a scratch pair of that stream), and the GEMM
+    # runs on the pair kernels (transposing LDS reads, no operand work in the loop) instead of splitting every fragment in
+    # registers.  RADET_WGRAD_PAIRS=0: the in-register one-tap kernels.
+    # Measured (round 5, r50 640x480 bs 4): the pair kernels take 0.64 ms less kernel time per step than the in-register ones
+    # (3.19 against 3.83 ms over the 49 backbone / neck launches), the 98 split launches give it back: 8.94 against 8.84 ms per
+    # step.  Off by default; the kernels stay (they are what a producer-side pair copy would feed, DESIGN.md "next").
+    wgrad_pairs = os.environ.get("RADET_WGRAD_PAIRS", "0") == "1"
+
+    def _wgrad_pairs_ok(self, geom, dy, x):
+        return (self.h2 and self.wgrad_pairs and not K._isp(dy) and geom.cin % 32 == 0 and geom.cout % 32 == 0
+                and dy.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] == geom.cout and x.shape[1] == geom.cin)
+
+    def _wgrad_via_pairs(self, geom, dy, x, slabs, dbias_partials):
+        """on the current (weight-gradient) stream: dy, x -> this stream's scratch pairs -> pair weight-gradient GEMM"""
+        key = torch.cuda.current_stream().cuda_stream
+        sc = self._pair_scratch.get(key)
+        need = max(dy.numel(), x.numel())
+        if sc is None or sc[0].numel() < 2 * need:
+            n = max(2 * need, 2 * self._pair_scratch_elems())
+            sc = self._pair_scratch[key] = (torch.empty(n, dtype=torch.float16, device=self.dev),
+                                            torch.empty(n, dtype=torch.float16, device=self.dev), K.new_amax(self.dev, 2))
+        dyq = K.Planes(dy.shape[0], geom.cout, t=sc[0][:2 * dy.numel()].view(dy.shape[0], 2 * geom.cout), kind="h2", amax=sc[2][0])
+        xq = K.Planes(x.shape[0], geom.cin, t=sc[1][:2 * x.numel()].view(x.shape[0], 2 * geom.cin), kind="h2", amax=sc[2][1])
+        K.split_planes(dy, dyq)
+        K.split_planes(x, xq)
+        K.conv_wgrad(geom, dyq, xq, slabs, dbias_partials)
+
+    def _pair_scratch_elems(self):
+        return max((max(c.geom.lout.rows * c.cout, c.geom.lin.rows * c.cin) for c in self.convs
+                    if c.trainable and c.geom is not None and hasattr(c.geom, "lout")), default=0)
+
+    _pair_scratch = None
+
     def _wgrad_async(self, geom, dy, x, slabs, dbias_partials=None, conv=None):
         """Weight-gradient GEMM off the critical path: issued on the side stream once `dy` is ready (or collected
         for the stage's grouped launch, see flush_wgrads)."""
         if conv is not None and conv.grouped:
             self._pending_wgrad.append(dict(g=geom, dy=dy, x=x, slabs=slabs, dbias=dbias_partials))
             return None
+        if self._pair_scratch is None:
+            self._pair_scratch = {}
+        wg = self._wgrad_via_pairs if self._wgrad_pairs_ok(geom, dy, x) else K.conv_wgrad
         if not self.use_streams:
-            K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
+            wg(geom, dy, x, slabs, dbias_partials)
             return None
         # weight-gradient GEMMs are small grids (250-800 workgroups): alternate them between the side stream and a
         # second one so that two run concurrently and fill each other's tails
@@ -837,7 +877,7 @@ class Engine:
                 self._side2_dirty = True
         self._fork(side)
         with torch.cuda.stream(side):
-            K.conv_wgrad(geom, dy, x, slabs, dbias_partials)
+            wg(geom, dy, x, slabs, dbias_partials)
             ev = self._event()
             ev.record()
         return ev   # completes when this weight-gradient GEMM has finished reading dy / x

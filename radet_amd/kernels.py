@@ -180,6 +180,8 @@ class ConvGeom:
         self._x3 = False                      # fp32 tensors, conv products from 16-bit planes of the operands (tile flag X3) ...
         self.h2 = False                       # ... two fp16 planes and 3 plane products (tile flag H2) instead of three bf16 / 6
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
+        self.wgrad_pair_flags = 0             # weight gradient on fp16 plane pairs: 0x40 one-tap kernel, bits 4-5 its tile (1: 128 x 128)
+        self.nsplit_pairs = 0                 # its pixel splits (0: nsplit)
         self._ft = self._bt = self._classes = None
         self._cgroup = 0                                   # 0 = not looked at yet, None = no class launch for this geometry
 
@@ -884,6 +886,8 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
 
 def _wgrad_key(g, dy, co):
     if _isp(dy):
+        if dy.kind == "h2" and (g.k != 3 or g.wgrad_pair_flags & 0x40):
+            return f"conv_wgradq_kernel<{'128, 128' if (g.wgrad_pair_flags >> 4) & 3 == 1 else '64, 64'}> (fp16 plane pairs)"
         return "conv_wgrad9q_kernel" if dy.kind == "h2" else "conv_wgrad9p_kernel"
     if getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not _is16(dy):
         tf = (g.wgrad_flags >> 4) & 3
@@ -915,9 +919,13 @@ def _conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
     if _isp(dy):
         assert _isp(x) and x.kind == dy.kind
         if dy.kind == "h2":
+            # all nine taps per workgroup for 3 x 3 convs unless the geometry's flags ask for the one-tap pair kernel (0x40;
+            # bits 4-5 = its tile), which also serves every other kernel size
+            fl = 0x1000 | 0x200 | (g.wgrad_pair_flags if (g.k == 3 and not (g.wgrad_pair_flags & 0x40)) else
+                                   (0x40 | (g.wgrad_pair_flags & 0x30)))
             _lib.call("radet_conv2d_wgrad_s", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table),
-                      g.lout.rows, g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x1000 | 0x200, _stream(),
-                      _scales(dy, x, None))
+                      g.lout.rows, g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k,
+                      g.nsplit_pairs or g.nsplit, fl, _stream(), _scales(dy, x, None))
             return
         _lib.call("radet_conv2d_wgrad", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table), g.lout.rows,
                   g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k, g.nsplit, 0x200 | (g.wgrad_flags & 0x40), _stream())

@@ -1280,3 +1280,28 @@ def test_split_k_in_launch_reduction_under_uneven_load(K):
                 bad += int(not torch.equal(y, y0))
         torch.cuda.synchronize()
         assert bad == 0 and torch.equal(y, y0), (mode, bad)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 256, 30, 40, 3, 1, 2), (1, 128, 512, 33, 21, 1, 1, 2), (2, 128, 128, 18, 22, 3, 2, 1),
+                                  (2, 512, 256, 16, 20, 1, 1, 1), (4, 1024, 256, 15, 20, 1, 1, 2), (3, 96, 160, 17, 23, 3, 1, 2)])
+def test_wgrad_one_tap_on_plane_pairs(K, case):
+    """conv_wgradq_kernel (radet_conv2d_wgrad_s flags 0x1000 | 0x200 | 0x40): the one-tap weight gradient with dy / x as fp16
+    plane pairs (transposing LDS reads) == fp64 wgrad, incl. the bias column sums, ragged pixel counts / channel tiles,
+    strided and 1 x 1 (no gather table) cases, both tiles."""
+    B, Cin, Cout, H, W, k, s, tile = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(B, Cin, H, W, generator=g).clamp_min(-0.5)
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g) * 1e-2
+    gw = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), stride=s, padding=pad)
+    geom = K.ConvGeom(K.Levels([(H, W)], B), Cin, Cout, k, s, pad)
+    geom.wgrad_pair_flags = 0x40 | (tile << 4)
+    xq, dyq = K.Planes.from_float(to_rows(x).cuda(), kind="h2"), K.Planes.from_float(to_rows(dy).cuda(), kind="h2")
+    for S in (1, 3):
+        geom.nsplit = S
+        slabs = torch.full((S, Cout, k * k, Cin), float("nan"), device="cuda")
+        bp = torch.full((S, Cout), float("nan"), device="cuda")
+        K.conv_wgrad(geom, dyq, xq, slabs, bp)
+        assert rel_err(slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2), gw) < 2e-5, S
+        assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S

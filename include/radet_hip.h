@@ -49,6 +49,11 @@ typedef struct RadetConvDesc {
                               "plane pairs" below; needs w_amax); bias_f stays fp32 */
     float* w_amax;         /* 64 words or NULL: amax slot (see RadetScales) of the folded weights, largest |wf|; zeroed and raised
                               by radet_fold_weights -- the weight operand's scale in the fp16 hi / lo arithmetic */
+    float* wfq;            /* optional: a second copy of wf as fp16 plane pairs (rows [2][Cin], scaled by w_amax's power of two),
+                              the weight operand of forward launches whose x arrives as plane pairs; or NULL */
+    float* w_l1;           /* amax-style slot or NULL: largest L1 norm of a folded output channel, max_o sum |wf[o][.][.]| --
+                              |conv output| <= amax(x) * it (+ |bias| + |addend|): the bound RadetScales.yq is scaled with */
+    float* bias_amax;      /* amax-style slot or NULL: largest |bias_f| */
 } RadetConvDesc;
 
 /* ---- amax slots (round 5, "fp16 hi / lo arithmetic").  The default fp32 conv arithmetic forms fp32-accurate products
@@ -74,6 +79,18 @@ typedef struct RadetScales {
     const void* x1_amax;   /* the same for the second problem of a pair launch */
     const void* w1_amax;
     void* y1_amax;
+    /* optional pair copy of the output (first problem only; fp32 y, Cout % 32 == 0): yq = y once more as fp16 plane pairs
+     * (rows [2][Cout]), scaled by the power of two of the bound  amax(x) * L1max(w) + max|bias| + amax(addend)  -- complete
+     * before the launch starts, unlike y's own largest magnitude -- which is stored to yq_amax.  x_true_amax: the slot x's
+     * producer RAISED (for a plane-pair x: not the bound its pairs were scaled with, or the bounds of consecutive layers would
+     * multiply); w_l1: RadetConvDesc.w_l1; bias_amax / addend_amax: NULL when the launch has no bias / addend.  The next
+     * conv reads yq as its x operand (+0x2000000 | 0x8000000) and needs no operand split in its K loop. */
+    void* yq;
+    void* yq_amax;
+    const void* x_true_amax;
+    const void* w_l1;
+    const void* bias_amax;
+    const void* addend_amax;
 } RadetScales;
 
 /* Gather table of one conv geometry: table[tap][Mp] = input row feeding (output row m, tap) or -1 (padding /
@@ -288,6 +305,12 @@ int radet_gn_relu_bwd_q(const float* dy, const float* z, const float* stats, con
 /* Elementwise kernels that also raise the amax slot of the tensor they write (not reset here), and a stand-alone pass for
  * tensors whose producer does not (n % 4 == 0). */
 int radet_maxpool3x3s2_a(const float* x, float* y, int B, int H, int W, int C, void* y_amax, void* stream);
+/* the max-pool with its output once more as fp16 plane pairs (scaled by x's amax slot, whose bits go to yq_amax), and the
+ * stem with an amax slot for its output */
+int radet_maxpool3x3s2_q(const float* x, float* y, int B, int H, int W, int C, void* y_amax, void* yq, void* yq_amax,
+                         const void* x_amax, void* stream);
+int radet_stem_conv_bn_relu_a(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc, int B, int H, int W,
+                              void* y_amax, void* stream);
 int radet_upsample_add_a(float* dst, const float* src, int B, int Ho, int Wo, int Hi, int Wi, int C, void* dst_amax,
                          void* stream);
 int radet_upsample_add_bwd_a(float* dsrc, const float* ddst, int B, int Ho, int Wo, int Hi, int Wi, int C, void* dsrc_amax,

@@ -22,12 +22,13 @@ class RadetConvDesc(C.Structure):
                 ("wf", _p), ("wft", _p), ("bias_f", _p), ("dwf_slabs", _p), ("dbias_partials", _p),
                 ("dw", _p), ("dbias", _p), ("dgamma", _p), ("dbeta", _p),
                 ("cout", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("nsplit", _i), ("eps", _f),
-                ("wft_ld", _i), ("wft_off", _i), ("w16", _i), ("w_amax", _p)]
+                ("wft_ld", _i), ("wft_off", _i), ("w16", _i), ("w_amax", _p), ("wfq", _p), ("w_l1", _p), ("bias_amax", _p)]
 
 
 class RadetScales(C.Structure):
     """Mirror of `struct RadetScales` (include/radet_hip.h): amax slots of the fp16 hi / lo arithmetic (device pointers)."""
-    _fields_ = [("x_amax", _p), ("w_amax", _p), ("y_amax", _p), ("x1_amax", _p), ("w1_amax", _p), ("y1_amax", _p)]
+    _fields_ = [("x_amax", _p), ("w_amax", _p), ("y_amax", _p), ("x1_amax", _p), ("w1_amax", _p), ("y1_amax", _p),
+                ("yq", _p), ("yq_amax", _p), ("x_true_amax", _p), ("w_l1", _p), ("bias_amax", _p), ("addend_amax", _p)]
 
 
 class RadetWgradJob(C.Structure):
@@ -55,6 +56,8 @@ SIGNATURES = {
     "radet_gn_relu_fwd_pair_q": (_i, [_p] * 20 + [_i, _i, _i, _f, _i, _p, _i, _p]),
     "radet_gn_relu_bwd_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p]),
     "radet_maxpool3x3s2_a": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "radet_maxpool3x3s2_q": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "radet_stem_conv_bn_relu_a": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "radet_upsample_add_a": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "radet_upsample_add_bwd_a": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "radet_relu_bwd_a": (_i, [_p, _p, _p, _p, _sz, _p, _p]),

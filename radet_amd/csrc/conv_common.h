@@ -25,6 +25,19 @@ struct ConvPtrs {
     const unsigned* xs;
     const unsigned* ws;
     unsigned* ys;
+    // optional second output: y once more as fp16 plane pairs (rows [2][Cout], Cout % 32 == 0; fp32 outputs only) -- the x
+    // operand of the next conv, so that it runs without an operand split in its K loop.  The pairs' power-of-two scale must be
+    // known BEFORE the first store, i.e. before y's largest magnitude is: it comes from a bound that is complete when the
+    // launch starts,  |y| <= amax(x) * max_n sum_k |w[n][k]|  +  max|bias|  +  amax(addend)   (ReLU and mask only shrink),
+    // built from the TRUE largest magnitude of x (xt: the slot its producer raised, not the bound its own pairs were scaled
+    // with -- bounds do not compound from layer to layer), the weights' largest channel L1 norm (wl1, from the fold) and the
+    // slots of bias / addend (bs / as, null: absent).  The bound's bit pattern is stored to yqs for the consumer.
+    _Float16* yq;
+    unsigned* yqs;
+    const unsigned* xt;
+    const unsigned* wl1;
+    const unsigned* bs;
+    const unsigned* as;
 };
 
 struct ConvArgs {
@@ -135,6 +148,7 @@ __device__ __forceinline__ void st_out_t(float* p, size_t o, float v) {
 // Everything the code after the K loop needs from the argument struct, loaded before the loop and pinned in SGPRs:
 // left to the compiler these become s_loads (each behind its own wait) between the last barrier and the first store.
 struct EpiArgs {
+    float qs, qs2;        // ConvPtrs::yq: 2^e, 2^(e + 11) of the output bound (igemm_pair_scale)
     int M, Cout, relu, io;
     const int* out_rows;
     float* partial;       // split-K / stream-K workspace (ConvArgs::partial, ::counters)
@@ -204,6 +218,24 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
             }
             // stores last, with nothing left in flight that they would have to wait for (on gfx9-class hardware a
             // store behind a conservative vmcnt(0) also waits for the store before it); interior tiles store unguarded
+            if constexpr (IO == 0) {
+                if (P.yq) {                 // the same values as fp16 plane pairs (two rows per split: packed halves go to rows r, r + 1)
+                    unsigned short* const q = reinterpret_cast<unsigned short*>(P.yq) + radet_pair_off(cc);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        unsigned h, l;
+                        radet_split2(out[r], out[r + 1], a.qs, a.qs2, h, l);
+                        if (interior || (cvalid && rvalid[r])) {
+                            q[2 * obase[r]] = (unsigned short)(h & 0xFFFFu);
+                            q[2 * obase[r] + 32] = (unsigned short)(l & 0xFFFFu);
+                        }
+                        if (interior || (cvalid && rvalid[r + 1])) {
+                            q[2 * obase[r + 1]] = (unsigned short)(h >> 16);
+                            q[2 * obase[r + 1] + 32] = (unsigned short)(l >> 16);
+                        }
+                    }
+                }
+            }
             if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
@@ -472,6 +504,20 @@ __device__ __forceinline__ void mfma_h2(f32x16& acc0, f32x16& acc1, const f16x8&
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1, 0, 0, 0);
 }
+// scale of the fp16 pair copy of the output (ConvPtrs::yq), from quantities that are complete when the launch starts; call with
+// all lanes active.  `store`: this workgroup publishes the bound (one per problem).
+__device__ __forceinline__ void igemm_pair_scale(const ConvPtrs& P, bool store, float& qs, float& qs2) {
+    float bound = __uint_as_float(radet_amax_read(P.xt)) * __uint_as_float(radet_amax_read(P.wl1));
+    if (P.bs) bound += __uint_as_float(radet_amax_read(P.bs));
+    if (P.as) bound += __uint_as_float(radet_amax_read(P.as));
+    bound *= 1.0001f;                                            // (fp32 rounding of the accumulation and of this sum)
+    const unsigned bits = __float_as_uint(bound);
+    if (store && threadIdx.x == 0) radet_amax_store(P.yqs, bits);
+    const int e = radet_h2_exp(bits);
+    qs = radet_pow2(e);
+    qs2 = radet_pow2(e + 11);
+}
+
 // the product in the operands' own units: (acc0 + 2^-11 acc1) 2^-ea 2^-eb (two multiplications: either factor alone is a
 // normal float, their product need not be)
 __device__ __forceinline__ void h2_combine(f32x16& acc0, const f32x16& acc1, float inv_a, float inv_b) {

@@ -42,8 +42,11 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
 
 bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
                            bool no_tail_split) {
-    if (tag & 16) {                                                  // plane pairs: the 8-wave tiles
+    if (tag & 16) {                                                  // plane pairs: the 8-wave tiles (+ the 4-wave tiles 1-3)
         switch (choice) {
+            case 1: launch_h2<128, 128, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
+            case 2: launch_h2<128, 64, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
+            case 3: launch_h2<64, 64, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
             case 5: launch_h2<128, 128, 2, 4, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
             case 6: launch_h2<256, 128, 4, 2, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
             default: return false;

@@ -912,6 +912,7 @@ extern "C" int radet_conv2d_igemm_pair(const float* x0, const float* w0, const f
     ConvPtrs second;
     second.x = x1; second.w = w1; second.bias = bias1; second.addend = addend1; second.mask = mask1; second.y = y1;
     second.xs = second.ws = nullptr; second.ys = nullptr;
+    second.yq = nullptr; second.yqs = nullptr; second.xt = second.wl1 = second.bs = second.as = nullptr;
     return igemm_impl(x0, w0, bias0, addend0, mask0, y0, gather_table, M, Cin, Cout, KH, KW, relu, tile_override,
                       splitk_ws, splitk_ws_floats, nullptr, nullptr, 0, stream, &second);
 }
@@ -943,6 +944,7 @@ extern "C" int radet_conv2d_igemm_pair_s(const float* x0, const float* w0, const
     ConvPtrs second;
     second.x = x1; second.w = w1; second.bias = bias1; second.addend = addend1; second.mask = mask1; second.y = y1;
     second.xs = second.ws = nullptr; second.ys = nullptr;
+    second.yq = nullptr; second.yqs = nullptr; second.xt = second.wl1 = second.bs = second.as = nullptr;
     return igemm_impl(x0, w0, bias0, addend0, mask0, y0, gather_table, M, Cin, Cout, KH, KW, relu, tile_override,
                       splitk_ws, splitk_ws_floats, nullptr, nullptr, 0, stream, &second, nullptr, sc);
 }
@@ -1037,10 +1039,22 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     a.p[0].xs = sc ? (const unsigned*)sc->x_amax : nullptr;
     a.p[0].ws = sc ? (const unsigned*)sc->w_amax : nullptr;
     a.p[0].ys = sc ? (unsigned*)sc->y_amax : nullptr;
+    a.p[0].yq = sc ? (_Float16*)sc->yq : nullptr;
+    a.p[0].yqs = sc ? (unsigned*)sc->yq_amax : nullptr;
+    a.p[0].xt = sc ? (const unsigned*)sc->x_true_amax : nullptr;
+    a.p[0].wl1 = sc ? (const unsigned*)sc->w_l1 : nullptr;
+    a.p[0].bs = (sc && bias) ? (const unsigned*)sc->bias_amax : nullptr;
+    a.p[0].as = (sc && addend) ? (const unsigned*)sc->addend_amax : nullptr;
+    if (a.p[0].yq != nullptr) {              // pair copy of the output: fp32 outputs, whole 32-channel groups, every slot it needs
+        if (h16 || Cout % 32 != 0 || a.p[0].yqs == nullptr || a.p[0].xt == nullptr || a.p[0].wl1 == nullptr ||
+            (bias && a.p[0].bs == nullptr) || (addend && a.p[0].as == nullptr) || second != nullptr)
+            return RADET_ERR_ARG;
+    }
     a.p[1] = a.p[0];
     a.groups = 1;
     if (second != nullptr) {
         a.p[1] = *second;
+        a.p[1].yq = nullptr; a.p[1].yqs = nullptr; a.p[1].xt = a.p[1].wl1 = a.p[1].bs = a.p[1].as = nullptr;
         a.p[1].xs = sc ? (const unsigned*)sc->x1_amax : nullptr;
         a.p[1].ws = sc ? (const unsigned*)sc->w1_amax : nullptr;
         a.p[1].ys = sc ? (unsigned*)sc->y1_amax : nullptr;

@@ -96,6 +96,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     epi.out_rows = pin_sgpr(a.out_rows);
     epi.partial = pin_sgpr(a.partial); epi.counters = pin_sgpr(a.counters);
     epi.sk_base = pin_sgpr(a.sk_base); epi.sk_rem = pin_sgpr(a.sk_rem);
+    epi.qs = 1.f; epi.qs2 = 2048.f;
+    if (P.yq) {                                                  // (uniform) pair copy of the output: its scale, from the bound
+        float qs, qs2;
+        igemm_pair_scale(P, id == 0 && (int)blockIdx.y == 0 && !SK, qs, qs2);
+        epi.qs = pin_sgpr(qs); epi.qs2 = pin_sgpr(qs2);
+    }
     // split episode of this workgroup: (number of splits, split-tile index, my split)
     const int nsplit = pin_sgpr(tail ? a.sk_tail : a.sk);
     const int ctile = pin_sgpr(tail ? tail_slot / a.sk_tail : sk_tile);

@@ -5,6 +5,7 @@
 //   GroupNorm(32)+ReLU forward / backward over multi-level buffers         atss_head.py:60-76
 //   nearest upsample-add forward / backward (FPN top-down path)            fpn.py:182-191
 #include "common.h"
+#include <type_traits>
 #include "../../include/radet_hip.h"
 
 // ------------------------------------------------------------------------------------------ stem
@@ -26,7 +27,8 @@ __host__ __device__ constexpr int stem_aoff(int k) {      // patch offset of red
 template <class T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ wf,
                                                    const float* __restrict__ bias, T* __restrict__ y, int H,
-                                                   int W, int Ho, int Wo, int B) {
+                                                   int W, int Ho, int Wo, int B, unsigned* y_amax = nullptr) {
+    float am = 0.f;                          // largest output this thread stores (y_amax: the tensor's amax slot, common.h "h2")
     constexpr int PR = 2 * STEM_TR + 5, PC = 2 * STEM_TC + 5, CS = PR * STEM_S, KP = 148;
     __shared__ float sw[KP * STEM_LDW];          // [k][n]
     __shared__ float sx[3 * CS];                 // [c][patch row][patch col]
@@ -124,28 +126,40 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
             const float bv = j ? bv1 : bv0;
             if (interior) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)fmaxf(acc[i][j][r] + bv, 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[i][j][r] + bv, 0.f);
+                    row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)v;
+                    am = fmaxf(am, v);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (oy < Ho && ox < Wo) row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)fmaxf(acc[i][j][r] + bv, 0.f);
+                    if (oy < Ho && ox < Wo) {
+                        const float v = fmaxf(acc[i][j][r] + bv, 0.f);
+                        row[((r & 3) + 8 * (r >> 2)) * 64 + j * 32] = (T)v;
+                        am = fmaxf(am, v);
+                    }
                 }
             }
         }
     }
   }
+  if (y_amax) radet_amax_publish(am, y_amax);                  // (persistent workgroups: one atomic per wave and launch)
 }
 
-extern "C" int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc,
-                                       int B, int H, int W, void* stream) {
+extern "C" int radet_stem_conv_bn_relu_a(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc,
+                                         int B, int H, int W, void* y_amax, void* stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int ntiles = ((Wo + STEM_TC - 1) / STEM_TC) * ((Ho + STEM_TR - 1) / STEM_TR) * B;
     dim3 grid(ntiles < 512 ? ntiles : 512);                      // 2 workgroups per CU (57 KiB of LDS each)
     hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, img_nchw, wf_ohwi, bias, y_nhwc, H, W,
-                       Ho, Wo, B);
+                       Ho, Wo, B, (unsigned*)y_amax);
     return radet_check_launch();
+}
+extern "C" int radet_stem_conv_bn_relu(const float* img_nchw, const float* wf_ohwi, const float* bias, float* y_nhwc,
+                                       int B, int H, int W, void* stream) {
+    return radet_stem_conv_bn_relu_a(img_nchw, wf_ohwi, bias, y_nhwc, B, H, W, nullptr, stream);
 }
 
 extern "C" int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_ohwi, const float* bias, void* y_nhwc,
@@ -161,8 +175,17 @@ extern "C" int radet_stem_conv_bn_relu_h(const float* img_nchw, const float* wf_
 // ------------------------------------------------------------------------------------------ maxpool
 template <class T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C4,
-                               int Ho, int Wo, unsigned* amax = nullptr) {
+                               int Ho, int Wo, unsigned* amax = nullptr, _Float16* yq = nullptr, unsigned* yq_amax = nullptr,
+                               const unsigned* x_amax = nullptr) {
     float am = 0.f;                          // largest |y| stored by this thread (amax: the output's h2 slot, common.h)
+    // yq: the output once more as fp16 plane pairs, scaled by the power of two of amax(x) (a max-pool's outputs are inputs)
+    float qs = 1.f, qs2 = 2048.f;
+    if (yq) {
+        const unsigned bits = radet_amax_read(x_amax);
+        if (blockIdx.x == 0 && threadIdx.x == 0) radet_amax_store(yq_amax, bits);
+        const int e = radet_h2_exp(bits);
+        qs = radet_pow2(e); qs2 = radet_pow2(e + 11);
+    }
     // one thread = TWO horizontally adjacent outputs of one channel quad: their 3 x 3 windows share a column, 15 loads
     // instead of 18 (all unconditional: an out-of-range tap is clamped onto the border pixel, which is inside the window
     // already -- max is idempotent -- instead of skipped: a skipped load is a branch and a wait per tap)
@@ -200,6 +223,9 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
                     m.x = fmaxf(m.x, u.x); m.y = fmaxf(m.y, u.y); m.z = fmaxf(m.z, u.z); m.w = fmaxf(m.w, u.w);
                 }
             st4(y, ((size_t)(n * Ho + oy) * Wo + ox + h) * C4 + c, m);
+            if constexpr (std::is_same<T, float>::value) {
+                if (yq) st4_pairs(yq, (size_t)(n * Ho + oy) * Wo + ox + h, C4 * 4, c, m, qs, qs2);
+            }
             am = fmaxf(fmaxf(am, fmaxf(fabsf(m.x), fabsf(m.y))), fmaxf(fabsf(m.z), fabsf(m.w)));
         }
     }
@@ -220,6 +246,18 @@ extern "C" int radet_maxpool3x3s2_a(const float* x, float* y, int B, int H, int 
 }
 extern "C" int radet_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     return radet_maxpool3x3s2_a(x, y, B, H, W, C, nullptr, stream);
+}
+// ... and the output once more as fp16 plane pairs yq (rows [2][C], C % 32 == 0) scaled by the power of two of x's amax slot
+// (x_amax; its bits are stored to yq_amax)
+extern "C" int radet_maxpool3x3s2_q(const float* x, float* y, int B, int H, int W, int C, void* y_amax, void* yq, void* yq_amax,
+                                    const void* x_amax, void* stream) {
+    if (C % 32 || yq == nullptr || yq_amax == nullptr || x_amax == nullptr) return RADET_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * ((Wo + 1) / 2) * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 4, Ho, Wo,
+                       (unsigned*)y_amax, (_Float16*)yq, (unsigned*)yq_amax, (const unsigned*)x_amax);
+    return radet_check_launch();
 }
 
 extern "C" int radet_maxpool3x3s2_h(const void* x, void* y, int B, int H, int W, int C, void* stream) {
@@ -401,8 +439,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
     const int tid = threadIdx.x;
     float wmax = 0.f;                       // largest |folded weight| this thread stores -> d.w_amax (fp32 / bf16 stores; the plane
                                             // pairs of w16 = 3 need the maximum BEFORE they are written: fold_amax_kernel)
-    float ps = 1.f, ps2 = 2048.f;           // w16 = 3: the power-of-two scale of this conv's plane pairs
-    if (d.w16 == 3) {
+    float ps = 1.f, ps2 = 2048.f;           // w16 = 3 / wfq: the power-of-two scale of this conv's plane pairs
+    if (d.w16 == 3 || d.wfq) {
         const int e = radet_h2_exp(radet_amax_read(reinterpret_cast<const unsigned*>(d.w_amax)));
         ps = radet_pow2(e); ps2 = radet_pow2(e + 11);
     }
@@ -418,6 +456,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             const float v = d.w[((size_t)o * d.cin + c) * KT + t] * s;
             wmax = fmaxf(wmax, fabsf(v));
             stw(d.wf, oc, c, d.cin, v, d.w16, ps, ps2);
+            if (d.wfq) stw(d.wfq, oc, c, d.cin, v, 3, ps, ps2);
             if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16, ps, ps2);
         }
     } else {
@@ -459,6 +498,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
                 const float v = tile[oo][cl * KT + t] * ssc[oo];
                 wmax = fmaxf(wmax, fabsf(v));
                 stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, v, d.w16, ps, ps2);
+                if (d.wfq) stw(d.wfq, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, v, 3, ps, ps2);
             }
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
@@ -470,8 +510,9 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             }
         }
     }
-    if (d.w_amax && d.w16 != 3) radet_amax_publish(wmax, reinterpret_cast<unsigned*>(d.w_amax));     // (uniform branch)
+    if (d.w_amax && d.w16 != 3 && !d.wfq) radet_amax_publish(wmax, reinterpret_cast<unsigned*>(d.w_amax));     // (uniform branch)
     if (blockIdx.x == 0 && d.bias_f) {
+        float bmax = 0.f;
         for (int o = tid; o < d.cout; o += 256) {
             float b = 0.f;
             if (d.bn_gamma) {
@@ -479,7 +520,9 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
                 b = d.bn_beta[o] - d.bn_mean[o] * s;
             } else if (d.bias) b = d.bias[o];
             d.bias_f[o] = b;
+            bmax = fmaxf(bmax, fabsf(b));
         }
+        if (d.bias_amax) radet_amax_publish(bmax, reinterpret_cast<unsigned*>(d.bias_amax));        // (all threads reach this)
     }
 }
 
@@ -488,22 +531,41 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
 // atomicMax (order independent): by fold_kernel as it stores fp32 / bf16 weights, by the pass below for the convs whose
 // weights are stored as plane pairs (w16 = 3: the scale has to be known before the first store).
 __global__ void fold_amax_zero_kernel(const RadetConvDesc* __restrict__ table, int nconv) {      // one wave per conv
-    if (table[blockIdx.x].w_amax) reinterpret_cast<unsigned*>(table[blockIdx.x].w_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
+    const RadetConvDesc& d = table[blockIdx.x];
+    if (d.w_amax) reinterpret_cast<unsigned*>(d.w_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
+    if (d.w_l1) reinterpret_cast<unsigned*>(d.w_l1)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
+    if (d.bias_amax) reinterpret_cast<unsigned*>(d.bias_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
 }
 __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
-    if (d.w_amax == nullptr || d.w16 != 3) return;             // (the other convs' slots are raised by fold_kernel itself)
+    // (the other convs' w_amax slots are raised by fold_kernel itself).  w_l1 (optional): the largest L1 norm of a folded
+    // output channel, max_o sum_{c,t} |wf[o][t][c]| -- |conv output| <= amax(x) * that: the bound an epilogue that writes
+    // fp16 plane pairs scales them with (conv_common.h).  One workgroup sums a whole channel in a fixed order.
+    if (d.w_amax == nullptr || (d.w16 != 3 && !d.wfq && !d.w_l1)) return;
     const int K = d.cin * d.kh * d.kw;                         // OIHW: K contiguous weights per output channel
-    float m = 0.f;
+    __shared__ float red[4];
+    float m = 0.f, l1max = 0.f;
     for (int o = blockIdx.x; o < d.cout; o += gridDim.x) {
         float s = 1.f;
         if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
         const float* w = d.w + (size_t)o * K;
-        float mo = 0.f;
-        for (int k = threadIdx.x; k < K; k += 256) mo = fmaxf(mo, fabsf(w[k] * s));       // (the product fold_kernel stores)
+        float mo = 0.f, so = 0.f;
+        for (int k = threadIdx.x; k < K; k += 256) {
+            const float v = fabsf(w[k] * s);                   // (the product fold_kernel stores)
+            mo = fmaxf(mo, v);
+            so += v;
+        }
         m = fmaxf(m, mo);
+        if (d.w_l1) {                                           // (uniform)
+            so = wave_sum(so);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = so;
+            __syncthreads();
+            l1max = fmaxf(l1max, (red[0] + red[1]) + (red[2] + red[3]));
+        }
     }
-    radet_amax_publish(m, reinterpret_cast<unsigned*>(d.w_amax));
+    if (d.w16 == 3 || d.wfq) radet_amax_publish(m, reinterpret_cast<unsigned*>(d.w_amax));
+    if (d.w_l1) radet_amax_publish(l1max, reinterpret_cast<unsigned*>(d.w_l1));
 }
 
 extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {

@@ -85,6 +85,13 @@ class Engine:
         x3mode = os.environ.get("RADET_X3", "h2")
         self.x3 = math == "fp32" and x3mode != "0"
         self.h2 = self.x3 and x3mode not in ("bf16", "b3")      # fp16 hi / lo arithmetic (3 plane products instead of 6)
+        # Pair copies in the backbone (round 5): the forward launches of the bottleneck blocks and the lateral convs read their
+        # x operand as fp16 plane pairs that the PRODUCER's epilogue wrote next to the fp32 tensor (scaled by a bound it can
+        # form before it starts, conv_common.h ConvPtrs::yq), and their weights as pairs from the fold -- no operand split in
+        # those K loops (25-30 % less time per launch alone, tools/bench_h2.py).  RADET_PAIRS=0: split in registers.
+        # From layer2 on (RADET_PAIRS_FROM): the pair copy is a second 4-byte write per output element, which the
+        # 76 800-row layer1 tensors do not earn back (measured: 9.14 ms with layer1, 8.73 from layer2, 8.91 without).
+        self.pairs = self.h2 and os.environ.get("RADET_PAIRS", "1") != "0"
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
         # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only
@@ -224,12 +231,16 @@ class Engine:
         self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
         # amax slots of the folded weights (fp16 hi / lo arithmetic): one per conv, written by radet_fold_weights
         self.w_amax = K.new_amax(dev, len(self.convs))
+        self.w_l1 = K.new_amax(dev, len(self.convs)) if self.pairs else None          # largest channel L1 norm / largest |bias_f|
+        self.b_amax = K.new_amax(dev, len(self.convs)) if self.pairs else None
         self._w_amax_keys = []
         o_w = o_b = o_t = 0
         towers = (self.cls_tower + self.reg_tower) if self.p3 else []
         pkind = "h2" if self.h2 else "b3"
         for ci, c in enumerate(self.convs):
             c.w_amax = self.w_amax[ci]
+            c.wfq = None
+            c.wmeta = (self.w_l1[ci], self.b_amax[ci] if (c.bn or c.bias) else None) if self.pairs else None
             c.w16 = (3 if self.h2 else 2) if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
             c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
@@ -246,6 +257,9 @@ class Engine:
                 c.wf = K.Planes(c.cout * c.k * c.k, c.cin, device=dev, kind=pkind, amax=c.w_amax)
                 c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev, kind=pkind, amax=c.w_amax)
             elif self.h2 and c is not self.convs[0]:
+                if self.pairs and c.name.startswith(("backbone.layer", "neck.lateral")) and c.cin % 32 == 0 and \
+                        (not c.name.startswith("backbone.layer") or int(c.name[14]) >= int(os.environ.get("RADET_PAIRS_FROM", "2"))):
+                    c.wfq = K.Planes(c.cout * c.k * c.k, c.cin, device=dev, kind="h2", amax=c.w_amax)
                 self._w_amax_keys.append(K.register_amax(c.wf, c.w_amax))
                 if c.need_dgrad and c.wft_shared is None:
                     self._w_amax_keys.append(K.register_amax(c.wft, c.w_amax))
@@ -324,12 +338,14 @@ class Engine:
         self._pfx_active, self._pfx_ready = 0, None
         n_pfx = [0]
 
-        def new(name, rows, ch, dtype=None, prefix=False):
+        def new(name, rows, ch, dtype=None, prefix=False, twin=False):
+            """twin: a pair copy of the buffer (Planes "h2", written by the producer's epilogue) under name + '@q'"""
             t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)
             self.buf[name] = t
             if prefix:
-                self._pfx_shapes[name] = (rows, ch, t.dtype)
+                self._pfx_shapes[name] = (rows, ch, t.dtype, twin and self.pairs)
                 self._pfx_sets[0][name] = t
+            sl_ = None
             if self.h2 and t.dtype == torch.float32:
                 if prefix:
                     assert n_pfx[0] < self.amax_pfx[0].shape[0], "frozen prefix: more buffers than amax slots"
@@ -338,11 +354,17 @@ class Engine:
                 else:
                     sl_ = slot()
                 self._amax_keys.append(K.register_amax(t, sl_, by_storage=True))
+            if twin and self.pairs and ch % 32 == 0:
+                q = K.Planes(rows, ch, device=dev, kind="h2")
+                q.true_amax = sl_                 # (the slot the producer RAISES; q.amax holds the bound its pairs were scaled with)
+                self.buf[name + "@q"] = q
+                if prefix:
+                    self._pfx_sets[0][name + "@q"] = q
             return t
 
         frozen_prefix = not self.stem.trainable
         new("stem", B * h1 * w1, 64, prefix=frozen_prefix)
-        new("pool", B * h2 * w2, 64, prefix=frozen_prefix)
+        new("pool", B * h2 * w2, 64, prefix=frozen_prefix, twin=True)
         if self.stem.trainable:           # frozen_stages = -1: gradients w.r.t. the pooled map and the stem's pre-activation
             new("d_pool", B * h2 * w2, 64)
             new("d_stem", B * h1 * w1, 64)
@@ -361,9 +383,9 @@ class Engine:
                     blk["ds"].geom = ConvGeom(lv, blk["ds"].cin, blk["ds"].cout, 1, blk["stride"], 0)
                     new(pfx + ".idt", lo.rows, blk["ds"].cout, prefix=fz)
                 blk["lout"] = lo
-                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz)
-                new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz)
-                new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz)
+                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz, twin=True)
+                new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz, twin=True)
+                new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz, twin=True)
                 if blk["train"]:
                     new(pfx + ".d_o1", lv.rows, blk["c1"].cout)
                     new(pfx + ".d_o2", lo.rows, blk["c2"].cout)
@@ -447,6 +469,7 @@ class Engine:
                 c.geom.h16 = self.h16
                 c.geom.x3 = self.x3
                 c.geom.h2 = self.h2
+                c.geom.pairs = c.wfq is not None
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         self._plan_wgrad_groups()
         if tune:
@@ -556,6 +579,9 @@ class Engine:
             d.wft_ld, d.wft_off = c.wft_ld, c.wft_off
             d.w16 = c.w16
             d.w_amax = ptr(c.w_amax) if self.h2 else None
+            if self.pairs and c is not self.convs[0]:
+                d.wfq = ptr(c.wfq)
+                d.w_l1, d.bias_amax = ptr(c.wmeta[0]), ptr(self.b_amax[self.convs.index(c)])
             d.nsplit = c.geom.nsplit if c.geom is not None else 1
             if c.trainable and c.geom is not None:
                 d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
@@ -651,9 +677,24 @@ class Engine:
         K.unfold_grads(self.table, len(self.convs), self.max_cout)
 
     # ------------------------------------------------------------------ forward
-    def _block_forward(self, blk, pfx, x, b):
+    def _block_forward(self, blk, pfx, x, b, xq=None):
+        """one bottleneck block; xq: the pair copy of x (written by x's producer) -- with it, and pair weights from the fold,
+        the block's launches run without an operand split and write pair copies of their own outputs for the next ones"""
         blk["x"] = x
         o1, o2, out = b[pfx + ".o1"], b[pfx + ".o2"], b[pfx + ".out"]
+        c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+        if xq is not None and c1.wfq is not None and c2.wfq is not None and c3.wfq is not None and (ds is None or ds.wfq is not None):
+            o1q, o2q, outq = b[pfx + ".o1@q"], b[pfx + ".o2@q"], b.get(pfx + ".out@q")
+            K.conv_fwd(c1.geom, xq, c1.wfq, c1.bias_f, o1, relu=True, tile=c1.geom.fwd_tile_q, yq=o1q, wmeta=c1.wmeta)
+            K.conv_fwd(c2.geom, o1q, c2.wfq, c2.bias_f, o2, relu=True, tile=c2.geom.fwd_tile_q, yq=o2q, wmeta=c2.wmeta)
+            if ds is not None:
+                idt = b[pfx + ".idt"]
+                K.conv_fwd(ds.geom, xq, ds.wfq, ds.bias_f, idt, tile=ds.geom.fwd_tile_q)
+            else:
+                idt = x
+            K.conv_fwd(c3.geom, o2q, c3.wfq, c3.bias_f, out, addend=idt, relu=True, tile=c3.geom.fwd_tile_q, yq=outq,
+                       wmeta=c3.wmeta)
+            return out
         K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
         K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
         if blk["ds"] is not None:
@@ -678,12 +719,13 @@ class Engine:
             self.amax_pfx[which].zero_()     # every producer of this pass raises its buffer's slot from zero
         K.STAGE = "stem"
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
-        K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64)
-        x = b["pool"]
+        K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64, yq=b.get("pool@q"))
+        x, xq = b["pool"], b.get("pool@q")
         for li in range(self._n_frozen_stages()):
             K.STAGE = f"layer{li + 1}"
             for bi, blk in enumerate(self.stages[li]):
-                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b)
+                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b, xq)
+                xq = b.get(f"l{li + 1}.{bi}.out@q")
         return b
 
     @staticmethod
@@ -705,11 +747,15 @@ class Engine:
             self._pfx_sets[other] = {}
             if self.h2:
                 self.amax_pfx[other] = K.new_amax(self.dev, 128)
-            for i, (name, (rows, ch, dt)) in enumerate(self._pfx_shapes.items()):
+            for i, (name, (rows, ch, dt, twin)) in enumerate(self._pfx_shapes.items()):
                 t = torch.empty(rows, ch, device=self.dev, dtype=dt)
                 self._pfx_sets[other][name] = t
                 if self.h2 and dt == torch.float32:
                     self._amax_keys.append(K.register_amax(t, self.amax_pfx[other][i], by_storage=True))
+                if twin:
+                    q = K.Planes(rows, ch, device=self.dev, kind="h2")
+                    q.true_amax = self.amax_pfx[other][i]
+                    self._pfx_sets[other][name + "@q"] = q
         cs = self._chain_stream()
         self._fork(cs)                                         # (the frozen convs' folded weights are complete on this stream)
         stage = K.STAGE
@@ -737,11 +783,12 @@ class Engine:
         else:
             K.STAGE = "stem"
             K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], self.B, self.H, self.W)
-            K.maxpool(b["stem"], b["pool"], self.B, self.stem_hw[0], self.stem_hw[1], 64)
+            K.maxpool(b["stem"], b["pool"], self.B, self.stem_hw[0], self.stem_hw[1], 64, yq=b.get("pool@q"))
             pb = b
         if not self.stem.trainable:
             b.update(pb)                     # the names of the prefix buffers resolve to the set this step uses
-        x = pb["pool"] if nf == 0 else pb[f"l{nf}.{len(self.stages[nf - 1]) - 1}.out"]
+        last = "pool" if nf == 0 else f"l{nf}.{len(self.stages[nf - 1]) - 1}.out"
+        x, xq = pb[last], pb.get(last + "@q")
         outs = [pb[f"l{li + 1}.{len(self.stages[li]) - 1}.out"] for li in range(nf)]
         for li in range(nf, len(self.stages)):
             blocks = self.stages[li]
@@ -749,7 +796,8 @@ class Engine:
             if blocks[0]["train"]:
                 self._await_fold()            # trainable weights are being folded on the side stream
             for bi, blk in enumerate(blocks):
-                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b)
+                x = self._block_forward(blk, f"l{li + 1}.{bi}", x, b, xq)
+                xq = b.get(f"l{li + 1}.{bi}.out@q")
             outs.append(x)
         return outs  # C2..C5 row buffers
 
@@ -760,7 +808,11 @@ class Engine:
         b, B = self.buf, self.B
         c = feats[1:]
         for i in range(3):
-            K.conv_fwd(self.lat[i].geom, c[i], self.lat[i].wf, self.lat[i].bias_f, b[f"lat{i}"])
+            cq = b.get(f"l{i + 2}.{len(self.stages[i + 1]) - 1}.out@q")
+            if cq is not None and self.lat[i].wfq is not None:      # the block's epilogue wrote C3..C5 as plane pairs too
+                K.conv_fwd(self.lat[i].geom, cq, self.lat[i].wfq, self.lat[i].bias_f, b[f"lat{i}"], tile=self.lat[i].geom.fwd_tile_q)
+            else:
+                K.conv_fwd(self.lat[i].geom, c[i], self.lat[i].wf, self.lat[i].bias_f, b[f"lat{i}"])
         hw = self.plv.hw
         for i in (2, 1):
             K.upsample_add(b[f"lat{i - 1}"], b[f"lat{i}"], B, hw[i - 1][0], hw[i - 1][1], hw[i][0], hw[i][1], self.feat)

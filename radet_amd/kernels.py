@@ -180,6 +180,8 @@ class ConvGeom:
         self._x3 = False                      # fp32 tensors, conv products from 16-bit planes of the operands (tile flag X3) ...
         self.h2 = False                       # ... two fp16 planes and 3 plane products (tile flag H2) instead of three bf16 / 6
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
+        self.pairs = False                    # forward launches read x as plane pairs written by its producer (fwd_tile_q)
+        self.fwd_tile_q = 0
         self.wgrad_pair_flags = 0             # weight gradient on fp16 plane pairs: 0x40 one-tap kernel, bits 4-5 its tile (1: 128 x 128)
         self.nsplit_pairs = 0                 # its pixel splits (0: nsplit)
         self._ft = self._bt = self._classes = None
@@ -482,6 +484,28 @@ def autotune(g, need_dgrad=True, reps=None):
         if os.environ.get("RADET_TUNE_LOG"):
             print(f"[tune igemm] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={ft:#x} dgrad tile={bt:#x}")
     g.fwd_tile, g.bwd_tile = _TUNE_CACHE[key]
+    if getattr(g, "pairs", False) and _h2key(g) and g.cin % 32 == 0:
+        # forward launches whose x arrives as fp16 plane pairs (the producer's epilogue wrote them): the 4-wave plane tiles
+        keyq = key + ("q",)
+        if keyq not in _TUNE_CACHE:
+            _TUNE_DIRTY = True
+            TUNE_RUNS += 1
+            x = torch.randn(g.lin.rows, g.cin, device=dev)
+            w = torch.randn(g.cout * g.k * g.k, g.cin, device=dev) * 0.05
+            xq, wq = Planes.from_float(x, kind="h2"), Planes.from_float(w, kind="h2")
+            y = torch.empty(g.lout.rows, g.cout, device=dev)
+            cq = [1, 2, 3, 1 | STAGES3, 2 | STAGES3, 3 | STAGES3]
+            for t in list(cq):
+                bm = 64 if (t & 0xFF) == 3 else 128
+                bn = {1: 128, 2: 64, 3: 64}[t & 0xFF]
+                ntiles = -(-g.lout.rows // bm) * -(-g.cout // bn)
+                nk = g.k * g.k * g.cin // 32
+                if ntiles < 1024:
+                    cq += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
+            _TUNE_CACHE[keyq] = (best_of(lambda t: conv_fwd(g, xq, wq, None, y, relu=True, tile=t), cq), 0)
+            if os.environ.get("RADET_TUNE_LOG"):
+                print(f"[tune igemm pairs] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={_TUNE_CACHE[keyq][0]:#x}")
+        g.fwd_tile_q = _TUNE_CACHE[keyq][0]
 
 
 KW_DEEP = os.environ.get("RADET_KW_DEEP", "1") != "0"
@@ -606,18 +630,26 @@ def absmax(t, slot):
 _SCALES = _LRU(4096)
 
 
-def _scales(x, w, y, x1=None, w1=None, y1=None, need=True):
+def _scales(x, w, y, x1=None, w1=None, y1=None, need=True, yq=None, wmeta=None, addend=None):
     """RadetScales for a launch (cached per slot combination).  need: the x / w slots are required (h2 arithmetic): missing
-    ones are computed on the spot; otherwise only the output slot matters and None is returned when there is none."""
+    ones are computed on the spot; otherwise only the output slot matters and None is returned when there is none.
+    yq (Planes "h2"): the pair copy of the output, with wmeta = (w_l1 slot, bias amax slot or None) of the conv and the
+    launch's addend (its slot bounds the residual term)."""
     sx, sw, sy = amax_slot(x, need), amax_slot(w, need), amax_slot(y)
     sx1, sw1, sy1 = amax_slot(x1, need), amax_slot(w1, need), amax_slot(y1)
-    if not need and sy is None and sy1 is None:
+    if not need and sy is None and sy1 is None and yq is None:
         return None
-    key = tuple(0 if t is None else t.data_ptr() for t in (sx, sw, sy, sx1, sw1, sy1))
+    ext = (None,) * 6
+    if yq is not None:
+        xt = getattr(x, "true_amax", None) if _isp(x) else amax_slot(x, True)
+        assert xt is not None and wmeta is not None, "pair copy of a conv output: the true amax slot of x and the conv's L1 slot"
+        ext = (yq.t, yq.amax, xt, wmeta[0], wmeta[1], amax_slot(addend, True) if addend is not None else None)
+    slots = (sx, sw, sy, sx1, sw1, sy1) + ext
+    key = tuple(0 if t is None else t.data_ptr() for t in slots)
     ent = _SCALES.get(key)
     if ent is None:
         sc = _lib.RadetScales(*[None if v == 0 else v for v in key])
-        ent = _SCALES[key] = (C.byref(sc), sc, (sx, sw, sy, sx1, sw1, sy1))       # (the struct and the slots stay alive with it)
+        ent = _SCALES[key] = (C.byref(sc), sc, slots)              # (the struct and the slots stay alive with it)
     return ent[0]
 
 
@@ -707,12 +739,13 @@ def _tile(g, tile, default, x=None, y=None):
     return t
 
 
-def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True):
+def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True, yq=None, wmeta=None):
+    """yq (Planes "h2", optional): y once more as fp16 plane pairs, scaled by the bound the launch can form before it starts
+    (include/radet_hip.h RadetScales.yq); wmeta = (w_l1 slot, bias amax slot) of the conv, from the fold"""
     tile = _tile(g, tile, g.fwd_tile, x, y)
     ws = splitk_ws() if splitk else None
     table = g.fwd_table
-
-    sc = _scales(x, wf, y, need=bool(tile & H2))
+    sc = _scales(x, wf, y, need=bool(tile & H2), yq=yq, wmeta=wmeta, addend=addend)
 
     def launch():
         _lib.call("radet_conv2d_igemm_s", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
@@ -985,9 +1018,12 @@ def _h(name, t):
 
 def stem(img, wf, bias, y, B, H, W):
     ho, wo = (H + 1) // 2, (W + 1) // 2
-    _timed("stem_kernel", 2.0 * B * ho * wo * 64 * 147,
-           lambda: _lib.call(_h("radet_stem_conv_bn_relu", y), _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream()),
-           4.0 * (B * 3 * H * W + 64 * 147 + B * ho * wo * 64))
+    if _is16(y):
+        fn = lambda: _lib.call("radet_stem_conv_bn_relu_h", _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _stream())  # noqa: E731
+    else:
+        sl = amax_slot(y)
+        fn = lambda: _lib.call("radet_stem_conv_bn_relu_a", _ptr(img), _ptr(wf), _ptr(bias), _ptr(y), B, H, W, _ptr(sl), _stream())  # noqa: E731
+    _timed("stem_kernel", 2.0 * B * ho * wo * 64 * 147, fn, 4.0 * (B * 3 * H * W + 64 * 147 + B * ho * wo * 64))
 
 
 def convert_rows(src, dst, ncols=None, src_off=0, dst_off=0):
@@ -998,9 +1034,14 @@ def convert_rows(src, dst, ncols=None, src_off=0, dst_off=0):
               dst.stride(0), dst_off, 1 if dst.dtype == torch.bfloat16 else 0, _stream())
 
 
-def maxpool(x, y, B, H, W, Cch):
+def maxpool(x, y, B, H, W, Cch, yq=None):
+    """yq (Planes "h2", optional): the output once more as plane pairs, scaled by x's amax slot"""
     if _is16(x):
         _lib.call("radet_maxpool3x3s2_h", _ptr(x), _ptr(y), B, H, W, Cch, _stream())
+        return
+    if yq is not None:
+        _lib.call("radet_maxpool3x3s2_q", _ptr(x), _ptr(y), B, H, W, Cch, _ptr(amax_slot(y)), _ptr(yq.t), _ptr(yq.amax),
+                  _ptr(amax_slot(x, True)), _stream())
         return
     _lib.call("radet_maxpool3x3s2_a", _ptr(x), _ptr(y), B, H, W, Cch, _ptr(amax_slot(y)), _stream())
 

@@ -136,7 +136,7 @@ def _harness(seed):
         def loss(self, tg, grad_scale=None, **kw):
             return self.engine.losses
 
-        def backward(self, bucket_hook=None):
+        def backward(self, bucket_hook=None, next_img=None):
             g = torch.Generator().manual_seed(1000 + dist.get_rank())
             self.flat.grads.copy_(torch.randn(self.flat.n_train, generator=g) * self.param_mask())
             for b in self.buckets:                       # head -> neck -> layer4 -> layer3 -> layer2

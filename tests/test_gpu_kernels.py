@@ -1305,3 +1305,59 @@ def test_wgrad_one_tap_on_plane_pairs(K, case):
         K.conv_wgrad(geom, dyq, xq, slabs, bp)
         assert rel_err(slabs.sum(0).reshape(Cout, k, k, Cin).permute(0, 3, 1, 2), gw) < 2e-5, S
         assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 20, 24, 1, 1, 3), (2, 256, 128, 18, 22, 3, 2, 2), (1, 128, 256, 17, 23, 3, 1, 1),
+                                  (2, 512, 128, 15, 20, 1, 1, 0x3003), (1, 64, 256, 9, 11, 1, 1, 7), (2, 128, 128, 12, 16, 3, 1, 8)])
+def test_conv_epilogue_writes_plane_pair_copy(K, case):
+    """RadetScales.yq: a conv launch (any fp32-tensor tile, here the in-register fp16 hi / lo ones, and plane-pair inputs)
+    writes its output once more as fp16 plane pairs, scaled by a bound it can form before it starts,
+    amax(x) * L1max(w) + max|bias| + amax(addend).  The bound bounds (and is not wildly loose), the pairs reproduce y to
+    2^-22 of every element, and a second conv that reads them (no operand split in its K loop) matches the fp64 chain like
+    the fp32 path does -- incl. split-K, K-divided and strided producers and a residual + ReLU epilogue."""
+    B, Cin, Cout, H, W, k, s, tile = case
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    dev = "cuda"
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pad = k // 2
+    y_ref = F.conv2d(x.double(), w.double(), bias.double(), stride=s, padding=pad)
+    Ho, Wo = y_ref.shape[2:]
+    res = torch.randn(B, Cout, Ho, Wo, generator=g)
+    out_ref = F.relu(y_ref + res.double())
+    geom = K.ConvGeom(K.Levels([(H, W)], B), Cin, Cout, k, s, pad)
+    geom.x3 = "h2"
+    xr, wf = to_rows(x).to(dev), fold_w(w).to(dev)
+    resr, br = to_rows(res).to(dev), bias.to(dev)
+    l1 = K.new_amax(dev)
+    l1[0] = int(torch.tensor(float(wf.abs().reshape(Cout, -1).sum(1).max()), dtype=torch.float32).view(torch.int32))
+    ba = K.new_amax(dev)
+    K.absmax(torch.cat([br, torch.zeros((4 - Cout % 4) % 4, device=dev)]), ba)
+    y = torch.empty(B * Ho * Wo, Cout, device=dev)
+    yq = K.Planes(B * Ho * Wo, Cout, device=dev, kind="h2")
+    ys = K.new_amax(dev)
+    key = K.register_amax(y, ys)
+    for xin, win in ((xr, wf), (K.Planes.from_float(xr, kind="h2"), K.Planes.from_float(wf.reshape(Cout * k * k, Cin), kind="h2"))):
+        if K._isp(xin):
+            xin.true_amax = K.amax_slot(xr, compute=True)
+            t = (tile & 0xF000) | (3 if (tile & 0xFF) >= 7 else tile & 0xFF)          # (no K-divided tile for plane operands)
+        else:
+            t = tile
+        y.fill_(float("nan")); yq.t.zero_(); ys.zero_()
+        K.conv_fwd(geom, xin, win, br, y, addend=resr, relu=True, tile=t, yq=yq, wmeta=(l1, ba))
+        assert rel_err(from_rows(y, B, Ho, Wo), out_ref) < 1e-5
+        bound, amax = K.amax_value(yq.amax), float(y.abs().max())
+        assert K.amax_value(ys) == amax and amax <= bound <= 64 * amax + 8.0, (amax, bound)
+        back = yq.to_float()
+        tol = y.abs() * 2.0 ** -22 + bound * 2.0 ** -36
+        assert bool(((back - y).abs() <= tol).all()), float(((back - y).abs() / tol).max())
+    K.unregister_amax([key])
+    # the consumer: a 1 x 1 conv on the pairs against the fp64 chain
+    C2 = 96
+    w2 = torch.randn(C2, Cout, 1, 1, generator=g) / Cout ** 0.5
+    ref2 = F.conv2d(out_ref, w2.double())
+    g2 = K.ConvGeom(K.Levels([(Ho, Wo)], B), Cout, C2, 1, 1, 0)
+    y2 = torch.empty(B * Ho * Wo, C2, device=dev)
+    K.conv_fwd(g2, yq, K.Planes.from_float(fold_w(w2).reshape(C2, Cout).to(dev), kind="h2"), None, y2, tile=3)
+    assert rel_err(from_rows(y2, B, Ho, Wo), ref2) < 1e-5

@@ -31,8 +31,8 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/radet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
     _lib.load()
-    assert ctypes.sizeof(_lib.RadetConvDesc) == 168                 # 15 pointers + 9 32-bit fields (padded to 8) + w_amax
-    assert ctypes.sizeof(_lib.RadetScales) == 48                    # 6 device pointers
+    assert ctypes.sizeof(_lib.RadetConvDesc) == 192                 # 15 pointers + 9 32-bit fields (padded to 8) + 4 pointers
+    assert ctypes.sizeof(_lib.RadetScales) == 96                    # 12 device pointers
 
 
 def test_host_only_entry_points():

@@ -65,6 +65,10 @@ def main():
                 thz = timeit(lambda: zf(slots[2]))
                 K.unregister_amax([ky])
                 row.append(f"t{tile & 0xFF}{chr(97 + (tile >> 17))}: {t3:5.1f} {th:5.1f} {tha:5.1f} [{thd:5.1f} {thz:5.1f}]")
+            xq, wq = K.Planes.from_float(x, kind="h2"), K.Planes.from_float(w.view(Cout * k * k, Cin), kind="h2")
+            for tile in (1, 2, 3, 3 | 0x20000):
+                tq = timeit(lambda: K.conv_fwd(g, xq, wq, None, y, relu=True, tile=tile))
+                row.append(f"pairs t{tile & 0xFF}{chr(97 + (tile >> 17))}: {tq:5.1f}")
         else:
             dy = torch.randn(g.lout.rows, Cout, device=dev)
             K.absmax(dy, slots[2])

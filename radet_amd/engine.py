@@ -89,9 +89,13 @@ class Engine:
         # x operand as fp16 plane pairs that the PRODUCER's epilogue wrote next to the fp32 tensor (scaled by a bound it can
         # form before it starts, conv_common.h ConvPtrs::yq), and their weights as pairs from the fold -- no operand split in
         # those K loops (25-30 % less time per launch alone, tools/bench_h2.py).  RADET_PAIRS=0: split in registers.
-        # From layer2 on (RADET_PAIRS_FROM): the pair copy is a second 4-byte write per output element, which the
-        # 76 800-row layer1 tensors do not earn back (measured: 9.14 ms with layer1, 8.73 from layer2, 8.91 without).
-        self.pairs = self.h2 and os.environ.get("RADET_PAIRS", "1") != "0"
+        # The pair copy is a second 4-byte write per output element, and in the step that costs more than the K loops save:
+        # measured (r50 640x480 bs 4, same box, ms per step) 8.92 without, 9.10 from layer2 on (RADET_PAIRS_FROM), 8.99 from
+        # layer3, 8.96 from layer4, 9.14 with layer1 -- OFF by default (RADET_PAIRS=1 selects it; the kernels, the bound logic
+        # and the tests stay).  [A first measurement showed 8.73: the first pair stage was reading a copy nobody had written
+        # -- zeros -- and the matrix cores clock higher on zeros.  Timings are only comparable on live data.]
+        self.pairs = self.h2 and os.environ.get("RADET_PAIRS", "0") == "1"
+        self.pairs_from = int(os.environ.get("RADET_PAIRS_FROM", "2"))          # first ResNet stage (1-based) that reads pairs
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
         # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only
@@ -258,7 +262,7 @@ class Engine:
                 c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev, kind=pkind, amax=c.w_amax)
             elif self.h2 and c is not self.convs[0]:
                 if self.pairs and c.name.startswith(("backbone.layer", "neck.lateral")) and c.cin % 32 == 0 and \
-                        (not c.name.startswith("backbone.layer") or int(c.name[14]) >= int(os.environ.get("RADET_PAIRS_FROM", "2"))):
+                        (not c.name.startswith("backbone.layer") or int(c.name[14]) >= self.pairs_from):
                     c.wfq = K.Planes(c.cout * c.k * c.k, c.cin, device=dev, kind="h2", amax=c.w_amax)
                 self._w_amax_keys.append(K.register_amax(c.wf, c.w_amax))
                 if c.need_dgrad and c.wft_shared is None:
@@ -364,7 +368,7 @@ class Engine:
 
         frozen_prefix = not self.stem.trainable
         new("stem", B * h1 * w1, 64, prefix=frozen_prefix)
-        new("pool", B * h2 * w2, 64, prefix=frozen_prefix, twin=True)
+        new("pool", B * h2 * w2, 64, prefix=frozen_prefix, twin=self.pairs_from <= 1)
         if self.stem.trainable:           # frozen_stages = -1: gradients w.r.t. the pooled map and the stem's pre-activation
             new("d_pool", B * h2 * w2, 64)
             new("d_stem", B * h1 * w1, 64)
@@ -383,9 +387,10 @@ class Engine:
                     blk["ds"].geom = ConvGeom(lv, blk["ds"].cin, blk["ds"].cout, 1, blk["stride"], 0)
                     new(pfx + ".idt", lo.rows, blk["ds"].cout, prefix=fz)
                 blk["lout"] = lo
-                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz, twin=True)
-                new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz, twin=True)
-                new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz, twin=True)
+                tw = li + 1 >= self.pairs_from                  # pair copies where a consumer reads them: inside the stages that
+                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz, twin=tw)            # run on pairs, and the block output
+                new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz, twin=tw)            # that feeds the first of them
+                new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz, twin=tw or (li + 2 == self.pairs_from and b == len(blocks) - 1))
                 if blk["train"]:
                     new(pfx + ".d_o1", lv.rows, blk["c1"].cout)
                     new(pfx + ".d_o2", lo.rows, blk["c2"].cout)
@@ -702,7 +707,9 @@ class Engine:
             K.conv_fwd(blk["ds"].geom, x, blk["ds"].wf, blk["ds"].bias_f, idt)
         else:
             idt = x
-        K.conv_fwd(blk["c3"].geom, o2, blk["c3"].wf, blk["c3"].bias_f, out, addend=idt, relu=True)
+        outq = b.get(pfx + ".out@q")       # (the last block before the stages that run on pairs writes the copy they start from)
+        K.conv_fwd(blk["c3"].geom, o2, blk["c3"].wf, blk["c3"].bias_f, out, addend=idt, relu=True, yq=outq,
+                   wmeta=c3.wmeta if outq is not None else None)
         return out
 
     def _n_frozen_stages(self):
@@ -841,6 +848,28 @@ class Engine:
         st = Engine._SHARED_STREAMS.get(key)
         if st is None:
             st = Engine._SHARED_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+        return st
+
+    def caller_stream(self):
+        """A HIP stream for the CALLER's own asynchronous work next to the step (a data loader's upload stream, say) that does not
+        land on the main stream's pipe.  HIP hands out hardware queues in the order of the streams' first use, and queues k and
+        k + 4 share a pipe of the command processor, on which a queue waiting in a cross-stream barrier holds up the other one
+        (tools/micro/stream_cliff.hip, profiles/round5_stream_cliff.txt): the engine's four streams take queues 0-3, so the
+        next stream anybody uses gets queue 4 = the pipe of queue 0, the main stream -- the critical path.  This touches the
+        engine's streams (so that they hold 0-3), two placeholders (queues 4, 5; kept alive) and returns the stream that got
+        queue 6.  Measured (tools/bench_user_stream.py): a 14.7 MB upload per step costs 9.05 -> 9.30 ms on a plainly created
+        fifth stream and 9.05 -> 9.05 ms on this one.  Call it after the first step or prepare(), before creating other streams."""
+        key = (torch.device(self.dev).index if torch.device(self.dev).index is not None else torch.cuda.current_device(), "caller")
+        st = Engine._SHARED_STREAMS.get(key)
+        if st is None:
+            touch = [self._side(), self._side2(), self._chain_stream()]
+            touch += [torch.cuda.Stream(device=self.dev) for _ in range(2)]
+            Engine._SHARED_STREAMS[key + ("placeholders",)] = touch[3:]
+            st = Engine._SHARED_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+            for t in touch + [st]:
+                with torch.cuda.stream(t):
+                    torch.zeros(1, device=self.dev)
+            torch.cuda.synchronize(self.dev)
         return st
 
     def _side(self):

@@ -281,6 +281,11 @@ class DetectorRuntime:
         # (no collective here: a runtime may be built by a subset of the ranks -- rank-0 evaluation, checkpoint
         # conversion.  Data-parallel replicas are equalised by init_optimizer(), the entry point of every training run.)
 
+    def caller_stream(self):
+        """a HIP stream for the caller's own asynchronous work (next-batch upload) that stays off the main stream's pipe of the
+        command processor (Engine.caller_stream; INTEGRATION.md, streams)"""
+        return self.engine.caller_stream()
+
     def sync_replicas(self, src=0):
         """Broadcast the parameter arenas (trainable + frozen / BN statistics) and, once it exists, the optimizer
         state from rank `src`: what wrapping the model in MMDistributedDataParallel does at construction in the

@@ -49,3 +49,17 @@ b2 = run(None, "(a) after the fifth stream was used")
 e = run(torch.cuda.current_stream(), "(e) + next-batch upload on the main stream, in front of the step")
 print(f"main-stream upload {e / a2:.3f}")
 print(f"ratios vs (a): chain stream {c / a:.3f}, idle fifth stream {d / a2:.3f}, busy fifth stream {b / a2:.3f}, afterwards {b2 / a2:.3f}")
+# Round 5 (tools/micro/stream_cliff.hip): HIP hands hardware queues to streams in the order of their FIRST USE, and queues k and
+# k + 4 share a pipe of the command processor.  The engine's four streams hold queues 0-3, so a fifth stream gets queue 4 = the
+# MAIN stream's pipe.  Touching placeholder streams first moves the upload to queue 5 / 6 / 7 = the pipe of another engine stream.
+g = run(rt.engine.caller_stream(), "(g) upload on Engine.caller_stream()")
+run(None, "(a) afterwards")
+ph = []
+for n in (1, 2, 3):
+    p = torch.cuda.Stream()
+    with torch.cuda.stream(p):
+        torch.zeros(1, device=dev)
+    ph.append(p)
+    u = torch.cuda.Stream()
+    f = run(u, f"(f{n}) upload on a stream first used after {n} placeholder stream(s)")
+    run(None, "(a) afterwards")

@@ -219,20 +219,25 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
             // stores last, with nothing left in flight that they would have to wait for (on gfx9-class hardware a
             // store behind a conservative vmcnt(0) also waits for the store before it); interior tiles store unguarded
             if constexpr (IO == 0) {
-                if (P.yq) {                 // the same values as fp16 plane pairs (two rows per split: packed halves go to rows r, r + 1)
-                    unsigned short* const q = reinterpret_cast<unsigned short*>(P.yq) + radet_pair_off(cc);
+                if (P.yq) {
+                    // The same values as fp16 plane pairs.  A lane holds ONE channel of 16 rows; a row's 32-channel group is 128
+                    // bytes [hi x 32 | lo x 32].  Neighbouring lanes swap halves (one DPP move per row pair) so that every lane
+                    // stores 4 bytes: even lanes the hi halves of channels (c, c + 1), odd lanes the lo halves of (c - 1, c) --
+                    // one store instruction per row covers the whole 128-byte group, like the fp32 store next to it.
+                    const bool odd = li & 1;
+                    unsigned* const q = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(P.yq) +
+                                                                    radet_pair_off(cc & ~1) + (odd ? 32 : 0));
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         unsigned h, l;
-                        radet_split2(out[r], out[r + 1], a.qs, a.qs2, h, l);
-                        if (interior || (cvalid && rvalid[r])) {
-                            q[2 * obase[r]] = (unsigned short)(h & 0xFFFFu);
-                            q[2 * obase[r] + 32] = (unsigned short)(l & 0xFFFFu);
-                        }
-                        if (interior || (cvalid && rvalid[r + 1])) {
-                            q[2 * obase[r + 1]] = (unsigned short)(h >> 16);
-                            q[2 * obase[r + 1] + 32] = (unsigned short)(l >> 16);
-                        }
+                        radet_split2(out[r], out[r + 1], a.qs, a.qs2, h, l);     // h = hi(row r) | hi(row r + 1) << 16, l alike
+                        const unsigned send = odd ? h : l;                         // what the neighbour stores
+                        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);   // lanes 2k <-> 2k + 1
+                        const unsigned lo_ch = odd ? recv : h, hi_ch = odd ? l : recv;                     // channel c & ~1, channel c | 1
+                        const unsigned w0 = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);              // row r:     lo_ch[15:0] | hi_ch[15:0] << 16
+                        const unsigned w1 = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);              // row r + 1: the upper halves
+                        if (interior || (cvalid && rvalid[r])) q[obase[r]] = w0;
+                        if (interior || (cvalid && rvalid[r + 1])) q[obase[r + 1]] = w1;
                     }
                 }
             }

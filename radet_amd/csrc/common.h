@@ -210,14 +210,22 @@ __device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {   
     }
 }
 // the slot's value; call with all 64 lanes of the wave active (every lane loads one word).  Wave-uniform.
-__device__ __forceinline__ unsigned radet_amax_read(const unsigned* slot) {
-    unsigned v = slot[(threadIdx.x & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned u = (unsigned)__shfl_xor((int)v, o, 64);
-        v = u > v ? u : v;
-    }
-    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+// In two halves, so that a GEMM can put the (cold: every launch starts on invalidated L2s) load at its very top and the
+// reduction behind the wait for its first tiles: radet_amax_load issues the gather, radet_amax_reduce is four DPP maxima
+// inside the rows of 16 lanes + four v_readlane (a ds_bpermute butterfly is six dependent LDS round trips).
+__device__ __forceinline__ unsigned radet_amax_load(const unsigned* slot) {
+    return slot[(threadIdx.x & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE];
 }
+__device__ __forceinline__ unsigned radet_amax_reduce(unsigned v) {
+    auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    v = mx(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));       // quad_perm [1, 0, 3, 2]
+    v = mx(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));       // quad_perm [2, 3, 0, 1]
+    v = mx(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));      // row_half_mirror
+    v = mx(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));      // row_mirror: every lane of a row holds the row's maximum
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return mx(mx(r0, r1), mx(r2, r3));
+}
+__device__ __forceinline__ unsigned radet_amax_read(const unsigned* slot) { return radet_amax_reduce(radet_amax_load(slot)); }
 // a producer that KNOWS the value (a bound computed before writing): word 0, the other words stay zero
 __device__ __forceinline__ void radet_amax_store(unsigned* slot, unsigned bits) { slot[0] = bits; }

@@ -480,11 +480,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct H2Scale {              // of one operand tensor: s = 2^e, s2 = 2^(e + 11), inv = 2^-e
     float s, s2, inv;
 };
-__device__ __forceinline__ H2Scale h2_scale(const unsigned* slot) {
-    const int e = radet_h2_exp(radet_amax_read(slot));          // (all lanes active: kernel prologue)
+__device__ __forceinline__ H2Scale h2_scale_bits(unsigned amax_bits) {
+    const int e = radet_h2_exp(amax_bits);
     H2Scale r;
     r.s = radet_pow2(e); r.s2 = radet_pow2(e + 11); r.inv = radet_pow2(-e);
     return r;
+}
+__device__ __forceinline__ H2Scale h2_scale(const unsigned* slot) {          // (all lanes active: kernel prologue)
+    return h2_scale_bits(radet_amax_read(slot));
+}
+// the two halves of h2_scale for kernels that overlap the slot's (cold) load with their first tile loads: h2_scale_load at the
+// top of the kernel, h2_scale_finish behind the prologue's wait (the empty volatile asm keeps the reduction from being
+// scheduled in front of that wait)
+__device__ __forceinline__ unsigned h2_scale_load(const unsigned* slot) { return radet_amax_load(slot); }
+__device__ __forceinline__ H2Scale h2_scale_finish(unsigned raw) {
+    asm volatile("" : "+v"(raw));
+    return h2_scale_bits(radet_amax_reduce(raw));
 }
 // 8 k values of one lane -> the hi and lo operands of v_mfma_f32_32x32x16_f16 (24 VALU operations; split3_bf16: 44)
 __device__ __forceinline__ void split2_f16(const float (&a)[8], const H2Scale& sc, f16x8& hi, f16x8& lo) {
@@ -511,10 +522,19 @@ __device__ __forceinline__ void mfma_h2(f32x16& acc0, f32x16& acc1, const f16x8&
 }
 // scale of the fp16 pair copy of the output (ConvPtrs::yq), from quantities that are complete when the launch starts; call with
 // all lanes active.  `store`: this workgroup publishes the bound (one per problem).
-__device__ __forceinline__ void igemm_pair_scale(const ConvPtrs& P, bool store, float& qs, float& qs2) {
-    float bound = __uint_as_float(radet_amax_read(P.xt)) * __uint_as_float(radet_amax_read(P.wl1));
-    if (P.bs) bound += __uint_as_float(radet_amax_read(P.bs));
-    if (P.as) bound += __uint_as_float(radet_amax_read(P.as));
+struct PairScaleRaw { unsigned xt, wl1, bs, as; };
+__device__ __forceinline__ PairScaleRaw igemm_pair_scale_load(const ConvPtrs& P) {           // (P.yq != nullptr)
+    PairScaleRaw r;
+    r.xt = radet_amax_load(P.xt); r.wl1 = radet_amax_load(P.wl1);
+    r.bs = P.bs ? radet_amax_load(P.bs) : 0u;
+    r.as = P.as ? radet_amax_load(P.as) : 0u;
+    return r;
+}
+__device__ __forceinline__ void igemm_pair_scale(const ConvPtrs& P, PairScaleRaw r, bool store, float& qs, float& qs2) {
+    asm volatile("" : "+v"(r.xt), "+v"(r.wl1), "+v"(r.bs), "+v"(r.as));
+    float bound = __uint_as_float(radet_amax_reduce(r.xt)) * __uint_as_float(radet_amax_reduce(r.wl1));
+    bound += __uint_as_float(radet_amax_reduce(r.bs));           // (0 when the launch has no bias / addend)
+    bound += __uint_as_float(radet_amax_reduce(r.as));
     bound *= 1.0001f;                                            // (fp32 rounding of the accumulation and of this sum)
     const unsigned bits = __float_as_uint(bound);
     if (store && threadIdx.x == 0) radet_amax_store(P.yqs, bits);

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acc1[t][r] = 0.f; }
-    const H2Scale sdy = h2_scale(a.dys), sxx = h2_scale(a.xss);
+    const unsigned raw_dy = h2_scale_load(a.dys), raw_x = h2_scale_load(a.xss);   // reduced behind the first tiles' wait
     float bsum = 0.f;
     const bool want_bias = a.dbias_partials != nullptr && tc == 0;
     const int g16 = (lane >> 4) & 1, m16 = lane & 15;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     if (nIt > 0) issue_stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) { acc[i][j][t] = 0.f; acc1[i][j][t] = 0.f; }
-    const H2Scale sdy = h2_scale(a.dys), sxx = h2_scale(a.xss);
+    const unsigned raw_dy = h2_scale_load(a.dys), raw_x = h2_scale_load(a.xss);   // reduced behind the first tiles' wait
     float bsum = 0.f;
     const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
     const int g16 = (lane >> 4) & 1, m16 = lane & 15;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
     if (nIt > 0) issue_stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);

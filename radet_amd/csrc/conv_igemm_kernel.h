@@ -97,11 +97,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     epi.partial = pin_sgpr(a.partial); epi.counters = pin_sgpr(a.counters);
     epi.sk_base = pin_sgpr(a.sk_base); epi.sk_rem = pin_sgpr(a.sk_rem);
     epi.qs = 1.f; epi.qs2 = 2048.f;
-    if (P.yq) {                                                  // (uniform) pair copy of the output: its scale, from the bound
-        float qs, qs2;
-        igemm_pair_scale(P, id == 0 && (int)blockIdx.y == 0 && !SK, qs, qs2);
-        epi.qs = pin_sgpr(qs); epi.qs2 = pin_sgpr(qs2);
-    }
+    // amax slots (h2 arithmetic: the operands' scales; pair copy of the output: the terms of its bound): the gathers are issued
+    // HERE, in front of everything, and reduced behind the prologue's wait for the first tiles -- every launch starts on cold
+    // L2s, and a reduction in this place kept the tile loads of each workgroup waiting for the slot's round trip (1.5-2.5 us)
+    unsigned raw_xs = 0u, raw_ws = 0u;
+    if constexpr ((TAG & 64) != 0) { raw_xs = h2_scale_load(P.xs); raw_ws = h2_scale_load(P.ws); }
+    PairScaleRaw raw_q = {0u, 0u, 0u, 0u};
+    const bool pair_copy = P.yq != nullptr;                      // (uniform)
+    if (pair_copy) raw_q = igemm_pair_scale_load(P);
+    const bool pair_store = id == 0 && (int)blockIdx.y == 0 && !SK;
     // split episode of this workgroup: (number of splits, split-tile index, my split)
     const int nsplit = pin_sgpr(tail ? a.sk_tail : a.sk);
     const int ctile = pin_sgpr(tail ? tail_slot / a.sk_tail : sk_tile);
@@ -252,8 +256,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
     }
-    H2Scale sx = {1.f, 1.f, 1.f}, sw = {1.f, 1.f, 1.f};       // power-of-two scales of x and w (uniform: scalar loads)
-    if constexpr (H2) { sx = h2_scale(P.xs); sw = h2_scale(P.ws); }
+    H2Scale sx = {1.f, 1.f, 1.f}, sw = {1.f, 1.f, 1.f};       // power-of-two scales of x and w (set behind the prologue's wait)
 
     // vmcnt(LOADS) = "everything except the newest stage's loads has landed" (in-order return); only valid when every
     // wave owns exactly A_PW + B_PW loads per stage
@@ -269,6 +272,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    if constexpr (H2) { sx = h2_scale_finish(raw_xs); sw = h2_scale_finish(raw_ws); }
+    if (pair_copy) {                                             // pair copy of the output: its scale, from the bound
+        float qs, qs2;
+        igemm_pair_scale(P, raw_q, pair_store, qs, qs2);
+        epi.qs = pin_sgpr(qs); epi.qs2 = pin_sgpr(qs2);
+    }
 
     // reader side: tile rows wm*TM*32 + i*32 + li; (i*32) % (RPB*F4) == 0 so swz only depends on li.
     // The fragment reads are inline asm: the compiler would otherwise order every ds_read behind a vmcnt(0) wait on

@@ -367,9 +367,9 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
             for (int j = 0; j < TNA; ++j)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc1[i][j][t] = 0.f;
-        sdy = h2_scale(a.dys);
-        sxx = h2_scale(a.xss);
     }
+    unsigned raw_dy = 0u, raw_x = 0u;                          // slot gathers in front of the first tile loads, reduced behind them
+    if constexpr (H2) { raw_dy = h2_scale_load(a.dys); raw_x = h2_scale_load(a.xss); }
     float bsum = 0.f;
     const int kg = wave % KD, nh = wave / KD;
     const bool want_bias = a.dbias_partials != nullptr && tap == 0 && tc == 0;
@@ -379,6 +379,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + 4u * (unsigned)(lh * BN + wn * TN * 32 + li);
     if (nIt > 0) issue_stage(0, 0);
     __syncthreads();
+    if constexpr (H2) { sdy = h2_scale_finish(raw_dy); sxx = h2_scale_finish(raw_x); }
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);

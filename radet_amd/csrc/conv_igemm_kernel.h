@@ -141,9 +141,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     for (int k = 0; k < A_PW; ++k) {
         const int r = (wave + NW * k) * RPI + lrow;
         akq[k] = 4 * ((lane % F4) ^ ((r / RPB) % F4));
-        // (no table: a 1 x 1 / stride 1 conv, GEMM row m reads input row m -- one dependent global load less in the prologue)
-        arow[k] = (nK > 0 && wave + NW * k < A_INSTR)
-                      ? (a.rowtab ? a.rowtab[(size_t)ld_tap * a.Mp + m0 + r] : (m0 + r < a.M ? m0 + r : -1)) : -1;
+    }
+    {
+        // first gather rows: UNCONDITIONAL loads from clamped indices, selected afterwards -- with the load inside the
+        // condition every one of the A_PW loads sat behind its own branch and its own vmcnt(0): four dependent round trips
+        // at the head of every workgroup.  (no table: a 1 x 1 / stride 1 conv, GEMM row m reads input row m)
+        int araw[A_PW];
+        if (a.rowtab) {                                          // (uniform)
+            const int* const tab = a.rowtab + (size_t)(nK > 0 ? ld_tap : 0) * a.Mp;
+#pragma unroll
+            for (int k = 0; k < A_PW; ++k) {
+                const int m = m0 + (wave + NW * k) * RPI + lrow;
+                araw[k] = tab[m < a.Mp ? m : a.Mp - 1];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < A_PW; ++k) {
+                const int m = m0 + (wave + NW * k) * RPI + lrow;
+                araw[k] = m < a.M ? m : -1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < A_PW; ++k) arow[k] = (nK > 0 && (A_INSTR % NW == 0 || wave + NW * k < A_INSTR)) ? araw[k] : -1;
     }
 #pragma unroll
     for (int k = 0; k < B_PW; ++k) {

@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
         }
     }
     auto issue_stage = [&](int it, int buf) {                 // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
+        // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
+        // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
+        // (free), and the rows are plain registers afterwards.
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
         const int p0 = p_begin + it * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
@@ -456,6 +462,12 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
         }
     }
     auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
+        // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
+        // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
+        // (free), and the rows are plain registers afterwards.
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
         const int p0 = p_begin + it * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
@@ -617,6 +629,12 @@ __global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
         }
     }
     auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+        // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
+        // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
+        // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
+        // (free), and the rows are plain registers afterwards.
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
         const int p0 = p_begin + it * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {

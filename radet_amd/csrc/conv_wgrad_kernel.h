@@ -77,6 +77,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
         }
     }
     auto issue_stage = [&](int it, int buf) {                // order: x tiles (consume brow), dy tiles, next gather rows
+        // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
+        // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
+        // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
+        // (free), and the rows are plain registers afterwards.
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
         const int p0 = p_begin + it * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
@@ -317,6 +323,12 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
     // iteration were already drained by the barrier's vmcnt(0) and waits (vmcnt(0)) before their first use: placed first,
     // that wait is free; placed after a dy-tile load (the former order) it stalled every stage on its own prefetch.
     auto issue_stage = [&](int it, int buf) {
+        // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
+        // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
+        // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
+        // (free), and the rows are plain registers afterwards.
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
         const int p0 = p_begin + it * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {

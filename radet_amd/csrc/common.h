@@ -193,22 +193,15 @@ __device__ __forceinline__ float4 ld4_pairs(const _Float16* p, size_t row, int C
 // it every scale derived from it -- is the same in every run.  Why 64 words: the ~3000 waves of a launch's first round finish
 // together and each raises the slot once; on ONE address these device-scope atomics serialise (measured: a fixed +35 us per
 // launch on the 76 800-row layer1 convs; 64 words in two cache lines: still +10-16 us), spread by (workgroup, wave) over 64
-// words in 64 different 128-byte lines they do not (+0.5-3 us, tools/bench_h2.py).  A wave also looks before the
-// read-modify-write: the words only grow, and after the first arrivals almost every wave finds its maximum covered.
+// words in 64 different 128-byte lines they do not (+0.5-3 us, tools/bench_h2.py).  On ONE word a look before the
+// read-modify-write helped (the words only grow); on 64 lines it costs more than it saves -- the load is a round trip at the
+// tail of every wave, the atomic is fire-and-forget: 8.45 against 8.55 ms per step without the look.
 #ifndef RADET_AMAX_WORDS
 #define RADET_AMAX_WORDS 64
 #endif
 #ifndef RADET_AMAX_STRIDE
 #define RADET_AMAX_STRIDE 32           // distance between the words of a slot, in words: one 128-byte line per word (see above)
 #endif
-__device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {        // largest magnitude seen by this wave
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        unsigned* w = slot + ((blockIdx.x * 8u + (threadIdx.x >> 6)) & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE;
-        const unsigned bits = __float_as_uint(m);
-        if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(w, bits);
-    }
-}
 // the slot's value; call with all 64 lanes of the wave active (every lane loads one word).  Wave-uniform.
 // In two halves, so that a GEMM can put the (cold: every launch starts on invalidated L2s) load at its very top and the
 // reduction behind the wait for its first tiles: radet_amax_load issues the gather, radet_amax_reduce is four DPP maxima
@@ -227,5 +220,14 @@ __device__ __forceinline__ unsigned radet_amax_reduce(unsigned v) {
     return mx(mx(r0, r1), mx(r2, r3));
 }
 __device__ __forceinline__ unsigned radet_amax_read(const unsigned* slot) { return radet_amax_reduce(radet_amax_load(slot)); }
+// largest magnitude seen by this wave (m >= 0 in every lane, all 64 lanes active): the bit patterns of non-negative floats order
+// like the floats, so the wave maximum is the DPP reduction below on the bits
+__device__ __forceinline__ void radet_amax_publish(float m, unsigned* slot) {
+    const unsigned bits = radet_amax_reduce(__float_as_uint(m > 0.f ? m : 0.f));       // (NaN, -0: not published, as fmaxf would)
+    if ((threadIdx.x & 63) == 0 && bits != 0u) {
+        unsigned* w = slot + ((blockIdx.x * 8u + (threadIdx.x >> 6)) & (RADET_AMAX_WORDS - 1)) * RADET_AMAX_STRIDE;
+        atomicMax(w, bits);          // result unused: a fire-and-forget L2 atomic -- nothing at the wave's tail waits for it
+    }
+}
 // a producer that KNOWS the value (a bound computed before writing): word 0, the other words stay zero
 __device__ __forceinline__ void radet_amax_store(unsigned* slot, unsigned bits) { slot[0] = bits; }

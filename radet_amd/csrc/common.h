@@ -48,6 +48,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Touch every 64-byte line of the kernel-argument segment at once.  The compiler fetches by-value argument structs field by
+// field where they are first used, each fetch behind its own s_waitcnt: a chain of scalar-cache misses (the segment was just
+// written by the command processor) at the head of every workgroup.  One batch of independent s_load_dword + one wait turns
+// the chain into a single miss latency; the later field loads hit the scalar cache.  BYTES = sizeof(the argument struct).
+template <int BYTES>
+__device__ __forceinline__ void radet_kernarg_warm() {
+    typedef const char __attribute__((address_space(4))) * kptr_t;
+    const kptr_t kp = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int N = (BYTES + 63) / 64;
+    unsigned d[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("s_load_dword %0, %1, %2" : "=s"(d[i]) : "s"(kp), "n"(i * 64));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" ::"s"(d[i]));       // (the destination registers stay reserved until here)
+}
+
 // XCD-aware bijective remap of a 1-D grid: blocks that land on the same XCD (bid % 8) get a
 // contiguous chunk of tile ids, so neighbouring tiles share that XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

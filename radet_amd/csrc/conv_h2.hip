@@ -71,6 +71,7 @@ bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int ta
 // shared by TWO waves, taps 0-4 and 5-8 (160 / 128 accumulator registers).  Per 16-pixel stage: 8 KiB of dy + 18 KiB of x by
 // LDS-DMA, 15 / 12 MFMAs per wave between barriers.
 __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
     constexpr int CBA = BM / 16, CBB = BC / 16;
     constexpr int A_PL = BP * BM, B_PL = BP * BC;           // fp16 elements per dy plane tile / per (tap, plane) x tile
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
 // 8-pixel fragment and 24 VALU operations per fragment, this one 2 transposing reads and none.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 32, NW = 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int CBA = BM / 16, CBB = BN / 16;             // 16-channel sub-tile columns

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     __shared__ __attribute__((aligned(16))) float As[NSTG][NPL * BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs[NSTG][NPL * BN * BK];
 
+    radet_kernarg_warm<sizeof(ConvArgs)>();
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;

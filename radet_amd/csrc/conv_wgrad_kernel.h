@@ -34,6 +34,7 @@ struct WgradArgs {
 
 template <int NW, int MATH>   // MATH 1: bf16 operands (rounded from the fp32 tiles), fp32 accumulate
 __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 16, BM = 32 * NW, BC = 32, KT = 9, NT = NW * 64;
     constexpr int A_INSTR = BP * BM * 4 / 1024;             // wave instructions per dy tile (1 KiB each)
     constexpr int B_INSTR = KT * BP * BC * 4 / 1024;        // 18
@@ -634,6 +635,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
 
 template <int BM, int BN, int WM, int WN, int MATH, int BP = 16, int KD = 1>
 __global__ __launch_bounds__(256) void conv_wgradg_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
     wgradg_body<BM, BN, WM, WN, MATH, BP, KD>(a, blockIdx.x);
 }
 

@@ -27,6 +27,12 @@ elif "--retune-x3" in sys.argv:
     for cache in (K._TUNE_CACHE, K._WTUNE_CACHE):
         for key in [k for k in cache if k[-1] == "x3"]:
             del cache[key]
+elif "--retune-h2" in sys.argv:
+    # keep the shipped choices except the entries of the fp16 hi / lo arithmetic (their prologues changed): timed again
+    K.load_tune_cache()
+    for cache in (K._TUNE_CACHE, K._WTUNE_CACHE):
+        for key in [k for k in cache if "h2" in k]:
+            del cache[key]
 elif os.path.exists(K._PACKAGED_TUNE) and "--keep" not in sys.argv:
     K._TUNE_LOADED = True                                       # ignore the shipped file too
 out = [a for a in sys.argv[1:] if not a.startswith("--")][0]
@@ -39,7 +45,7 @@ JOBS = [  # depth, math, (B, H, W) list
     (101, "fp32-mfma", [(2, 800, 800)]),
     (101, "bf16-storage", [(2, 800, 800)]),
 ]
-if "--retune-x3" in sys.argv or "--fp32-only" in sys.argv:
+if "--retune-x3" in sys.argv or "--retune-h2" in sys.argv or "--fp32-only" in sys.argv:
     JOBS = [j for j in JOBS if j[1] == "fp32"]
 for depth, math, geos in JOBS:
     cfg = Config.fromfile(os.path.join(ROOT, "configs", "bop", "r50_ycbv_pbr.py"))

@@ -110,6 +110,19 @@ class LabelAssignment:
                  positive_num=10, neg_threshold=0.2, adapt_positive_num=False, balance_sample=False,
                  multiply_samplepro_for_weight=False, ambiguous_sample="min_area", random_sample_by_distance=True):
         assert len(strides) == len(regress_ranges)
+        if adapt_positive_num and anchor_generator_cfg is not None:
+            # the adapted positive_num reads the anchor side of a level (label_assignment.py:88-110: concat_anchor_boxes[:, 2] -
+            # [:, 0]); kernel and oracle compute it as 8 * stride -- the one anchor per location of every RADet config.  Any
+            # other generator would silently change K per gt: refuse it.
+            ag = dict(anchor_generator_cfg)
+            ok = (ag.get("octave_base_scale", 8) == 8 and ag.get("scales_per_octave", 1) == 1
+                  and [float(r) for r in ag.get("ratios", [1.0])] == [1.0]
+                  and tuple(ag.get("strides", strides)) == tuple(strides) and float(ag.get("center_offset", 0.0)) == 0.0
+                  and ag.get("scales") is None and ag.get("base_sizes") is None)
+            if not ok:
+                raise NotImplementedError("LabelAssignment(adapt_positive_num=True): the anchor side is 8 * stride here (ratios [1.0], "
+                                          "octave_base_scale 8, scales_per_octave 1, center_offset 0, strides as given); got "
+                                          f"anchor_generator_cfg={anchor_generator_cfg}")
         if ambiguous_sample != "min_area":
             # ('max_dis' does not run in the reference either: label_assignment.py:158-161 reads an undefined `is_candidate`)
             raise NotImplementedError("LabelAssignment: ambiguous_sample='min_area' is the only rule the reference can execute")
@@ -134,7 +147,8 @@ class LabelAssignment:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         B = len(gt_bboxes)
         rngs = list(rngs) if rngs is not None else [None] * B
-        if B > 1 and len({id(r) for r in rngs}) < B:
+        # (None, the np.random module and np.random.mtrand._rand are ONE generator: compare what they resolve to)
+        if B > 1 and len({id(np.random.mtrand._rand if (r is None or r is np.random) else r) for r in rngs}) < B:
             # several images share one RNG object (e.g. the global np.random, as in the reference's loader): image i
             # must start where image i-1 stopped in that stream, which is only known after i-1 has been assigned ->
             # one launch per image, in order.  Distinct RandomStates per image (the fast path below) need no ordering.
@@ -171,6 +185,9 @@ class LabelAssignment:
         gens = [np.random.mtrand._rand if (r is None or r is np.random) else r for r in rngs]
         states = [g.get_state() for g in gens]
         U = self.word_budget
+        # what a stream can need: two words per weighted draw incl. redraws, one or two per candidate of a shuffle -- a few
+        # words per (point, gt) at the very most; beyond that the stream cannot be satisfied and more words only cost memory
+        U_max = max(self.word_budget, min(1 << 22, 4 * N * max(max(counts, default=1), 1) + 64 * self.positive_num * max(tot, 1)))
         while True:
             words = np.empty((B, U), np.uint32)
             for i, g in enumerate(gens):
@@ -179,8 +196,8 @@ class LabelAssignment:
             K.assign_points(boxes_d, off_d, mk, H, W, torch.from_numpy(words.view(np.int32)).to(dev), U, ldesc, rr, nlvl, B,
                             self.positive_num, float(self.neg_threshold), p2g, pw, used, ws, flags=self.flags)
             used_h = used.cpu().numpy()
-            if (used_h == -1).any() and U < (1 << 24):     # stream exhausted (a shuffle of thousands of candidates): more words,
-                U *= 4                                     # same results -- the kernel is a function of the stream's prefix
+            if (used_h == -1).any() and U < U_max:         # stream exhausted (a shuffle of thousands of candidates): more words,
+                U = min(4 * U, U_max)                      # same results -- the kernel is a function of the stream's prefix
                 continue
             break
         for g, st in zip(gens, states):

@@ -177,6 +177,14 @@ def test_assigner_shared_rng_consumes_one_stream_in_order():
         rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), masks[i], (H, W, 3), rng=ref)
         assert np.array_equal(p2g[i].cpu().numpy(), rp), i
     assert shared.random_sample() == ref.random_sample()
+    # None, the np.random module and np.random.mtrand._rand are ONE generator, whatever mixture names it
+    np.random.seed(4242)
+    p2g, pw = la.assign_batch(boxes, masks, (H, W, 3), rngs=[None, np.random, np.random.mtrand._rand, None])
+    ref = np.random.RandomState(4242)
+    for i in range(B):
+        rp, rw = oa.assign_points(boxes[i], np.zeros(len(boxes[i]), np.int64), masks[i], (H, W, 3), rng=ref)
+        assert np.array_equal(p2g[i].cpu().numpy(), rp) and np.array_equal(pw[i].cpu().numpy(), rw), i
+    assert np.random.random_sample() == ref.random_sample()
     with pytest.raises(ValueError):
         la.assign_batch([np.zeros((300, 4), np.float32)], [np.zeros((300, 8, 8), np.uint8)], (8, 8, 3))
 

@@ -290,3 +290,17 @@ def test_generate_distance_map_crops_properties():
                 inside = 0 <= iy < min(479, y1 + py) and 0 <= ix < min(639, x1 + px)   # (the reference's clip to H-1 / W-1 is exclusive)
                 want = img[iy, ix] if inside else colours[k]
                 assert (crops[k][cy, cx] == want).all(), (k, cy, cx)
+
+
+def test_label_assignment_refuses_anchor_generators_it_does_not_model():
+    """adapt_positive_num reads the anchor side of a level (label_assignment.py:88-110); kernel and oracle use 8 * stride.
+    Any anchor_generator_cfg that would give another size must raise instead of silently changing K per gt."""
+    from radet_amd.datasets.pipelines import LabelAssignment
+    std = dict(type="AnchorGenerator", ratios=[1.0], octave_base_scale=8, scales_per_octave=1, strides=[8, 16, 32, 64, 128])
+    LabelAssignment(adapt_positive_num=True, anchor_generator_cfg=std)
+    LabelAssignment(adapt_positive_num=True)
+    for bad in (dict(std, ratios=[0.5, 1.0]), dict(std, octave_base_scale=4), dict(std, scales_per_octave=3),
+                dict(std, strides=[8, 16, 32, 64, 256]), dict(std, center_offset=0.5)):
+        with pytest.raises(NotImplementedError):
+            LabelAssignment(adapt_positive_num=True, anchor_generator_cfg=bad)
+        LabelAssignment(adapt_positive_num=False, anchor_generator_cfg=bad)      # unused without adapt_positive_num, as in the reference

@@ -251,6 +251,10 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
             tj = json.load(f)
         if tj.get("kernel", "").replace(" ", "") == dom_k.replace(" ", ""):
             traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
+        else:                                # (the same passes cover every kernel of the step: "all_kernels")
+            for k, v in tj.get("all_kernels", {}).items():
+                if k.replace(" ", "") == dom_k.replace(" ", ""):
+                    traffic, tnote = v, "average over this kernel's launches of one step (several conv shapes share the symbol)"
     roof["traffic"] = traffic
     roof["traffic_source"] = ("profiles/roofline_traffic.json (committed rocprofv3 PMC pass of this kernel: FETCH_SIZE / WRITE_SIZE in separate "
                               "runs, tools/pmc_traffic.py); NOT measured in this run") if traffic is not None else None
@@ -261,8 +265,8 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
     roof["note"] = ("`frac` is priced on the launch's duration IN the step, where launches on the engine's four streams share the "
                     "CUs (the tower weight gradients run next to the two dgrad chains by design: a workgroup of either owns a CU and "
                     "their tiles interleave), so a launch's duration covers other launches' work too; `alone` = the same launches "
-                    "one at a time.  The step runs at the socket power limit (1.36 kW, ~2.2 GHz: profiles/round3_clock_power.txt); "
-                    "`peak` is the 2.4 GHz figure.")
+                    "one at a time.  `peak` is the 2.4 GHz figure; `clock_power` has the clock the step sustains (the fp16 hi / lo "
+                    "arithmetic stays below the socket power limit, the bf16-triple scheme of rounds 2-4 ran at it).")
     mult_all = (3.0 if getattr(rt.engine, "h2", False) else 6.0) if x3 else 1.0
     peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
     if math in ("bf16", "bf16-storage"):

@@ -70,6 +70,10 @@ bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int ta
 // block (8 waves = 256 registers each), so a workgroup owns 128 output x 32 input channels and a 32-channel output group is
 // shared by TWO waves, taps 0-4 and 5-8 (160 / 128 accumulator registers).  Per 16-pixel stage: 8 KiB of dy + 18 KiB of x by
 // LDS-DMA, 15 / 12 MFMAs per wave between barriers.
+// SUB: 16-pixel sub-stages per pipeline stage (one wait + barrier per SUB x 16 pixels).  With one 8-wave workgroup per CU a
+// 16-pixel stage is 0.19 us of MFMA work per wave behind ~1 us of load latency + barrier; two sub-stages per barrier amortise
+// that (104 KiB of LDS: the workgroup owns the CU anyway).
+template <int SUB>
 __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     constexpr int N_INSTR = A_INSTR + B_INSTR;              // 26
     constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 4
     static_assert(B_PL * 2 == 1024, "one wave load per x tile");
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][2 * A_PL];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][KT * 2 * B_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * SUB][2 * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * SUB][KT * 2 * B_PL];
     const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
     const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
 
@@ -104,41 +108,47 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     const int p_begin = split * a.chunks_per_split * 16;
     int p_end = p_begin + a.chunks_per_split * 16;
     if (p_end > a.M) p_end = a.M;
-    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + SUB * BP - 1) / (SUB * BP) : 0;
 
     const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
     // x-tile load bi = tap * 2 + plane: the 8 sub-tiles [4 pixel quads][2 channel blocks] of that tap and plane
-    int brow[PER_WAVE];
-    bool bok[PER_WAVE];
+    int brow[SUB][PER_WAVE];
+    bool bok[SUB][PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < PER_WAVE; ++k) {
-        const int bi = wave + k * NW - A_INSTR;
-        brow[k] = -1;
-        bok[k] = false;
-        if (bi >= 0 && bi < B_INSTR) {
-            const int m = p_begin + 4 * (l_blk / CBB) + l_prow;
-            brow[k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
-            bok[k] = m < p_end;
+    for (int s = 0; s < SUB; ++s)
+#pragma unroll
+        for (int k = 0; k < PER_WAVE; ++k) {
+            const int bi = wave + k * NW - A_INSTR;
+            brow[s][k] = -1;
+            bok[s][k] = false;
+            if (bi >= 0 && bi < B_INSTR) {
+                const int m = p_begin + s * BP + 4 * (l_blk / CBB) + l_prow;
+                brow[s][k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[s][k] = m < p_end;
+            }
         }
-    }
     auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
         // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
         // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
         // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
         // (free), and the rows are plain registers afterwards.
 #pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[k]));
-        const int p0 = p_begin + it * BP;
+        for (int s = 0; s < SUB; ++s)
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[s][k]));
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+        const int p0 = p_begin + (it * SUB + s) * BP;
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
             const int ins = wave + k * NW;
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
                 const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
-                const void* src = (bok[k] && brow[k] >= 0)
-                                      ? (const void*)(xh + (size_t)brow[k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2))
+                const void* src = (bok[s][k] && brow[s][k] >= 0)
+                                      ? (const void*)(xh + (size_t)brow[s][k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2))
                                       : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * B_PL]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf * SUB + s][bi * B_PL]), 16, 0, 0);
             }
         }
 #pragma unroll
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
                 const void* src = (m < p_end && o < a.Cout)
                                       ? (const void*)(dyh + (size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl)
                                       : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf * SUB + s][ins * 512]), 16, 0, 0);
             }
         }
 #pragma unroll
@@ -159,10 +169,11 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
             const int ins = wave + k * NW;
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
-                const int m = p0 + BP + 4 * (l_blk / CBB) + l_prow;
-                brow[k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
-                bok[k] = m < p_end;
+                const int m = p0 + SUB * BP + 4 * (l_blk / CBB) + l_prow;
+                brow[s][k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                bok[s][k] = m < p_end;
             }
+        }
         }
     };
 
@@ -190,7 +201,9 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
         if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
-        const unsigned ab = a_thr + (unsigned)buf * (2 * A_PL * 2), bb = b_thr + (unsigned)buf * (KT * 2 * B_PL * 2);
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+        const unsigned ab = a_thr + (unsigned)(buf * SUB + s) * (2 * A_PL * 2), bb = b_thr + (unsigned)(buf * SUB + s) * (KT * 2 * B_PL * 2);
         s16x4v_ al[2], ah[2], bl[2][2], bh[2][2];
         static_for<0, 2>([&](auto pc) {
             constexpr int pl = decltype(pc)::value;
@@ -237,12 +250,13 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
         });
         if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
             const int cb = tid >> 4, cc = tid & 15;
-            const unsigned short* ap = &As[buf][0];
+            const unsigned short* ap = &As[buf * SUB + s][0];
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
                 const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
                 bsum += radet_pair_value(ap[e], ap[A_PL + e]);
             }
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -484,7 +498,9 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
         if ((a.ld_dy & 31) || (a.Cin & 31)) return RADET_ERR_ARG;
         if (a.KH == 3 && a.KW == 3 && !(flags & 0x40)) {               // all nine taps per workgroup
             const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
-            hipLaunchKernelGGL(conv_wgrad9q_kernel, dim3(tiles9), dim3(512), 0, st, a);
+            static const int sub = getenv("RADET_WGRAD9_SUB") ? atoi(getenv("RADET_WGRAD9_SUB")) : 2;
+            if (sub == 1) hipLaunchKernelGGL(conv_wgrad9q_kernel<1>, dim3(tiles9), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL(conv_wgrad9q_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);
             return radet_check_launch();
         }
         // one tap per workgroup (0x40, or not a 3 x 3): bits 4-5 = 1: 128 x 128 tile, otherwise 64 x 64

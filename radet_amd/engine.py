@@ -126,6 +126,9 @@ class Engine:
     TOWER_TAG = 0x100 | 0x200 | 3        # backward: 64 x 64 tile, K step 32
     TOWER_TAG_FWD = 0x100 | 0x200 | 2    # forward: 128 x 64 tile (2 accumulators per wave), K step 32
 
+    # plane-operand tower tiles with three LDS stages (144 KiB; experiment switch)
+    tower_stages = K.STAGES3 if os.environ.get("RADET_TOWER_STAGES3", "0") == "1" else 0
+
     def _ttile(self, c, bwd=False, tag=True, pair=True):
         """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step
         (the forward launches are grouped cls + reg pairs, which the single-conv timing of the autotuner does not
@@ -138,7 +141,7 @@ class Engine:
         if self.p3:
             # plane operands: 256 x 128 tiles, 8 waves (one workgroup per CU owns its LDS: 2 x 72 KiB of stages) for the
             # grouped cls + reg launches, 128 x 128 / 8 waves for a single tower GEMM (tools/bench_p3.py)
-            return (6 if pair else 5) | (0x100 if tag else 0)
+            return (6 if pair else 5) | (0x100 if tag else 0) | self.tower_stages
         if fp32 and self.x3:
             # products from bf16 planes: the operand split is VALU work per fragment, so the tile with the most MFMAs per
             # fragment wins -- 128 x 128 (4 accumulators per wave), 2 LDS stages, forward (178 vs 158 TFLOP/s fp32-equivalent
@@ -1002,7 +1005,7 @@ class Engine:
         b, p = self.buf, self.p
         c = tower[i]
         z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
-        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12))
+        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12) | self.tower_stages)
         gn = f"bbox_head.{t}_convs.{i}.gn"
         pl = K._isp(y)                  # the last layer's output feeds the predictor convs: fp32
         if self.h2:

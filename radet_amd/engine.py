@@ -128,6 +128,7 @@ class Engine:
 
     # plane-operand tower tiles with three LDS stages (144 KiB; experiment switch)
     tower_stages = K.STAGES3 if os.environ.get("RADET_TOWER_STAGES3", "0") == "1" else 0
+    tower_tile = int(os.environ.get("RADET_TOWER_TILE", "6"))       # 6: 256 x 128 (one workgroup per CU), 5: 128 x 128 (two)
 
     def _ttile(self, c, bwd=False, tag=True, pair=True):
         """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step
@@ -1005,7 +1006,7 @@ class Engine:
         b, p = self.buf, self.p
         c = tower[i]
         z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
-        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=6 | 0x100 | (1 << 12) | self.tower_stages)
+        self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=self.tower_tile | 0x100 | (1 << 12) | self.tower_stages)
         gn = f"bbox_head.{t}_convs.{i}.gn"
         pl = K._isp(y)                  # the last layer's output feeds the predictor convs: fp32
         if self.h2:
@@ -1239,7 +1240,7 @@ class Engine:
                 x = b[f"{t}.y{i - 1}"] if i > 0 else b["Pp"]
                 wg_done[(t, i)] = self._wgrad_async(tower[i].geom, b[f"{t}.dz{i & 1}"], x, tower[i].slabs, None)
                 if i > 0:
-                    K.conv_dgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], tower[i].wft, b[f"{t}.dy"], tile=6 | (1 << 12))
+                    K.conv_dgrad(tower[i].geom, b[f"{t}.dz{i & 1}"], tower[i].wft, b[f"{t}.dy"], tile=self.tower_tile | (1 << 12))
             self._tower_bwd_head_async("cls")
             self._fork(cs)
             with torch.cuda.stream(cs):
@@ -1249,10 +1250,10 @@ class Engine:
                 with torch.cuda.stream(cs):
                     layer("reg", self.reg_tower, self.gn_ws2, i)
             # both first layers write dL/dP: cls on this stream, then reg accumulates onto it on the chain stream
-            K.conv_dgrad(self.cls_tower[0].geom, b["cls.dz0"], self.cls_tower[0].wft, dP, tile=6 | (1 << 12))
+            K.conv_dgrad(self.cls_tower[0].geom, b["cls.dz0"], self.cls_tower[0].wft, dP, tile=self.tower_tile | (1 << 12))
             self._fork(cs)
             with torch.cuda.stream(cs):
-                K.conv_dgrad(self.reg_tower[0].geom, b["reg.dz0"], self.reg_tower[0].wft, dP, addend=dP, tile=6 | (1 << 12))
+                K.conv_dgrad(self.reg_tower[0].geom, b["reg.dz0"], self.reg_tower[0].wft, dP, addend=dP, tile=self.tower_tile | (1 << 12))
             self._join(cs)
         elif self.tower_mode in ("pair", "pairbwd"):
             p, g = self.p, self.g

@@ -253,7 +253,7 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
             traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
         else:                                # (the same passes cover every kernel of the step: "all_kernels")
             for k, v in tj.get("all_kernels", {}).items():
-                if k.replace(" ", "") == dom_k.replace(" ", ""):
+                if k.replace(" ", "") == dom_k.replace(" ", "") or k.replace(" ", "").startswith(dom_k.replace(" ", "") + "<"):
                     traffic, tnote = v, "average over this kernel's launches of one step (several conv shapes share the symbol)"
     roof["traffic"] = traffic
     roof["traffic_source"] = ("profiles/roofline_traffic.json (committed rocprofv3 PMC pass of this kernel: FETCH_SIZE / WRITE_SIZE in separate "

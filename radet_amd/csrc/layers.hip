@@ -1062,6 +1062,40 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
     }
 }
 
+// final per-channel reduce over chunks: dgamma[c], dbeta[c].  32 workgroups x (16 row groups x 16 columns) over the
+// [nchunks][2][256] partials, fixed summation order (8 workgroups x 4 row groups made a 100-step chain per thread on
+// the critical path of every tower layer's backward).
+// Runs as the LAST 32 workgroups of the apply launch (it only needs the stats pass's partials): as a launch of its own it sat
+// on the tower's backward chain between the GroupNorm and the next dgrad GEMM, 8 us + a kernel boundary per layer.
+__device__ __forceinline__ void gn_bwd_param_body(const float* __restrict__ cpart, int nchunks, float* __restrict__ dgamma,
+                                                  float* __restrict__ dbeta, int bx) {
+    const int lc = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int col = bx * 16 + lc;   // 0..511 = k*256 + c
+    float a = 0.f;
+    // same order of additions as a plain loop, with 8 loads in flight (a plain loop is one round trip per chunk row: 26
+    // dependent loads per thread on the tower's backward chain)
+    for (int k0 = rg; k0 < nchunks; k0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 16 * u;
+            v[u] = cpart[(size_t)(k < nchunks ? k : rg) * 512 + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 16 * u < nchunks) a += v[u];
+    }
+    __shared__ float red[16][16];
+    red[rg][lc] = a;
+    __syncthreads();
+    if (rg == 0) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][lc];
+        if (col < 256) dgamma[col] = v; else dbeta[col - 256] = v;
+    }
+}
+
 // backward pass 2: dz = rstd * (g*gamma - m1 - xhat*m2), m1/m2 = group means of g*gamma, g*gamma*xhat
 template <class T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z,
@@ -1070,8 +1104,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ gpart, T* __restrict__ dz,
                                                            __bf16* __restrict__ dzp, const RadetSegs segs, int B,
-                                                           int relu, const unsigned* dy_amax = nullptr,
-                                                           const unsigned* zhat_amax = nullptr, unsigned* dzq_amax = nullptr) {
+                                                           int relu, const unsigned* dy_amax, const unsigned* zhat_amax,
+                                                           unsigned* dzq_amax, const float* __restrict__ cpart, int nchunks,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    if ((int)blockIdx.x >= nchunks) {                            // (uniform) the parameter-gradient reduction: workgroups nchunks .. + 31
+        gn_bwd_param_body(cpart, nchunks, dgamma, dbeta, (int)blockIdx.x - nchunks);
+        return;
+    }
     const GnChunk c = gn_decode(segs, B, blockIdx.x);
     const int tid = threadIdx.x;
     __shared__ float m1s[32], m2s[32];
@@ -1154,38 +1193,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
-// final per-channel reduce over chunks: dgamma[c], dbeta[c].  32 workgroups x (16 row groups x 16 columns) over the
-// [nchunks][2][256] partials, fixed summation order (8 workgroups x 4 row groups made a 100-step chain per thread on
-// the critical path of every tower layer's backward).
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ cpart, int nchunks,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int lc = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int col = blockIdx.x * 16 + lc;   // 0..511 = k*256 + c
-    float a = 0.f;
-    // same order of additions as a plain loop, with 8 loads in flight (a plain loop is one round trip per chunk row: 26
-    // dependent loads per thread on the tower's backward chain)
-    for (int k0 = rg; k0 < nchunks; k0 += 16 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + 16 * u;
-            v[u] = cpart[(size_t)(k < nchunks ? k : rg) * 512 + col];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + 16 * u < nchunks) a += v[u];
-    }
-    __shared__ float red[16][16];
-    red[rg][lc] = a;
-    __syncthreads();
-    if (rg == 0) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += red[i][lc];
-        if (col < 256) dgamma[col] = v; else dbeta[col - 256] = v;
-    }
-}
-
 template <class T>
 static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const float* gamma,
                             const float* beta, T* dz, float* dgamma, float* dbeta, float* partial_ws, int B,
@@ -1207,9 +1214,8 @@ static int gn_relu_bwd_impl(const T* dy, const T* z, const float* stats, const f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, cpart,
                        segs, B, relu);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, dzp,
-                       segs, B, relu, dy_amax, zhat_amax, dzq_amax);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(32), dim3(256), 0, st, cpart, chunks, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3(chunks + 32), dim3(256), 0, st, dy, z, stats, gamma, beta, gpart, dz, dzp,
+                       segs, B, relu, dy_amax, zhat_amax, dzq_amax, cpart, chunks, dgamma, dbeta);
     return radet_check_launch();
 }
 

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         auto read_one = [&](auto bufc, auto sc, auto ppc, auto rc) {
             constexpr int BUF = decltype(bufc)::value, s = decltype(sc)::value, pp = decltype(ppc)::value, r = decltype(rc)::value;
             constexpr int AO = BUF * NPL * BM * BK * 4, BO = BUF * NPL * BN * BK * 4, RO = 32 * BK * 4;
-            constexpr int pl = r / (TM + TN), e = r % (TM + TN);
+            // (h2: the lo plane's reads go B first -- group 1 = hi lo' needs B lo, group 2 = lo hi' A lo: see the waits in slice())
+            constexpr int pl = r / (TM + TN), e = (H2 && pl == 1) ? (r % (TM + TN) + TM) % (TM + TN) : r % (TM + TN);
             // (the buffer offset goes into the address register: a ds_read immediate holds 16 bits)
             if constexpr (e < TM) lds_read128<pl * BM * BK * 4 + e * RO>(fa[pp][pl][e], aaddr[s] + (unsigned)AO);
             else lds_read128<pl * BN * BK * 4 + (e - TM) * RO>(fb[pp][pl][e - TM], baddr[s] + (unsigned)BO);
@@ -532,6 +533,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
                 constexpr int t = decltype(tc)::value;          // terms: hi hi, mid hi, hi mid, mid mid, lo hi, hi lo
                 constexpr int pa = H2 ? (t == 2 ? 1 : 0) : (t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0));      // (h2: hi hi, hi lo, lo hi)
                 constexpr int pb = H2 ? (t == 1 ? 1 : 0) : (t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0));
+                // (h2: the slice started with only the hi fragments waited for -- the lo fragments, read behind them, are due now;
+                // the reads issued behind group 0 may stay in flight)
+                // in order: [A hi, B hi | B lo | A lo] of this set, then the NRD / 2 reads issued behind each earlier group
+                if constexpr (H2 && t == 1) { if (do_read) lds_wait<TM + NRD / (NT - 1)>(); else lds_wait<TM>(); }
+                if constexpr (H2 && t == 2) { if (do_read) lds_wait<2 * (NRD / (NT - 1))>(); else lds_wait<0>(); }
                 if (!RADET_P3_DBG || !(a.dbg & 2)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -567,7 +573,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             static_for<0, NS>([&](auto sc) {
                 constexpr int s = decltype(sc)::value;
                 constexpr int PP = s & 1;                                      // parity of the global slice index (NS even)
-                lds_wait<0>();                                                 // fragment set PP has arrived
+                // fragment set PP has arrived -- h2: its hi fragments (read first); group 0 = hi hi' starts on them
+                if constexpr (H2 && s + 1 < NS) lds_wait<NRD / 2>(); else lds_wait<0>();
                 if constexpr (s + 1 < NS) {
                     slice(std::integral_constant<int, PP>{}, bufc, std::integral_constant<int, s + 1>{},
                           !RADET_P3_DBG || !(a.dbg & 4), std::false_type{}, 0, false);

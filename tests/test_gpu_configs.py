@@ -84,7 +84,7 @@ def test_headline_size_bs4_640x480_vs_oracle(math):
     """BASELINE configs[1] at its full size -- r50, 640 x 480, bs 4, the bench's own batch -- against the CPU oracle: loss
     triple within 1e-4 and every parameter's gradient TENSOR against the oracle's (tests/_grads.py: 3e-3 per parameter, median
     5e-4 -- a wiring error is of order 1); both fp32
-    arithmetics (products from bf16 planes = the default, native fp32 MFMA)."""
+    arithmetics (products from fp16 hi / lo pairs = the default, native fp32 MFMA)."""
     from oracle import model as om, synth
     from _grads import assert_grads_close
     from radet_amd.models import build_detector

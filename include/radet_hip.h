@@ -500,6 +500,33 @@ int radet_adamw_step(float* p, const float* g, float* m, float* v, size_t n, flo
                      float eps, float weight_decay, int step, float max_norm, float grad_div,
                      const float* partials, int npartials, float* grad_norm_out, void* stream);
 
+/* ---- launch tape (round 6): the host side of a steady-state train step as ONE call.  The reference drives its step from
+ *      Python, one autograd node and one cuDNN / ATen launch at a time (mmcv's EpochBasedRunner.train -> model.train_step ->
+ *      radet/models/detectors/base.py:218-253 -> optimizer hook); here a step is ~250 C-ABI calls on four HIP streams, and
+ *      issuing them from Python costs ~19 us each -- 4.5-4.9 ms of host time per step, which bounds the bf16-storage step and
+ *      would bound every step on a node whose ranks share the host.  A tape is a host array of RadetTapeOp recorded from one
+ *      eager step (radet_amd/tape.py): every entry point of this header that was called, with its argument values, and the
+ *      event record / wait operations between the streams.  radet_tape_replay issues ops [first, last) in order -- exactly the
+ *      calls the eager step made, so results are bit-identical -- without re-entering Python.  Arguments that change from step
+ *      to step (input / target pointers, learning rate, step number) are patched in the array by the owner before the call.
+ *      Not a hipGraph: the launches stay ordinary stream-ordered launches (graphs measured slower here), the
+ *      gradient exchange stays in Python between two replayed segments. */
+typedef struct RadetTapeOp {
+    int32_t kind;        /* 0: call thunk `fn` with args; 1: hipEventRecord(event, stream); 2: hipStreamWaitEvent(stream, event) */
+    int32_t fn;          /* kind 0: index returned by radet_tape_fn_index */
+    void* stream;        /* kind 1 / 2 (host handle: hipStream_t) */
+    void* event;         /* kind 1 / 2 (host handle: hipEvent_t) */
+    uint64_t args[32];   /* kind 0: one 64-bit word per argument in declaration order: pointers / size_t as is, int sign-extended,
+                            float as its bit pattern in the low 32 bits */
+} RadetTapeOp;
+int radet_tape_fn_index(const char* name);    /* index of an `int radet_*(...)` entry point of this header, -1 if unknown (host) */
+/* issues ops[first .. last); stops at the first op that fails: returns its code and stores its index in *failed (host, may be
+ * NULL); 0 when all were issued */
+int radet_tape_replay(const RadetTapeOp* ops, int first, int last, int* failed);
+/* stream-ordered helpers a taped step uses instead of torch's fill / copy (hipMemsetAsync / hipMemcpyAsync device to device) */
+int radet_fill_zero(void* dst, size_t nbytes, void* stream);
+int radet_copy_d2d(void* dst, const void* src, size_t nbytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

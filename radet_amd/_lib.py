@@ -37,6 +37,11 @@ class RadetWgradJob(C.Structure):
                 ("M", _i), ("Cin", _i), ("Cout", _i), ("ld_dy", _i), ("KH", _i), ("KW", _i), ("S", _i)]
 
 
+class RadetTapeOp(C.Structure):
+    """Mirror of `struct RadetTapeOp` (include/radet_hip.h, "launch tape")."""
+    _fields_ = [("kind", C.c_int32), ("fn", C.c_int32), ("stream", _p), ("event", _p), ("args", C.c_uint64 * 32)]
+
+
 # name -> (restype, argtypes); must list every function of include/radet_hip.h
 SIGNATURES = {
     "radet_gather_table_rows": (_i, [_i]),
@@ -132,6 +137,10 @@ SIGNATURES = {
     "radet_threshold_compact": (_i, [_p, _sz, _f, _p, _p, _p]),
     "radet_sqnorm_partials": (_i, [_p, _sz, _p, _i, _p]),
     "radet_adamw_step": (_i, [_p, _p, _p, _p, _sz, _f, _f, _f, _f, _f, _i, _f, _f, _p, _i, _p, _p]),
+    "radet_tape_fn_index": (_i, [C.c_char_p]),
+    "radet_tape_replay": (_i, [_p, _i, _i, _p]),
+    "radet_fill_zero": (_i, [_p, _sz, _p]),
+    "radet_copy_d2d": (_i, [_p, _p, _sz, _p]),
 }
 
 _lib = None
@@ -179,3 +188,8 @@ def call(name, *args):
     rc = fn(*args)
     if rc != 0:
         raise RadetHipError(f"{name} failed with code {rc} (-1 bad argument, -2 launch failure)")
+    if TAPE is not None:
+        TAPE.record_call(name, args)
+
+
+TAPE = None         # a radet_amd.tape.Tape while a step is being recorded (every call above is appended to it)

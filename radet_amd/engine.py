@@ -279,7 +279,8 @@ class Engine:
     max_plans = int(os.environ.get("RADET_MAX_PLANS", "4"))
     _PLAN_ATTRS = ("B", "H", "W", "stem_hw", "pool_hw", "buf", "plv", "R", "gn_ws", "gn_ws2", "ldesc", "nlvl", "loss_ws",
                    "losses", "dscales", "slab_arena", "bp_arena", "table", "_table_keepalive", "max_cout", "_pending_wgrad",
-                   "amax_act", "amax_aux", "_amax_keys", "amax_pfx", "_pfx_shapes", "_pfx_sets", "_pfx_active", "_pfx_ready")
+                   "amax_act", "amax_aux", "_amax_keys", "amax_pfx", "_pfx_shapes", "_pfx_sets", "_pfx_active", "_pfx_ready",
+                   "plan_id")
 
     def _snapshot(self):
         return dict(attrs={k: getattr(self, k) for k in self._PLAN_ATTRS},
@@ -318,6 +319,7 @@ class Engine:
             self._restore(self._plans.pop(key))
             return
         self.plans_built = getattr(self, "plans_built", 0) + 1
+        self.plan_id = self.plans_built           # identifies this plan's buffers (a launch tape recorded on them: runtime.py)
         dev = self.dev
         self.B, self.H, self.W = B, H, W
         h1, w1 = conv_out_hw(H, W, 7, 2, 3)
@@ -635,7 +637,7 @@ class Engine:
             with torch.cuda.stream(side):
                 K.fold_weights(tail, n - nf)
                 ev = self._event()
-                ev.record()
+                K.ev_record(ev)
             self._fold_event = ev
             if do_f:
                 K.fold_weights(self.table, nf)
@@ -646,7 +648,15 @@ class Engine:
         elif do_t:
             K.fold_weights(tail, n - nf)
         self._folded = (vf, vt)
+        self._last_fold = (do_f, do_t)          # (a launch tape may only be recorded from a step that folded the trainable part alone)
 
+    def _frozen_conv_count(self):
+        nf = 0
+        while nf < len(self.convs) and not self.convs[nf].trainable:
+            nf += 1
+        return nf
+
+    _last_fold = (None, None)
     _folded = (None, None)
     _param_epoch = 0
     _watched = None
@@ -679,7 +689,7 @@ class Engine:
 
     def _await_fold(self):
         if self._fold_event is not None:
-            torch.cuda.current_stream().wait_event(self._fold_event)
+            K.ev_wait(self._fold_event)
             self._fold_event = None
 
     def unfold(self):
@@ -727,7 +737,7 @@ class Engine:
         B, H, W = self.B, self.H, self.W
         b = self._pfx_sets[which]
         if self.h2:
-            self.amax_pfx[which].zero_()     # every producer of this pass raises its buffer's slot from zero
+            K.fill_zero(self.amax_pfx[which])     # every producer of this pass raises its buffer's slot from zero
         K.STAGE = "stem"
         K.stem(img, self.stem.wf, self.stem.bias_f, b["stem"], B, H, W)
         K.maxpool(b["stem"], b["pool"], B, self.stem_hw[0], self.stem_hw[1], 64, yq=b.get("pool@q"))
@@ -773,7 +783,7 @@ class Engine:
         with torch.cuda.stream(cs):
             self._prefix_forward(next_img, other)
             ev = self._event()
-            ev.record()
+            K.ev_record(ev)
         K.STAGE = stage
         self._pfx_ready = (self._img_key(next_img, self.geo_key), other, ev)
         return True
@@ -782,11 +792,11 @@ class Engine:
         b = self.buf
         self._img = img if self.stem.trainable else None      # (the stem's weight gradient reads the image again)
         if self.h2:
-            self.amax_act.zero_()            # every producer of this pass raises its buffer's slot from zero
+            K.fill_zero(self.amax_act)            # every producer of this pass raises its buffer's slot from zero
         nf = self._n_frozen_stages() if not self.stem.trainable else 0
         rdy, self._pfx_ready = self._pfx_ready, None
         if not self.stem.trainable and rdy is not None and rdy[0] == self._img_key(img, self.geo_key):
-            torch.cuda.current_stream().wait_event(rdy[2])    # prefetched during the previous step's backward pass
+            K.ev_wait(rdy[2])                                 # prefetched during the previous step's backward pass
             self._pfx_active = rdy[1]
             pb = self._pfx_sets[self._pfx_active]
         elif not self.stem.trainable:
@@ -898,13 +908,13 @@ class Engine:
     def _fork(self, side):
         """side stream waits for everything enqueued so far on the current stream"""
         ev = self._event()
-        ev.record()
-        side.wait_event(ev)
+        K.ev_record(ev)
+        K.ev_wait(ev, side)
 
     def _join(self, side):
         ev = self._event()
-        ev.record(side)
-        torch.cuda.current_stream().wait_event(ev)
+        K.ev_record(ev, side)
+        K.ev_wait(ev)
 
     # Backbone / neck weight gradients on fp16 plane pairs (round 5): dy and x are split into pairs ONCE per tensor by
     # radet_split_pairs on the weight-gradient stream (off the dgrad chain, into a scratch pair of that stream), and the GEMM
@@ -964,7 +974,7 @@ class Engine:
         with torch.cuda.stream(side):
             wg(geom, dy, x, slabs, dbias_partials)
             ev = self._event()
-            ev.record()
+            K.ev_record(ev)
         return ev   # completes when this weight-gradient GEMM has finished reading dy / x
 
     wgrad_streams = int(os.environ.get("RADET_WGRAD_STREAMS", "2"))
@@ -980,8 +990,8 @@ class Engine:
         """Side stream waits for the wgrads issued on the second wgrad stream (call on the way to a slab reduction)."""
         if self._side2_dirty:
             ev = self._event()
-            ev.record(self._side2_stream)
-            self._side().wait_event(ev)
+            K.ev_record(ev, self._side2_stream)
+            K.ev_wait(ev, self._side())
             self._side2_dirty = False
 
     def join_side(self):
@@ -1229,7 +1239,7 @@ class Engine:
                 gn = f"bbox_head.{t}_convs.{i}.gn"
                 ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
                 if ev is not None:
-                    torch.cuda.current_stream().wait_event(ev)
+                    K.ev_wait(ev)
                 if self.h2:
                     K.gn_relu_bwd_q(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
                                     p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], ws,
@@ -1272,7 +1282,7 @@ class Engine:
                     gn = f"bbox_head.{t}_convs.{i}.gn"
                     ev = wg_done.get((t, i + 2))          # dz[i & 1] was last read by the wgrad of layer i + 2
                     if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
+                        K.ev_wait(ev)
                     if self.p3 and self.h2:
                         K.gn_relu_bwd_q(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
                                         p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws,
@@ -1330,10 +1340,10 @@ class Engine:
         ts = [g[f"bbox_head.scales.{i}.scale"] for i in range(len(self.strides))]
         base = ts[0].data_ptr()
         if all(t.data_ptr() == base + 4 * i for i, t in enumerate(ts)):      # contiguous in the gradient arena: one copy
-            torch.as_strided(ts[0], (len(ts),), (1,)).copy_(self.dscales)
+            K.copy_d2d(torch.as_strided(ts[0], (len(ts),), (1,)), self.dscales)
             return
         for i, t in enumerate(ts):
-            t.copy_(self.dscales[i])
+            K.copy_d2d(t, self.dscales[i])
 
     def neck_backward(self, dP):
         K.STAGE = "neck"

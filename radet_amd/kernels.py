@@ -30,6 +30,38 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def ev_record(ev, stream=None):
+    """ev.record() on `stream` (a torch stream; None: the current one).  The engine's cross-stream dependencies go through
+    these two helpers so that a launch tape being recorded (radet_amd/tape.py) sees them."""
+    if stream is None:
+        ev.record()
+    else:
+        ev.record(stream)
+    t = _lib.TAPE
+    if t is not None:
+        t.record_event(ev, _stream() if stream is None else stream.cuda_stream)
+
+
+def ev_wait(ev, stream=None):
+    """`stream` (None: the current one) waits for event ev"""
+    (torch.cuda.current_stream() if stream is None else stream).wait_event(ev)
+    t = _lib.TAPE
+    if t is not None:
+        t.wait_event(ev, _stream() if stream is None else stream.cuda_stream)
+
+
+def fill_zero(t):
+    """stream-ordered zero fill of a contiguous device tensor (hipMemsetAsync; tape-able, unlike Tensor.zero_())"""
+    _lib.call("radet_fill_zero", _ptr(t), C.c_size_t(t.numel() * t.element_size()), _stream())
+
+
+def copy_d2d(dst, src):
+    """stream-ordered device-to-device copy between contiguous tensors of equal byte size"""
+    n = dst.numel() * dst.element_size()
+    assert n == src.numel() * src.element_size()
+    _lib.call("radet_copy_d2d", _ptr(dst), _ptr(src), C.c_size_t(n), _stream())
+
+
 class Levels:
     """Row-concatenated multi-level NHWC geometry: level l = B images of h_l x w_l pixels."""
 

@@ -412,10 +412,14 @@ class DetectorRuntime:
             with torch.cuda.stream(side):
                 K.unfold_grads(e.table[a * desc_bytes:], b - a, e.max_cout)
                 if bucket_hook is not None:
+                    if _lib.TAPE is not None:       # a replayed step hands the bucket over at the same point, on this stream
+                        _lib.TAPE.cut(lambda: bucket_hook(bucket), side)
                     bucket_hook(bucket)
         else:
             K.unfold_grads(e.table[a * desc_bytes:], b - a, e.max_cout)
             if bucket_hook is not None:
+                if _lib.TAPE is not None:
+                    _lib.TAPE.cut(lambda: bucket_hook(bucket), None)
                 bucket_hook(bucket)
 
     # ------------------------------------------------------------------ optimiser
@@ -438,6 +442,9 @@ class DetectorRuntime:
         K.adamw_step(self.flat.params, self.flat.grads, st["m"], st["v"], self.flat.n_train, st["lr"] if lr is None else lr,
                      st["betas"], st["eps"], st["wd"], self.step_count, st["max_norm"], grad_div, st["partials"],
                      st["grad_norm"])
+        if _lib.TAPE is not None:                 # the two arguments of radet_adamw_step that move from step to step
+            _lib.TAPE.mark("lr", 5)
+            _lib.TAPE.mark("step", 10)
         self.engine.params_changed()              # the kernel wrote the arena behind torch's back: fold again next step
 
     def bf16_buckets(self):
@@ -489,6 +496,32 @@ class DetectorRuntime:
         return rep
 
     # ------------------------------------------------------------------ data-parallel train step
+    # ------------------------------------------------------------------ launch tape (radet_amd/tape.py)
+    # RADET_TAPE=1 (default): once a train step has run `tape_after` times with the same geometry / mode, the next one is
+    # recorded (every C-ABI call and cross-stream event operation it issues) and the steps after that are REPLAYED by one C
+    # call per segment -- the same calls on the same streams, bit-identical results, ~5x less host time per step.
+    # RADET_TAPE=0: always the eager step.  A step falls back to eager (and drops the tape) whenever something the tape baked
+    # in has moved: another geometry plan, re-folded frozen weights, a changed optimizer hyper-parameter, tracing / per-kernel
+    # timing switched on, a prefetch hand-over (next_img).
+    tape_mode = os.environ.get("RADET_TAPE", "1")
+    tape_after = int(os.environ.get("RADET_TAPE_AFTER", "2"))
+
+    def _tape_key(self, img, tg, world, use_reducer):
+        e, st = self.engine, self.opt_state
+        return (e.geo_key, getattr(e, "plan_id", None), tuple(img.shape), img.dtype, tuple(tg["p2g"].shape), int(tg["off"].numel()),
+                world, use_reducer, self.loss_weights is None or self.loss_weights.data_ptr(),
+                st["betas"], st["eps"], st["wd"], st["max_norm"], st["m"].data_ptr(), e.wgrad_streams, e.use_streams,
+                tuple(sorted(self.loss_hparams.items())) if self.loss_hparams else None)
+
+    def drop_tape(self):
+        self._tape = None
+
+    _tape = None            # dict(key, count, tape, failed)
+
+    def tape_stats(self):
+        t = (self._tape or {}).get("tape")
+        return None if t is None else dict(t.stats(), replays=t.replays)
+
     def train_step(self, img, tg, lr=None, next_img=None):
         """One optimisation step. With torch.distributed initialised (backend nccl = RCCL) gradients
         are summed across ranks per bucket on a side stream while the backward of earlier layers is
@@ -496,46 +529,110 @@ class DetectorRuntime:
         next_img: the batch of the NEXT call, if it is already on the device (a data loader one batch ahead): the frozen part
         of its forward pass (stem + frozen stages, `frozen_stages` of resnet.py:572-588) is then computed during this step's
         backward pass and picked up by the next call when it is given the same tensor; results are bit-identical to calls
-        without it."""
+        without it.
+        Steady-state calls are replayed from a launch tape (see above); results are bit-identical to the eager step."""
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.reducer is not None and self.reducer.trace is not None:
-            self._ev_begin = torch.cuda.Event(enable_timing=True)
-            self._ev_begin.record()
-        self.forward(img)
-        self.loss(tg, grad_scale=self.loss_weights)
         # a 1-rank process group still exercises the bucketed exchange when forced (single-GPU test of the RCCL path)
         use_reducer = world > 1 or (world == 1 and dist.is_available() and dist.is_initialized()
                                     and os.environ.get("RADET_FORCE_REDUCER") == "1")
-        if use_reducer:
-            if self.reducer is None:
-                on_chain = self.engine.use_streams and self.flat.grads.is_cuda
-                if on_chain and not sync_collectives_run_on_current_stream():
-                    # the process group's internal stream will carry the exchange: keep the process at four streams by
-                    # giving up the second weight-gradient stream (10.43 instead of 9.97 ms at one rank, DESIGN.md 5)
-                    import warnings
-                    warnings.warn(f"torch {torch.__version__} runs synchronous collectives on the process group's own stream: "
-                                  "the gradient exchange uses that stream and the engine drops its second weight-gradient "
-                                  "stream to stay inside the four-stream budget of this device")
-                    on_chain = False
-                    self.engine.wgrad_streams = 1
-                self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets(),
-                                           comm_stream=self.engine._chain_stream() if on_chain else None)
-            tr = self.reducer.trace is not None
-            if tr:
-                ev0 = torch.cuda.Event(enable_timing=True)
-                ev0.record()                     # (after forward + loss: the exchange can only overlap the backward pass)
-            self.backward(self.reducer.bucket_ready, next_img=next_img)
-            if tr:
-                ev1 = torch.cuda.Event(enable_timing=True)
-                ev1.record()                     # end of the backward pass on the main stream
-                self.__dict__.setdefault("comm_marks", []).append((self._ev_begin, ev0, ev1, len(self.reducer.trace)))
-            self.reducer.finish()
-        else:
-            self.backward(next_img=next_img)
-        self.optimizer_step(lr=lr, grad_div=float(world))
+        e = self.engine
+        record = None
+        tapeable = (self.tape_mode != "0" and next_img is None and K.EVENTS is None and e.tower_events is None
+                    and not (self.reducer is not None and self.reducer.trace is not None) and e._pfx_ready is None
+                    and img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and self.opt_state is not None
+                    and all(tg[k].is_contiguous() for k in ("boxes", "labels", "off", "p2g", "pw")))
+        if tapeable:
+            key = self._tape_key(img, tg, world, use_reducer)
+            st = self._tape
+            if st is None or st["key"] != key:
+                st = self._tape = dict(key=key, count=0, tape=None, failed=None)
+            if st["tape"] is not None:
+                if self._tape_still_valid():
+                    return self._replay_step(st["tape"], img, tg, lr, world)
+                st = self._tape = dict(key=key, count=0, tape=None, failed=None)      # something moved: start over
+            st["count"] += 1
+            if st["count"] > self.tape_after and st["failed"] is None and (not use_reducer or self.reducer is not None):
+                from .tape import Tape
+                record = Tape()
+        if self.reducer is not None and self.reducer.trace is not None:
+            self._ev_begin = torch.cuda.Event(enable_timing=True)
+            self._ev_begin.record()
+        if record is not None:
+            torch.cuda.current_stream().synchronize()     # (recording compares allocator counters: nothing of ours in flight)
+            record.begin(self.dev)
+        try:
+            self.forward(img)
+            self.loss(tg, grad_scale=self.loss_weights)
+            if use_reducer:
+                if self.reducer is None:
+                    on_chain = self.engine.use_streams and self.flat.grads.is_cuda
+                    if on_chain and not sync_collectives_run_on_current_stream():
+                        # the process group's internal stream will carry the exchange: keep the process at four streams by
+                        # giving up the second weight-gradient stream (10.43 instead of 9.97 ms at one rank, DESIGN.md 5)
+                        import warnings
+                        warnings.warn(f"torch {torch.__version__} runs synchronous collectives on the process group's own stream: "
+                                      "the gradient exchange uses that stream and the engine drops its second weight-gradient "
+                                      "stream to stay inside the four-stream budget of this device")
+                        on_chain = False
+                        self.engine.wgrad_streams = 1
+                    self.reducer = GradReducer(self.flat.grads, self.dev, bf16=self.bf16_buckets(),
+                                               comm_stream=self.engine._chain_stream() if on_chain else None)
+                tr = self.reducer.trace is not None
+                if tr:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record()                     # (after forward + loss: the exchange can only overlap the backward pass)
+                self.backward(self.reducer.bucket_ready, next_img=next_img)
+                if tr:
+                    ev1 = torch.cuda.Event(enable_timing=True)
+                    ev1.record()                     # end of the backward pass on the main stream
+                    self.__dict__.setdefault("comm_marks", []).append((self._ev_begin, ev0, ev1, len(self.reducer.trace)))
+                if record is not None:
+                    record.cut(self.reducer.finish, None)
+                self.reducer.finish()
+            else:
+                self.backward(next_img=next_img)
+            self.optimizer_step(lr=lr, grad_div=float(world))
+        except BaseException:
+            if record is not None:
+                record.abort()
+            raise
+        if record is not None:
+            record.end()
+            st = self._tape
+            if record.poisoned is None and (e._last_fold != (False, True) or e._pfx_ready is not None):
+                record.poisoned = "the recorded step was not a steady-state step (frozen weights were folded in it)"
+            if record.poisoned is None:
+                record.bind("img", img)
+                for k in ("boxes", "labels", "off", "p2g", "pw"):
+                    record.bind(k, tg[k])
+                st["tape"] = record
+                st["nf"] = e._frozen_conv_count()
+            else:
+                st["failed"] = record.poisoned
+                if os.environ.get("RADET_TAPE_STRICT") == "1":
+                    raise _lib.RadetHipError(f"launch tape could not be recorded: {record.poisoned}")
         if self.loss_weights is not None:       # reported values carry the configured loss weights, like the reference's
             return self.engine.losses * self.loss_weights
         return self.engine.losses
+
+    def _tape_still_valid(self):
+        """what a recorded step baked in beyond its key: the frozen convs' folded weights (folded outside the tape whenever
+        their sources move) and the arenas the module's parameters view"""
+        e, st = self.engine, self._tape
+        nf = st["nf"]
+        if nf > 0 and e._part_version(0, nf) != e._folded[0]:
+            return False
+        return self.flat.still_bound() and _lib.TAPE is None
+
+    def _replay_step(self, tape, img, tg, lr, world):
+        e, st = self.engine, self.opt_state
+        self.step_count += 1
+        tape.replay(tensors=dict(img=img, boxes=tg["boxes"], labels=tg["labels"], off=tg["off"], p2g=tg["p2g"], pw=tg["pw"]),
+                    values=dict(lr=st["lr"] if lr is None else lr, step=self.step_count))
+        e.params_changed()
+        if self.loss_weights is not None:
+            return e.losses * self.loss_weights
+        return e.losses
 
 
 # ---------------------------------------------------------------------- autograd bridge (drop-in API)

@@ -147,6 +147,61 @@ def test_frozen_prefix_prefetch_is_bit_identical():
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16-storage"])
+def test_tape_replay_is_bit_identical(math):
+    """The launch tape (radet_amd/tape.py, include/radet_hip.h "launch tape"): eight train steps over two alternating batches
+    (other tensors, other gt counts: the tape's pointer words are patched) with a learning rate that changes every step, once
+    eager (RADET_TAPE=0) and once with the tape (two eager steps, one recorded, five replayed) -- losses of every step,
+    parameters, AdamW moments and the gradient arena are equal bit for bit.  Then what must drop the tape: a write to a frozen
+    parameter (the frozen convs are folded outside the tape) and another batch size."""
+    import os
+    import bench
+    from radet_amd.models import build_detector
+    from radet_amd.utils import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    batches = [bench.make_batch(r, 2, torch.device("cuda")) for r in range(2)]
+    outs = []
+    for mode in ("0", "1"):
+        cfg = Config.fromfile(os.path.join(root, "configs", "bop", "r50_ycbv_pbr.py"))
+        cfg.model["pretrained"] = None
+        torch.manual_seed(0)
+        det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
+        rt = det.runtime(math=math)
+        rt.tape_mode = mode
+        rt.init_optimizer()
+        rt.set_loss_from_head(det.bbox_head)
+        tgs = [rt.pack_targets([torch.from_numpy(x) for x in b[1]], [torch.from_numpy(x) for x in b[2]], list(b[3]), list(b[4]))
+               for b in batches]
+        losses = []
+        for i in range(8):
+            losses.append(rt.train_step(batches[i & 1][0], tgs[i & 1], lr=4e-4 * (1 + 0.1 * i)).clone())
+        torch.cuda.synchronize()
+        if mode == "1":
+            st = rt.tape_stats()
+            assert st is not None and st["replays"] == 5 and st["calls"] > 150 and st["segments"] == 1, (st, rt._tape["failed"])
+            assert st["bound"]["img"] >= 1 and st["bound"]["p2g"] >= 1 and st["bound"]["boxes"] >= 1, st
+        else:
+            assert rt.tape_stats() is None
+        outs.append((torch.stack(losses).cpu(), rt.flat.params.clone().cpu(), rt.opt_state["m"].clone().cpu(),
+                     rt.opt_state["v"].clone().cpu(), rt.flat.grads.clone().cpu()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    # (rt is the taped runtime) a frozen parameter moves: the tape is dropped, the step runs eager and re-folds the frozen part
+    tape = rt._tape["tape"]
+    with torch.no_grad():
+        det.backbone.conv1.weight.mul_(1.0)
+    rt.train_step(batches[0][0], tgs[0])
+    assert rt._tape["tape"] is None and rt._tape["count"] == 1
+    for _ in range(4):
+        rt.train_step(batches[0][0], tgs[0])
+    assert rt._tape["tape"] is not None and rt._tape["tape"] is not tape and rt._tape["tape"].replays == 2
+    # another batch size: another plan, its own tape later; the first plan's tape is not replayed on it
+    b4 = bench.make_batch(0, 4, torch.device("cuda"))
+    tg4 = rt.pack_targets([torch.from_numpy(x) for x in b4[1]], [torch.from_numpy(x) for x in b4[2]], list(b4[3]), list(b4[4]))
+    l4 = rt.train_step(b4[0], tg4).clone()
+    assert rt._tape["tape"] is None and torch.isfinite(l4).all()
+
+
 def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
     """The default fp32 arithmetic (fp16 hi / lo pairs, three products on the fp16 matrix cores), the same with the backbone
     forward on producer-written plane pairs (RADET_PAIRS=1), the former one (three bf16 planes, six products) and the native

@@ -35,6 +35,47 @@ def test_cabi_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.RadetScales) == 96                    # 12 device pointers
 
 
+def test_tape_thunks_are_current_and_replay_runs_host_calls():
+    """The launch tape's generated thunks (radet_amd/csrc/tape_thunks.c) match _lib.SIGNATURES; radet_tape_replay unpacks
+    the argument words of a recorded call correctly (checked on entry points that fail on bad arguments before they touch
+    the device: the failing op's index and code come back) and the recorder produces the words ctypes would pass."""
+    import subprocess
+    import sys
+    assert subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_tape_thunks.py"), "--check"]).returncode == 0
+    from radet_amd import _lib
+    from radet_amd.tape import Tape, _raw, _fbits
+    lib = _lib.load()
+    assert lib.radet_tape_fn_index(b"radet_adamw_step") >= 0 and lib.radet_tape_fn_index(b"radet_tape_replay") == -1
+    assert ctypes.sizeof(_lib.RadetTapeOp) == 8 + 16 + 32 * 8
+    arr = (ctypes.c_int * 3)(1, 2, 3)
+    sc = _lib.RadetScales()
+    assert _raw(None, ctypes.c_void_p)[0] == 0 and _raw(arr, ctypes.c_void_p)[0] == ctypes.addressof(arr)
+    assert _raw(ctypes.byref(sc), ctypes.c_void_p)[0] == ctypes.addressof(sc)
+    assert _raw(ctypes.c_size_t(7), ctypes.c_size_t)[0] == 7 and _raw(-3, ctypes.c_int)[0] == 2 ** 64 - 3
+    assert _raw(0.25, ctypes.c_float)[0] == _fbits(0.25) == 0x3E800000
+    ops = (_lib.RadetTapeOp * 3)()
+    ops[0].kind, ops[0].fn = 0, lib.radet_tape_fn_index(b"radet_fill_zero")        # (NULL, 0 bytes): a no-op that succeeds
+    ops[1].kind, ops[1].fn = 0, lib.radet_tape_fn_index(b"radet_copy_d2d")         # (NULL, NULL, 16 bytes): -1 before any HIP call
+    ops[1].args[2] = 16
+    ops[2].kind = 7                                                                 # unknown kind
+    failed = ctypes.c_int(-1)
+    assert lib.radet_tape_replay(ops, 0, 1, ctypes.byref(failed)) == 0 and failed.value == -1
+    assert lib.radet_tape_replay(ops, 0, 3, ctypes.byref(failed)) == -1 and failed.value == 1
+    assert lib.radet_tape_replay(ops, 2, 3, ctypes.byref(failed)) == -1 and failed.value == 2
+    assert lib.radet_tape_replay(None, 0, 0, None) == -1
+    t = Tape()
+    t._ops.append((0, ops[0].fn, None, None, [0, 0, 0]))
+    t._last_call = (0, _lib.SIGNATURES["radet_fill_zero"][1])
+    t.mark("n", 1)
+    t._alloc0, t.dev = 0, None
+    t._alloc_count = lambda dev: 0
+    _lib.TAPE = t
+    t.end()
+    assert _lib.TAPE is None and t.n == 1 and t.stats()["calls"] == 1
+    t.replay(values=dict(n=0))
+    assert t.replays == 1 and t.ops[0].args[1] == 0
+
+
 def test_host_only_entry_points():
     """Pure host arithmetic exported by the library (no device access)."""
     from radet_amd import _lib

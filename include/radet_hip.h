@@ -54,6 +54,8 @@ typedef struct RadetConvDesc {
     float* w_l1;           /* amax-style slot or NULL: largest L1 norm of a folded output channel, max_o sum |wf[o][.][.]| --
                               |conv output| <= amax(x) * it (+ |bias| + |addend|): the bound RadetScales.yq is scaled with */
     float* bias_amax;      /* amax-style slot or NULL: largest |bias_f| */
+    float* w_l1t;          /* amax-style slot or NULL (round 6): largest L1 norm of a folded INPUT channel, max_c sum_{o,t} |wf[o][t][c]|
+                              -- |dgrad output| <= amax(dy) * it: the bound a dgrad launch scales its pair output with */
 } RadetConvDesc;
 
 /* ---- amax slots (round 5, "fp16 hi / lo arithmetic").  The default fp32 conv arithmetic forms fp32-accurate products

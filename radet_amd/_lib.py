@@ -22,7 +22,8 @@ class RadetConvDesc(C.Structure):
                 ("wf", _p), ("wft", _p), ("bias_f", _p), ("dwf_slabs", _p), ("dbias_partials", _p),
                 ("dw", _p), ("dbias", _p), ("dgamma", _p), ("dbeta", _p),
                 ("cout", _i), ("cin", _i), ("kh", _i), ("kw", _i), ("nsplit", _i), ("eps", _f),
-                ("wft_ld", _i), ("wft_off", _i), ("w16", _i), ("w_amax", _p), ("wfq", _p), ("w_l1", _p), ("bias_amax", _p)]
+                ("wft_ld", _i), ("wft_off", _i), ("w16", _i), ("w_amax", _p), ("wfq", _p), ("w_l1", _p), ("bias_amax", _p),
+                ("w_l1t", _p)]
 
 
 class RadetScales(C.Structure):

@@ -67,6 +67,7 @@ struct ConvArgs {
     int cls_nt, cls_b[3];
     int dbg;              // experiments (RADET_DBG_IGEMM, plane-operand kernels): 1 no tile loads after the prologue, 2 no MFMAs,
                           // 4 no fragment reads after the first
+    int maskq;            // 1: `mask` is an fp16 plane-pair tensor (rows [2][Cout]: an activation that exists ONLY as pairs, round 6)
 };
 
 __device__ __forceinline__ float ld_act(const float* p, size_t o, int io) {
@@ -150,6 +151,7 @@ __device__ __forceinline__ void st_out_t(float* p, size_t o, float v) {
 struct EpiArgs {
     float qs, qs2;        // ConvPtrs::yq: 2^e, 2^(e + 11) of the output bound (igemm_pair_scale)
     int M, Cout, relu, io;
+    int maskq;            // ConvArgs::maskq
     const int* out_rows;
     float* partial;       // split-K / stream-K workspace (ConvArgs::partial, ::counters)
     int* counters;
@@ -204,8 +206,22 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
                 for (int r = 0; r < 16; ++r) av[r] = ld_act_t<IO>(P.addend, obase[r] + cc);
             }
             if (has_mask) {
+                if (IO == 0 && a.maskq) {
+                    // the mask tensor exists only as fp16 plane pairs (hi + 2^-11 lo of the scaled value): positive iff hi > 0,
+                    // or hi == 0 and lo > 0 (an element below fp16's range in BOTH halves is zero for its consumers as well)
+                    const unsigned short* mq = reinterpret_cast<const unsigned short*>(P.mask) + radet_pair_off(cc);
+                    unsigned short mh[16], ml[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mv[r] = ld_act_t<IO>(P.mask, obase[r] + cc);
+                    for (int r = 0; r < 16; ++r) { mh[r] = mq[2 * obase[r]]; ml[r] = mq[2 * obase[r] + 32]; }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned sel = (mh[r] & 0x7FFFu) ? mh[r] : ml[r];
+                        mv[r] = ((sel & 0x7FFFu) != 0u && (sel & 0x8000u) == 0u) ? 1.f : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mv[r] = ld_act_t<IO>(P.mask, obase[r] + cc);
+                }
             }
             float out[16];
 #pragma unroll
@@ -241,9 +257,12 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
                     }
                 }
             }
+            const bool has_y = P.y != nullptr;                  // (uniform; null: the output exists only as the pairs above)
             if (interior) {
+                if (has_y) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                    for (int r = 0; r < 16; ++r) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                }
                 if (P.ys) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(out[r]));
@@ -252,7 +271,7 @@ __device__ __forceinline__ void igemm_epilogue(const EpiArgs& a, const ConvPtrs&
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (cvalid && rvalid[r]) {
-                        st_out_t<IO>(P.y, obase[r] + cc, out[r]);
+                        if (has_y) st_out_t<IO>(P.y, obase[r] + cc, out[r]);
                         amax = fmaxf(amax, fabsf(out[r]));
                     }
             }

@@ -1053,6 +1053,12 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
     }
     a.KTw = kt_w > 0 ? kt_w : KH * KW;
     { static const int dbg = getenv("RADET_DBG_IGEMM") ? atoi(getenv("RADET_DBG_IGEMM")) : 0; a.dbg = dbg; }
+    // 0x10000000: `mask` is an fp16 plane-pair tensor (rows [2][Cout]) -- the ReLU mask of an activation that exists only as
+    // pairs (fp32 tensors only)
+    a.maskq = ((tile_override >> 28) & 1) && mask != nullptr;
+    if (a.maskq && (h16 || Cout % 32 != 0 || second != nullptr)) return RADET_ERR_ARG;
+    // y may be NULL when the output is wanted as plane pairs only (RadetScales.yq): the launch then stores no fp32 tensor
+    if (y == nullptr && (sc == nullptr || sc->yq == nullptr)) return RADET_ERR_ARG;
     a.p[0].x = x; a.p[0].w = w; a.p[0].bias = bias; a.p[0].addend = addend; a.p[0].mask = mask; a.p[0].y = y;
     a.p[0].xs = sc ? (const unsigned*)sc->x_amax : nullptr;
     a.p[0].ws = sc ? (const unsigned*)sc->w_amax : nullptr;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     P.y = pin_sgpr(P.y); P.bias = pin_sgpr(P.bias); P.addend = pin_sgpr(P.addend); P.mask = pin_sgpr(P.mask);
     EpiArgs epi;
     epi.M = pin_sgpr(a.M); epi.Cout = pin_sgpr(a.Cout); epi.relu = pin_sgpr(a.relu); epi.io = pin_sgpr(a.io);
-    epi.out_rows = pin_sgpr(a.out_rows);
+    epi.out_rows = pin_sgpr(a.out_rows); epi.maskq = pin_sgpr(a.maskq);
     epi.partial = pin_sgpr(a.partial); epi.counters = pin_sgpr(a.counters);
     epi.sk_base = pin_sgpr(a.sk_base); epi.sk_rem = pin_sgpr(a.sk_rem);
     epi.qs = 1.f; epi.qs2 = 2048.f;

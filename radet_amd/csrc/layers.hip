@@ -535,15 +535,38 @@ __global__ void fold_amax_zero_kernel(const RadetConvDesc* __restrict__ table, i
     if (d.w_amax) reinterpret_cast<unsigned*>(d.w_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
     if (d.w_l1) reinterpret_cast<unsigned*>(d.w_l1)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
     if (d.bias_amax) reinterpret_cast<unsigned*>(d.bias_amax)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
+    if (d.w_l1t) reinterpret_cast<unsigned*>(d.w_l1t)[threadIdx.x * RADET_AMAX_STRIDE] = 0u;
 }
 __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
     // (the other convs' w_amax slots are raised by fold_kernel itself).  w_l1 (optional): the largest L1 norm of a folded
     // output channel, max_o sum_{c,t} |wf[o][t][c]| -- |conv output| <= amax(x) * that: the bound an epilogue that writes
     // fp16 plane pairs scales them with (conv_common.h).  One workgroup sums a whole channel in a fixed order.
-    if (d.w_amax == nullptr || (d.w16 != 3 && !d.wfq && !d.w_l1)) return;
     const int K = d.cin * d.kh * d.kw;                         // OIHW: K contiguous weights per output channel
     __shared__ float red[4];
+    if (d.w_l1t) {
+        // largest L1 norm of an input channel, max_c sum_{o,t} |wf[o][t][c]|: bounds the dgrad's output (its GEMM sums over
+        // o and t).  One workgroup per channel, fixed order; the reads stride through the OIHW tensor (small: once per fold)
+        const int KT = d.kh * d.kw, n = d.cout * KT;
+        float l1t = 0.f;
+        for (int c = blockIdx.x; c < d.cin; c += gridDim.x) {
+            float sc_ = 0.f;
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int o = i / KT, t = i - o * KT;
+                float s = 1.f;
+                if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+                sc_ += fabsf(d.w[((size_t)o * d.cin + c) * KT + t] * s);
+            }
+            sc_ = wave_sum(sc_);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sc_;
+            __syncthreads();
+            l1t = fmaxf(l1t, (red[0] + red[1]) + (red[2] + red[3]));
+        }
+        __syncthreads();
+        radet_amax_publish(l1t, reinterpret_cast<unsigned*>(d.w_l1t));
+    }
+    if (d.w_amax == nullptr || (d.w16 != 3 && !d.wfq && !d.w_l1)) return;
     float m = 0.f, l1max = 0.f;
     for (int o = blockIdx.x; o < d.cout; o += gridDim.x) {
         float s = 1.f;

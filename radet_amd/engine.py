@@ -95,6 +95,17 @@ class Engine:
         # and the tests stay).  [A first measurement showed 8.73: the first pair stage was reading a copy nobody had written
         # -- zeros -- and the matrix cores clock higher on zeros.  Timings are only comparable on live data.]
         self.pairs = self.h2 and os.environ.get("RADET_PAIRS", "0") == "1"
+        # Pairs-ONLY tensors in the bottleneck blocks (round 6, default): a tensor that nothing but conv GEMMs and a ReLU mask
+        # read is written by its producer's epilogue as fp16 plane pairs and NOT as fp32 (the towers' activations have been
+        # stored that way since round 3) -- the same 4 bytes per element leave the CU, the consumers' K loops run without an
+        # operand split (25-40 % less time per launch alone, profiles/round5_bench_h2.txt), and unlike RADET_PAIRS=1 there is
+        # no second write.  In a stride-1 bottleneck block: o1 = relu(bn1(conv1 x)) is read by conv2 (forward and weight
+        # gradient) and as the mask of conv2's dgrad; d_o2 = dL/d(o2) is read by conv2's dgrad and weight gradient; conv2's
+        # folded weights exist as pairs in both orientations.  The residual path (block inputs / outputs, d_pre) stays fp32,
+        # and so do o2 / d_o1: their weight gradients pair them with an fp32 tensor (a mixed-operand kernel is the next step).
+        # Strided blocks (the first of stages 2-4) keep fp32 tensors: their dgrad runs as parity-class launches.
+        # RADET_PAIRS_ONLY=0: every tensor fp32, operands split in registers (the round-5 step).
+        self.po = self.h2 and not self.pairs and os.environ.get("RADET_PAIRS_ONLY", "1") != "0"
         self.pairs_from = int(os.environ.get("RADET_PAIRS_FROM", "2"))          # first ResNet stage (1-based) that reads pairs
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
@@ -199,7 +210,8 @@ class Engine:
                     c1=self._add(Conv(pfx + ".conv1", inpl, planes, 1, 1, 0, bn=pfx + ".bn1", trainable=train, dgrad=in_dgrad)),
                     c2=self._add(Conv(pfx + ".conv2", planes, planes, 3, stride, 1, bn=pfx + ".bn2", trainable=train, dgrad=train)),
                     c3=self._add(Conv(pfx + ".conv3", planes, planes * 4, 1, 1, 0, bn=pfx + ".bn3", trainable=train, dgrad=train)),
-                    ds=None, stride=stride, train=train)
+                    ds=None, stride=stride, train=train,
+                    po=self.po and stride == 1 and planes % 32 == 0)       # o1 / d_o2 exist only as plane pairs (see __init__)
                 if b == 0:
                     blk["ds"] = self._add(Conv(pfx + ".downsample.0", inpl, planes * 4, 1, stride, 0, bn=pfx + ".downsample.1",
                                                trainable=train, dgrad=in_dgrad))
@@ -239,16 +251,22 @@ class Engine:
         self.wft_arena = torch.zeros(n_wft, device=dev, dtype=self.act_dtype)
         # amax slots of the folded weights (fp16 hi / lo arithmetic): one per conv, written by radet_fold_weights
         self.w_amax = K.new_amax(dev, len(self.convs))
-        self.w_l1 = K.new_amax(dev, len(self.convs)) if self.pairs else None          # largest channel L1 norm / largest |bias_f|
-        self.b_amax = K.new_amax(dev, len(self.convs)) if self.pairs else None
+        self.w_l1 = K.new_amax(dev, len(self.convs)) if (self.pairs or self.po) else None   # largest channel L1 norm / largest |bias_f|
+        self.b_amax = K.new_amax(dev, len(self.convs)) if (self.pairs or self.po) else None
+        self.w_l1t = K.new_amax(dev, len(self.convs)) if self.po else None          # largest INPUT-channel L1 norm (dgrad bounds)
         self._w_amax_keys = []
         o_w = o_b = o_t = 0
         towers = (self.cls_tower + self.reg_tower) if self.p3 else []
+        po_c1 = [blk["c1"] for st in self.stages for blk in st if blk["po"]]
+        po_c2 = [blk["c2"] for st in self.stages for blk in st if blk["po"]]
+        po_c3 = [blk["c3"] for st in self.stages for blk in st if blk["po"] and blk["train"]]
+        towers = towers + po_c2                   # conv2 of a pairs-only block: folded weights as pairs in both orientations
         pkind = "h2" if self.h2 else "b3"
         for ci, c in enumerate(self.convs):
             c.w_amax = self.w_amax[ci]
             c.wfq = None
-            c.wmeta = (self.w_l1[ci], self.b_amax[ci] if (c.bn or c.bias) else None) if self.pairs else None
+            c.wmeta = (self.w_l1[ci], self.b_amax[ci] if (c.bn or c.bias) else None) if (self.pairs or c in po_c1) else None
+            c.wmeta_t = (self.w_l1t[ci], None) if c in po_c3 else None          # (dgrad launches that write pairs)
             c.w16 = (3 if self.h2 else 2) if c in towers else (1 if (self.h16 and c is not self.convs[0]) else 0)
             c.wf = self.wf_arena[o_w:o_w + c.wsize] if c is not self.convs[0] else self.stem_wf
             o_w += c.wsize
@@ -348,8 +366,21 @@ class Engine:
         self._pfx_active, self._pfx_ready = 0, None
         n_pfx = [0]
 
-        def new(name, rows, ch, dtype=None, prefix=False, twin=False):
-            """twin: a pair copy of the buffer (Planes "h2", written by the producer's epilogue) under name + '@q'"""
+        def new(name, rows, ch, dtype=None, prefix=False, twin=False, only=False):
+            """twin: a pair copy of the buffer (Planes "h2", written by the producer's epilogue) under name + '@q';
+            only: the buffer exists ONLY as plane pairs (self.po) -- buf[name] is the Planes, .true_amax the slot its producer raises"""
+            if only:
+                q = K.Planes(rows, ch, device=dev, kind="h2")
+                if prefix:
+                    assert n_pfx[0] < self.amax_pfx[0].shape[0], "frozen prefix: more buffers than amax slots"
+                    q.true_amax = self.amax_pfx[0][n_pfx[0]]
+                    n_pfx[0] += 1
+                    self._pfx_shapes[name] = (rows, ch, "pairs-only", False)
+                    self._pfx_sets[0][name] = q
+                else:
+                    q.true_amax = slot()
+                self.buf[name] = q
+                return q
             t = torch.empty(rows, ch, device=dev, dtype=dtype or self.act_dtype)
             self.buf[name] = t
             if prefix:
@@ -394,12 +425,12 @@ class Engine:
                     new(pfx + ".idt", lo.rows, blk["ds"].cout, prefix=fz)
                 blk["lout"] = lo
                 tw = li + 1 >= self.pairs_from                  # pair copies where a consumer reads them: inside the stages that
-                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz, twin=tw)            # run on pairs, and the block output
+                new(pfx + ".o1", lv.rows, blk["c1"].cout, prefix=fz, twin=tw, only=blk["po"])   # run on pairs, and the block output
                 new(pfx + ".o2", lo.rows, blk["c2"].cout, prefix=fz, twin=tw)            # that feeds the first of them
                 new(pfx + ".out", lo.rows, blk["c3"].cout, prefix=fz, twin=tw or (li + 2 == self.pairs_from and b == len(blocks) - 1))
                 if blk["train"]:
                     new(pfx + ".d_o1", lv.rows, blk["c1"].cout)
-                    new(pfx + ".d_o2", lo.rows, blk["c2"].cout)
+                    new(pfx + ".d_o2", lo.rows, blk["c2"].cout, only=blk["po"])
                     new(pfx + ".d_pre", lo.rows, blk["c3"].cout)
                 lv = lo
         # FPN on C3..C5
@@ -480,7 +511,7 @@ class Engine:
                 c.geom.h16 = self.h16
                 c.geom.x3 = self.x3
                 c.geom.h2 = self.h2
-                c.geom.pairs = c.wfq is not None
+                c.geom.pairs = c.wfq is not None or (self.po and c.w16 == 3 and c.name.startswith("backbone."))
         tune = os.environ.get("RADET_AUTOTUNE", "1") != "0"
         self._plan_wgrad_groups()
         if tune:
@@ -593,6 +624,10 @@ class Engine:
             if self.pairs and c is not self.convs[0]:
                 d.wfq = ptr(c.wfq)
                 d.w_l1, d.bias_amax = ptr(c.wmeta[0]), ptr(self.b_amax[self.convs.index(c)])
+            if self.po and c.wmeta is not None:
+                d.w_l1, d.bias_amax = ptr(c.wmeta[0]), ptr(self.b_amax[self.convs.index(c)])
+            if c.wmeta_t is not None:
+                d.w_l1t = ptr(c.wmeta_t[0])
             d.nsplit = c.geom.nsplit if c.geom is not None else 1
             if c.trainable and c.geom is not None:
                 d.dwf_slabs, d.dbias_partials = ptr(c.slabs), ptr(c.dbias_partials)
@@ -714,8 +749,12 @@ class Engine:
             K.conv_fwd(c3.geom, o2q, c3.wfq, c3.bias_f, out, addend=idt, relu=True, tile=c3.geom.fwd_tile_q, yq=outq,
                        wmeta=c3.wmeta)
             return out
-        K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
-        K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
+        if blk["po"]:       # o1 only as plane pairs (written by conv1's epilogue), conv2 without an operand split
+            K.conv_fwd(c1.geom, x, c1.wf, c1.bias_f, None, relu=True, yq=o1, wmeta=c1.wmeta)
+            K.conv_fwd(c2.geom, o1, c2.wf, c2.bias_f, o2, relu=True, tile=c2.geom.fwd_tile_q)
+        else:
+            K.conv_fwd(blk["c1"].geom, x, blk["c1"].wf, blk["c1"].bias_f, o1, relu=True)
+            K.conv_fwd(blk["c2"].geom, o1, blk["c2"].wf, blk["c2"].bias_f, o2, relu=True)
         if blk["ds"] is not None:
             idt = b[pfx + ".idt"]
             K.conv_fwd(blk["ds"].geom, x, blk["ds"].wf, blk["ds"].bias_f, idt)
@@ -769,6 +808,11 @@ class Engine:
             if self.h2:
                 self.amax_pfx[other] = K.new_amax(self.dev, 128)
             for i, (name, (rows, ch, dt, twin)) in enumerate(self._pfx_shapes.items()):
+                if dt == "pairs-only":
+                    q = K.Planes(rows, ch, device=self.dev, kind="h2")
+                    q.true_amax = self.amax_pfx[other][i]
+                    self._pfx_sets[other][name] = q
+                    continue
                 t = torch.empty(rows, ch, device=self.dev, dtype=dt)
                 self._pfx_sets[other][name] = t
                 if self.h2 and dt == torch.float32:
@@ -1413,7 +1457,11 @@ class Engine:
                 # ---- inside the block
                 c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
                 self._wgrad_async(c3.geom, d_pre, o2, c3.slabs, c3.dbias_partials, conv=c3)
-                K.conv_dgrad(c3.geom, d_pre, c3.wft, d_o2, mask=o2)
+                if blk["po"]:     # d_o2 only as plane pairs (conv3's dgrad epilogue writes them), o1 is one: conv2's weight
+                    #               gradient and dgrad run on pairs, the ReLU mask of d_o1 is read from o1's pairs
+                    K.conv_dgrad(c3.geom, d_pre, c3.wft, None, mask=o2, yq=d_o2, wmeta=c3.wmeta_t)
+                else:
+                    K.conv_dgrad(c3.geom, d_pre, c3.wft, d_o2, mask=o2)
                 self._wgrad_async(c2.geom, d_o2, o1, c2.slabs, c2.dbias_partials, conv=c2)
                 K.conv_dgrad(c2.geom, d_o2, c2.wft, d_o1, mask=o1)
                 self._wgrad_async(c1.geom, d_o1, blk["x"], c1.slabs, c1.dbias_partials, conv=c1)

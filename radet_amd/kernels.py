@@ -214,6 +214,7 @@ class ConvGeom:
         self.nsplit = _lib.load().radet_conv2d_wgrad_splits(self.lout.rows, cin, cout, k, k)
         self.pairs = False                    # forward launches read x as plane pairs written by its producer (fwd_tile_q)
         self.fwd_tile_q = 0
+        self.bwd_tile_q = 0                   # dgrad launches whose dy arrives as plane pairs (pairs-only gradients, round 6)
         self.wgrad_pair_flags = 0             # weight gradient on fp16 plane pairs: 0x40 one-tap kernel, bits 4-5 its tile (1: 128 x 128)
         self.nsplit_pairs = 0                 # its pixel splits (0: nsplit)
         self._ft = self._bt = self._classes = None
@@ -534,10 +535,28 @@ def autotune(g, need_dgrad=True, reps=None):
                 nk = g.k * g.k * g.cin // 32
                 if ntiles < 1024:
                     cq += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
-            _TUNE_CACHE[keyq] = (best_of(lambda t: conv_fwd(g, xq, wq, None, y, relu=True, tile=t), cq), 0)
+            ftq = best_of(lambda t: conv_fwd(g, xq, wq, None, y, relu=True, tile=t), cq)
+            btq = 0
+            if need_dgrad and g.stride == 1 and g.cout % 32 == 0:
+                # ... and dgrad launches whose dy arrives as pairs (with the ReLU mask read from a pair tensor)
+                dyq = Planes.from_float(torch.randn(g.lout.rows, g.cout, device=dev), kind="h2")
+                wtq = Planes.from_float(torch.randn(g.cin * g.k * g.k, g.cout, device=dev) * 0.05, kind="h2")
+                dx = torch.empty(g.lin.rows, g.cin, device=dev)
+                tmp_q = _tune_slots(g, dx)
+                cb = [1, 2, 3]
+                for t in list(cb):
+                    bm = 64 if (t & 0xFF) == 3 else 128
+                    bn = {1: 128, 2: 64, 3: 64}[t & 0xFF]
+                    ntiles = -(-g.lin.rows // bm) * -(-g.cin // bn)
+                    nk = g.k * g.k * g.cout // 32
+                    if ntiles < 1024:
+                        cb += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
+                btq = best_of(lambda t: conv_dgrad(g, dyq, wtq, dx, mask=xq, tile=t), cb)
+                unregister_amax(tmp_q)
+            _TUNE_CACHE[keyq] = (ftq, btq)
             if os.environ.get("RADET_TUNE_LOG"):
-                print(f"[tune igemm pairs] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={_TUNE_CACHE[keyq][0]:#x}")
-        g.fwd_tile_q = _TUNE_CACHE[keyq][0]
+                print(f"[tune igemm pairs] M={g.lout.rows} {g.cin}->{g.cout} k{g.k}s{g.stride}: fwd tile={ftq:#x} dgrad tile={btq:#x}")
+        g.fwd_tile_q, g.bwd_tile_q = _TUNE_CACHE[keyq]
 
 
 KW_DEEP = os.environ.get("RADET_KW_DEEP", "1") != "0"
@@ -573,6 +592,7 @@ STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output fr
 P3 = 0x2000000                            # x / w arrive as plane tensors (bf16 triples, or fp16 pairs with H2); fp32 outputs
 P3_BK8 = 0x4000000                        # ... with a K step of 16 instead of 32 channels
 H2 = 0x8000000                            # fp16 hi / lo arithmetic (with X3 or P3): 3 f16 MFMAs per K = 16 step, needs amax slots
+MASKQ = 0x10000000                        # the launch's ReLU mask tensor is an fp16 plane-pair tensor (round 6: pairs-only activations)
 
 
 # ---------------------------------------------------------------------- amax slots (fp16 hi / lo arithmetic, radet_hip.h)
@@ -668,6 +688,8 @@ def _scales(x, w, y, x1=None, w1=None, y1=None, need=True, yq=None, wmeta=None, 
     yq (Planes "h2"): the pair copy of the output, with wmeta = (w_l1 slot, bias amax slot or None) of the conv and the
     launch's addend (its slot bounds the residual term)."""
     sx, sw, sy = amax_slot(x, need), amax_slot(w, need), amax_slot(y)
+    if y is None and yq is not None:       # pairs-only output: the slot of its TRUE largest magnitude is still raised
+        sy = getattr(yq, "true_amax", None)
     sx1, sw1, sy1 = amax_slot(x1, need), amax_slot(w1, need), amax_slot(y1)
     if not need and sy is None and sy1 is None and yq is None:
         return None
@@ -763,6 +785,8 @@ def _tile(g, tile, default, x=None, y=None):
     """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
     t = (tile or default) | (MATH_BF16 if g.math else 0)
     if _isp(x):                                          # plane operands: 0x200 (the fp32 paths' K-step bit) has no meaning here
+        if (t & 0xFF) in (7, 8):                         # (the K-divided tiles split in registers: fp32 operands only)
+            t = (t & ~0xF0FF) | 3
         return (t & ~(MATH_BF16 | 0x200)) | P3 | (H2 if x.kind == "h2" else 0)
     if getattr(g, "x3", False) and not g.math and not _is16(x):
         t |= X3 | (H2 if getattr(g, "h2", False) else 0)
@@ -773,7 +797,9 @@ def _tile(g, tile, default, x=None, y=None):
 
 def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, splitk=True, yq=None, wmeta=None):
     """yq (Planes "h2", optional): y once more as fp16 plane pairs, scaled by the bound the launch can form before it starts
-    (include/radet_hip.h RadetScales.yq); wmeta = (w_l1 slot, bias amax slot) of the conv, from the fold"""
+    (include/radet_hip.h RadetScales.yq); wmeta = (w_l1 slot, bias amax slot) of the conv, from the fold.  y = None with a
+    yq: the output exists ONLY as pairs (round 6: tensors that nothing but conv GEMMs and ReLU masks read)"""
+    assert y is not None or yq is not None
     tile = _tile(g, tile, g.fwd_tile, x, y)
     ws = splitk_ws() if splitk else None
     table = g.fwd_table
@@ -902,13 +928,20 @@ def conv_dgrad_pair(g, a, b, tile=0):
                              t, _ptr(ws), C.c_size_t(ws.numel()), _stream(), sc), _conv_bytes(g, 2), kind="dgrad")
 
 
-def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False):
+def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, splitk=True, skip_zero_rows=False,
+               yq=None, wmeta=None):
     """dx[rows_in, cin] = dgrad(dy[rows_out, k_channels]); k_channels = (padded) channel count of dy/wft.
     skip_zero_rows: the caller accumulates in place (addend is dx) with a mask already applied to dx, so the
     input positions a strided conv never touches (3/4 of them for a 1x1 / 2) are left alone instead of being
-    rewritten by an epilogue-only launch."""
+    rewritten by an epilogue-only launch.
+    mask may be a Planes "h2" (the ReLU mask of an activation that exists only as pairs).  yq (Planes "h2") with wmeta =
+    (w_l1t slot, None): dx as fp16 plane pairs scaled by amax(dy) * the weights' largest input-channel L1 norm; dx = None:
+    only as pairs (stride-1 convs)."""
     kc = g.cout if k_channels is None else k_channels
-    tile = _tile(g, tile, g.bwd_tile, dy, dx)
+    tile = _tile(g, tile, (g.bwd_tile_q if _isp(dy) and getattr(g, "bwd_tile_q", 0) else g.bwd_tile), dy, dx)
+    if _isp(mask):
+        tile |= MASKQ
+    assert dx is not None or (yq is not None and g.stride == 1)
     ws = splitk_ws() if splitk else None
     if EVENTS is not None:
         # algorithmic work of the dgrad = that of the forward conv (a strided conv's dgrad touches each weight tap once
@@ -916,16 +949,18 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
         real_k = min(kc, g.cout)
         _timed(_igemm_key(tile, dy) + (" [strided dgrad, class launch]" if g.stride > 1 else ""),
                2.0 * g.lout.rows * real_k * g.cin * g.k * g.k,
-               lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows), _conv_bytes(g), kind="dgrad")
+               lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows, yq, wmeta),
+               _conv_bytes(g), kind="dgrad")
         return
-    _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows)
+    _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows, yq, wmeta)
 
 
-def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows):
+def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows, yq=None, wmeta=None):
     # (a K that cannot be split into planes -- the 16-channel padded gradient of the reg / iou predictors -- runs on the
     # native fp32 MFMA inside the launcher and needs no operand slots)
-    sc = _scales(dy, wft, dx, need=bool(tile & H2) and (_isp(dy) or kc % 32 == 0))
+    sc = _scales(dy, wft, dx, need=bool(tile & H2) and (_isp(dy) or kc % 32 == 0), yq=yq, wmeta=wmeta, addend=addend)
     if g.stride > 1 and STRIDED_DGRAD_CLASSES:
+        assert yq is None and not _isp(mask) and not _isp(dy), "strided dgrad: fp32 tensors only"
         grp = _strided_dgrad_group(g)
         if grp is not None:
             _lib.call("radet_conv2d_igemm_classes_s", _ptr(dy), _ptr(wft), _ptr(addend), _ptr(mask), _ptr(dx),
@@ -945,7 +980,7 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
                       (32 if _is16(dy) else 16) if c["zero"] else kc, g.cin,
                       ct, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
         return
-    _lib.call("radet_conv2d_igemm_s", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr(mask), _ptr(dx), _ptr(g.bwd_table),
+    _lib.call("radet_conv2d_igemm_s", _ptr_any(dy), _ptr_any(wft), None, _ptr(addend), _ptr_any(mask), _ptr(dx), _ptr(g.bwd_table),
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
 
 

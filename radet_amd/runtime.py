@@ -539,7 +539,8 @@ class DetectorRuntime:
         record = None
         tapeable = (self.tape_mode != "0" and next_img is None and K.EVENTS is None and e.tower_events is None
                     and not (self.reducer is not None and self.reducer.trace is not None) and e._pfx_ready is None
-                    and img.is_cuda and img.dtype == torch.float32 and img.is_contiguous() and self.opt_state is not None
+                    and img is not None and img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
+                    and self.opt_state is not None and "partials" in self.opt_state
                     and all(tg[k].is_contiguous() for k in ("boxes", "labels", "off", "p2g", "pw")))
         if tapeable:
             key = self._tape_key(img, tg, world, use_reducer)

@@ -1307,6 +1307,89 @@ def test_wgrad_one_tap_on_plane_pairs(K, case):
         assert rel_err(bp.sum(0), dy.double().sum((0, 2, 3))) < 2e-5, S
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 20, 24, 3, 3), (1, 128, 128, 17, 23, 3, 8), (2, 256, 64, 12, 16, 3, 0x2003), (2, 64, 128, 9, 11, 1, 7)])
+def test_pairs_only_tensors_of_a_bottleneck_block(K, case):
+    """Round 6 (Engine.po): a tensor that only conv GEMMs and a ReLU mask read exists ONLY as fp16 plane pairs.
+    (1) a forward launch with y = NULL writes nothing but the pairs (bound-scaled), raises the true-amax slot and the pairs
+    equal those of the launch that also writes fp32; (2) a dgrad launch reads its ReLU mask from a pair tensor: bit-identical
+    to the same launch with the fp32 mask; (3) a dgrad launch writes its output only as pairs, scaled by
+    amax(dy) * (largest input-channel L1 norm of the folded weights, from radet_fold_weights: RadetConvDesc.w_l1t): the slot
+    equals the host's column sums, the bound bounds, the pairs reproduce the fp32 dgrad to 2^-22; (4) a dgrad launch on pair
+    operands with a pair mask matches the fp64 chain like the fp32 path."""
+    import ctypes as C
+    from radet_amd import _lib
+    B, Ci, Co, H, W, k, tile = case
+    gen = torch.Generator().manual_seed(sum(case) + 3)
+    dev = "cuda"
+    pad = k // 2
+    x = torch.randn(B, Ci, H, W, generator=gen)
+    w = torch.randn(Co, Ci, k, k, generator=gen) / (Ci * k * k) ** 0.5
+    bias = torch.randn(Co, generator=gen)
+    geom = K.ConvGeom(K.Levels([(H, W)], B), Ci, Co, k, 1, pad)
+    geom.x3 = "h2"
+    R = B * H * W
+    xr, wf, br = to_rows(x).to(dev), fold_w(w).to(dev), bias.to(dev)
+    l1, ba = K.new_amax(dev), K.new_amax(dev)
+    l1[0] = int(torch.tensor(float(wf.abs().reshape(Co, -1).sum(1).max()), dtype=torch.float32).view(torch.int32))
+    K.absmax(torch.cat([br, torch.zeros((4 - Co % 4) % 4, device=dev)]), ba)
+    # (1) pairs-only forward output
+    y = torch.empty(R, Co, device=dev)
+    q_both, q_only = K.Planes(R, Co, device=dev, kind="h2"), K.Planes(R, Co, device=dev, kind="h2")
+    ys = K.new_amax(dev)
+    key = K.register_amax(y, ys)
+    K.conv_fwd(geom, xr, wf, br, y, relu=True, tile=tile, yq=q_both, wmeta=(l1, ba))
+    q_only.true_amax = K.new_amax(dev)
+    q_only.t.fill_(float("nan"))
+    K.conv_fwd(geom, xr, wf, br, None, relu=True, tile=tile, yq=q_only, wmeta=(l1, ba))
+    assert torch.equal(q_only.t.view(torch.int16), q_both.t.view(torch.int16))
+    assert K.amax_value(q_only.true_amax) == K.amax_value(ys) == float(y.abs().max())
+    assert K.amax_value(q_only.amax) == K.amax_value(q_both.amax)
+    K.unregister_amax([key])
+    # (2) ReLU mask from a pair tensor == fp32 mask (y is a ReLU output: zeros and positives)
+    dy = torch.randn(R, Co, generator=gen).to(dev)
+    act = torch.relu(torch.randn(R, Ci, generator=gen)).to(dev)
+    act[::7] = 0.0
+    act[3::11] *= 2.0 ** -30                                                   # tiny positives: still positive in the pairs
+    actq = K.Planes.from_float(act, kind="h2")
+    dx_a, dx_b = torch.empty(R, Ci, device=dev), torch.empty(R, Ci, device=dev)
+    wtf = wf.reshape(Co, k * k, Ci).permute(2, 1, 0).contiguous().reshape(-1)     # [Ci][tap][Co]: the dgrad's weight operand
+    K.conv_dgrad(geom, dy, wtf, dx_a, mask=act, tile=tile)
+    K.conv_dgrad(geom, dy, wtf, dx_b, mask=actq, tile=tile)
+    assert torch.equal(dx_a, dx_b)
+    assert bool(((dx_a != 0) <= (act > 0)).all())
+    # (3) dgrad output only as pairs, bound from the fold's input-channel L1 slot
+    d = _lib.RadetConvDesc()
+    wp = w.to(dev).contiguous()
+    wf2, wft2, bf2 = torch.empty(Co * k * k * Ci, device=dev), torch.empty(Ci * k * k * Co, device=dev), torch.empty(Co, device=dev)
+    wa, l1t = K.new_amax(dev), K.new_amax(dev)
+    d.w, d.wf, d.wft, d.bias_f = wp.data_ptr(), wf2.data_ptr(), wft2.data_ptr(), bf2.data_ptr()
+    d.cout, d.cin, d.kh, d.kw, d.nsplit, d.eps = Co, Ci, k, k, 1, 1e-5
+    d.w_amax, d.w_l1t = wa.data_ptr(), l1t.data_ptr()
+    table = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(dev)
+    K.fold_weights(table, 1)
+    want = float(w.abs().sum(dim=(0, 2, 3)).max())
+    assert abs(K.amax_value(l1t) - want) <= 1e-5 * want, (K.amax_value(l1t), want)
+    assert torch.equal(wft2, wtf)
+    kw = K.register_amax(wft2, wa)
+    dq = K.Planes(R, Ci, device=dev, kind="h2")
+    dq.true_amax = K.new_amax(dev)
+    K.conv_dgrad(geom, dy, wft2, None, mask=act, tile=tile, yq=dq, wmeta=(l1t, None))
+    K.conv_dgrad(geom, dy, wft2, dx_b, mask=act, tile=tile)
+    bound, amax = K.amax_value(dq.amax), float(dx_b.abs().max())
+    assert K.amax_value(dq.true_amax) == amax and amax <= bound <= 256 * amax, (amax, bound)
+    back = dq.to_float()
+    tol = dx_b.abs() * 2.0 ** -22 + bound * 2.0 ** -36
+    assert bool(((back - dx_b).abs() <= tol).all()), float(((back - dx_b).abs() / tol).max())
+    K.unregister_amax([kw])
+    # (4) dgrad on pair operands + pair mask against fp64
+    dyq = K.Planes.from_float(dy, kind="h2")
+    wtq = K.Planes.from_float(wft2.reshape(Ci * k * k, Co), kind="h2")
+    K.conv_dgrad(geom, dyq, wtq, dx_a, mask=actq, tile=(tile & 0xF000) | 3)
+    ref = torch.nn.grad.conv2d_input((B, Ci, H, W), w.double(), from_rows(dy.cpu(), B, H, W).double(), stride=1, padding=pad)
+    ref = ref * (from_rows(act.cpu(), B, H, W) > 0)
+    assert rel_err(from_rows(dx_a, B, H, W), ref) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 20, 24, 1, 1, 3), (2, 256, 128, 18, 22, 3, 2, 2), (1, 128, 256, 17, 23, 3, 1, 1),
                                   (2, 512, 128, 15, 20, 1, 1, 0x3003), (1, 64, 256, 9, 11, 1, 1, 7), (2, 128, 128, 12, 16, 3, 1, 8)])
 def test_conv_epilogue_writes_plane_pair_copy(K, case):

@@ -151,7 +151,7 @@ def test_frozen_prefix_prefetch_is_bit_identical():
 def test_tape_replay_is_bit_identical(math):
     """The launch tape (radet_amd/tape.py, include/radet_hip.h "launch tape"): eight train steps over two alternating batches
     (other tensors, other gt counts: the tape's pointer words are patched) with a learning rate that changes every step, once
-    eager (RADET_TAPE=0) and once with the tape (two eager steps, one recorded, five replayed) -- losses of every step,
+    eager (RADET_TAPE=0) and once with the tape (three eager steps -- the first one builds the geometry plan --, one recorded, four replayed) -- losses of every step,
     parameters, AdamW moments and the gradient arena are equal bit for bit.  Then what must drop the tape: a write to a frozen
     parameter (the frozen convs are folded outside the tape) and another batch size."""
     import os
@@ -178,7 +178,7 @@ def test_tape_replay_is_bit_identical(math):
         torch.cuda.synchronize()
         if mode == "1":
             st = rt.tape_stats()
-            assert st is not None and st["replays"] == 5 and st["calls"] > 150 and st["segments"] == 1, (st, rt._tape["failed"])
+            assert st is not None and st["replays"] == 4 and st["calls"] > 150 and st["segments"] == 1, (st, rt._tape["failed"])
             assert st["bound"]["img"] >= 1 and st["bound"]["p2g"] >= 1 and st["bound"]["boxes"] >= 1, st
         else:
             assert rt.tape_stats() is None

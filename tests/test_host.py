@@ -31,7 +31,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/radet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
     _lib.load()
-    assert ctypes.sizeof(_lib.RadetConvDesc) == 192                 # 15 pointers + 9 32-bit fields (padded to 8) + 4 pointers
+    assert ctypes.sizeof(_lib.RadetConvDesc) == 200                 # 15 pointers + 9 32-bit fields (padded to 8) + 5 pointers
     assert ctypes.sizeof(_lib.RadetScales) == 96                    # 12 device pointers
 
 

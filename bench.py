@@ -121,6 +121,52 @@ def make_batch(rank, B, device):
     return img, boxes, labels, p2g, pw
 
 
+def pin_rank_to_cores(local_rank, world):
+    """Bind this process to the local_rank-th of `world` equal shares of the cores it is allowed to run on (physical
+    neighbours: consecutive ids).  Returns the sorted core list, or None when there is nothing to divide / it is switched off."""
+    if os.environ.get("RADET_BENCH_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        per = len(allowed) // world
+        if per < 1:
+            return None
+        mine = allowed[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
+class CommGuard:
+    """Watchdog around the start-up collectives of a multi-GPU run: if the armed phase does not finish within `limit`
+    seconds the process prints one line saying which phase of which rank hung and exits with code 4 (a blocked RCCL call
+    cannot be interrupted from Python)."""
+
+    def __init__(self, rank, limit):
+        self.rank, self.limit, self.what, self._t = rank, limit, "", None
+
+    def arm(self, what):
+        import threading
+        self.disarm()
+        self.what = what
+
+        def fire():
+            msg = f"rank {self.rank}: {what} did not complete within {self.limit:.0f} s"
+            print(json.dumps({"error": msg}), flush=True)
+            sys.stderr.write("bench.py: " + msg + "\n")
+            sys.stderr.flush()
+            os._exit(4)
+        self._t = threading.Timer(self.limit, fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def disarm(self):
+        if self._t is not None:
+            self._t.cancel()
+            self._t = None
+
+
 def effective_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota, at most 32."""
     try:
@@ -195,7 +241,9 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
     fp32-equivalent rate is next to it."""
     fam = {}
     for ev in events:
-        f = fam.setdefault(ev["key"], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, evs=[]))
+        # one row per kernel SYMBOL, as rocprofv3 counts them (a strided dgrad's class launch carries a suffix in its key:
+        # the same symbol -- round 5's record had 55 launches of the dominant symbol here against 58 under the profiler)
+        f = fam.setdefault(ev["key"].split(" [")[0], dict(n=0, ms=0.0, flops=0.0, bytes=0.0, evs=[]))
         d = ev["start"].elapsed_time(ev["end"])
         f["n"] += 1; f["ms"] += d; f["flops"] += ev["flops"]; f["bytes"] += ev["bytes"]; f["evs"].append(ev)
     tot_ms = sum(f["ms"] for f in fam.values())
@@ -245,18 +293,28 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
     dom_k, dom = order[0]
     roof = entry(dom_k, dom, alone=True)
     traffic, tnote = None, None             # HBM bytes / launch from the committed PMC passes, if they cover this kernel
-    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    tname = "roofline_traffic_bf16_storage.json" if math == "bf16-storage" else "roofline_traffic.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
+    tj = {}
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("kernel", "").replace(" ", "") == dom_k.replace(" ", ""):
-            traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
-        else:                                # (the same passes cover every kernel of the step: "all_kernels")
-            for k, v in tj.get("all_kernels", {}).items():
-                if k.replace(" ", "") == dom_k.replace(" ", "") or k.replace(" ", "").startswith(dom_k.replace(" ", "") + "<"):
-                    traffic, tnote = v, "average over this kernel's launches of one step (several conv shapes share the symbol)"
+
+    def pmc_traffic(k):                      # (the same PMC passes cover every kernel of the step: "all_kernels")
+        kk = k.split(" (")[0].replace(" ", "")
+        for name, v in tj.get("all_kernels", {}).items():
+            nn = name.replace(" ", "")
+            if nn == kk or nn.startswith(kk + "<") or (kk.endswith(">") and nn.startswith(kk)):
+                return v
+        return None
+    if tj.get("kernel", "").replace(" ", "") == dom_k.replace(" ", ""):
+        traffic, tnote = tj.get("traffic_bytes_per_launch"), tj.get("note")
+    elif pmc_traffic(dom_k) is not None:
+        traffic, tnote = pmc_traffic(dom_k), "average over this kernel's launches of one step (several conv shapes share the symbol)"
     roof["traffic"] = traffic
-    roof["traffic_source"] = ("profiles/roofline_traffic.json (committed rocprofv3 PMC pass of this kernel: FETCH_SIZE / WRITE_SIZE in separate "
+    if traffic and roof.get("algorithmic_bytes_per_launch"):
+        roof["traffic_over_algorithmic"] = round(traffic / roof["algorithmic_bytes_per_launch"], 2)
+    roof["traffic_source"] = (f"profiles/{tname} (committed rocprofv3 PMC pass of this kernel: FETCH_SIZE / WRITE_SIZE in separate "
                               "runs, tools/pmc_traffic.py); NOT measured in this run") if traffic is not None else None
     if tnote:
         roof["traffic_note"] = tnote
@@ -267,6 +325,10 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
                     "their tiles interleave), so a launch's duration covers other launches' work too; `alone` = the same launches "
                     "one at a time.  `peak` is the 2.4 GHz figure; `clock_power` has the clock the step sustains (the fp16 hi / lo "
                     "arithmetic stays below the socket power limit, the bf16-triple scheme of rounds 2-4 ran at it).")
+    def with_traffic(e, t):                 # HBM / fabric bytes per launch from the committed PMC passes (profiles/<tname>), if covered
+        e["traffic"] = t
+        e["traffic_over_algorithmic"] = round(t / e["algorithmic_bytes_per_launch"], 2) if t and e["algorithmic_bytes_per_launch"] else None
+        return e
     mult_all = (3.0 if getattr(rt.engine, "h2", False) else 6.0) if x3 else 1.0
     peak_all = BF16_MFMA_PEAK_TFLOPS if x3 else FP32_MFMA_PEAK_TFLOPS
     if math in ("bf16", "bf16-storage"):
@@ -281,7 +343,7 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
                               "achieved": round(value * TRAIN_FLOP_PER_IMG / 1e12 * mult_all, 2),
                               "frac": round(value * TRAIN_FLOP_PER_IMG / 1e12 * mult_all / peak_all, 4),
                               "note": "images/s x 341.1 GFLOP/img (SURVEY 8d) over the wall time of the step: streams overlap, so this is above the summed-kernel-time figure"},
-               "kernels": [entry(k, f) for k, f in order[:8]]},
+               "kernels": [with_traffic(entry(k, f), pmc_traffic(k)) for k, f in order[:10]]},
            "kernel_events": {"ms_per_step_with_events": round(dt_ev / steps * 1e3, 3), "ms_per_step": round(ms_clean, 3),
                              "conv_launches_per_step": round(len(events) / steps, 1)}}
     rep["stages"] = stage_table(events, steps, mult_all, peak_all)
@@ -391,7 +453,8 @@ def extras(args):
         d = _child([os.path.abspath(__file__), "--weights", "synth", "--steps", str(args.steps), "--warmup", str(args.warmup),
                     "--no-cpu-baseline", "--no-kernel-events", "--no-mfma-line", "--no-extras"])
         out["synthetic_trained_like_weights"] = {
-            "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"],
+            "value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"], "clock_power": d.get("clock_power"),
+            "losses_step1": d["config"]["losses_step1"],
             "note": "same step, `python bench.py --weights synth`: seeded trained-like parameters / running statistics "
                     "(radet_amd/utils/synth_init.py) -> dense, decorrelated activations; the plane arithmetic runs against "
                     "the power envelope, so its speed depends on the operands' bit activity (DESIGN.md 6)"}
@@ -436,10 +499,11 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-        for ln in r.stdout.splitlines():
-            if ln.startswith("{"):
-                print(ln, flush=True)
-        sys.exit(r.returncode)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        results = [ln for ln in lines if '"metric"' in ln]
+        for ln in (results or lines[:1]):               # rank 0's result line, else the first rank's one-line reason
+            print(ln, flush=True)
+        sys.exit(r.returncode if (r.returncode or results) else 5)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -450,16 +514,42 @@ def main():
     backend = os.environ.get("RADET_BENCH_BACKEND", "nccl")
     if share:
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    # Host cores: each rank of a multi-GPU run binds itself to its own share of the cores this job may use, BEFORE the first GPU
+    # call (os.sched_setaffinity on the running process: no taskset, no re-exec) -- eight ranks' Python loops and HIP runtime
+    # threads on one shared pool migrate and preempt each other; with the launch tape a rank needs ~3 ms of one core per step.
+    # RADET_BENCH_AFFINITY=0 leaves the scheduler alone.
+    cpus = pin_rank_to_cores(local_rank if not share else rank, world) if world > 1 else None
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or os.environ.get("RADET_FORCE_REDUCER") == "1":   # the latter: 1-rank RCCL run of the bucketed exchange
         os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")      # per-collective durations for the `comm` report
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        # a rank whose process group does not come up, or whose first collective does not complete, ends the job with ONE line
+        # and a non-zero exit code instead of hanging until the caller's timeout (the first N = 8 run is the driver's, unattended)
+        limit = float(os.environ.get("RADET_BENCH_COMM_TIMEOUT", "240"))
+        guard = CommGuard(rank, limit)
+        try:
+            import datetime
+            guard.arm("init_process_group")
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device,
+                                        timeout=datetime.timedelta(seconds=limit))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit))
+            guard.arm("first all_reduce")
+            probe = torch.ones(1024, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if probe.is_cuda:
+                torch.cuda.synchronize()
+            if float(probe[0]) != float(world):
+                raise RuntimeError(f"first all_reduce returned {float(probe[0])}, expected {world}")
+            guard.disarm()
+        except Exception as e:               # noqa: BLE001 -- whatever it is, say it in one line and leave
+            guard.disarm()
+            print(json.dumps({"error": f"rank {rank}/{world}: {guard.what} failed: {type(e).__name__}: {str(e)[:300]}"}), flush=True)
+            sys.stderr.write(f"bench.py: rank {rank}/{world}: {guard.what} failed: {type(e).__name__}: {str(e)[:300]}\n")
+            os._exit(3)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from radet_amd.models import build_detector
@@ -541,9 +631,11 @@ def main():
     t = torch.tensor([dt], device=cdev, dtype=torch.float64)
     rank_ms = None
     if world > 1:
-        per_rank = [torch.zeros(2, device=cdev, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([dt_rank, t_enq], device=cdev, dtype=torch.float64))
-        rank_ms = [[round(float(v[0]) / args.steps * 1e3, 3), round(float(v[1]) / args.steps * 1e3, 3)] for v in per_rank]
+        per_rank = [torch.zeros(4, device=cdev, dtype=torch.float64) for _ in range(world)]
+        mine = [dt_rank, t_enq, float(cpus[0]) if cpus else -1.0, float(len(cpus)) if cpus else 0.0]
+        dist.all_gather(per_rank, torch.tensor(mine, device=cdev, dtype=torch.float64))
+        rank_ms = [[round(float(v[0]) / args.steps * 1e3, 3), round(float(v[1]) / args.steps * 1e3, 3), int(v[2]), int(v[3])]
+                   for v in per_rank]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -572,8 +664,8 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "image": f"{IMG_W}x{IMG_H}",
                        "parallelism": f"dp{world}", "losses_step1": [float(x) for x in first.cpu()],
                        "losses": [float(x) for x in losses],
-                       "step_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
-                       "step_frac_of_fp32_mfma_peak": round(value / world * TRAIN_FLOP_PER_IMG / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)},
+                       "step_algorithmic_tflops": round(value * TRAIN_FLOP_PER_IMG / 1e12, 2),
+                       "launch_tape": rt.tape_stats()},
         }
         out["host_enqueue_ms_per_step"] = round(t_enq / args.steps * 1e3, 3)
         out["host"] = {"cores": effective_cores(), "cpu": cpu_model(),
@@ -586,6 +678,9 @@ def main():
         if rank_ms is not None:
             out["ranks"] = {"ms_per_step_min": min(r[0] for r in rank_ms), "ms_per_step_max": max(r[0] for r in rank_ms),
                             "host_enqueue_ms_per_step_max": max(r[1] for r in rank_ms), "per_rank_ms_per_step": [r[0] for r in rank_ms],
+                            "per_rank_host_enqueue_ms_per_step": [r[1] for r in rank_ms],
+                            "per_rank_cores": [(f"{r[2]}-{r[2] + r[3] - 1}" if r[3] > 0 else None) for r in rank_ms],
+                            "launch_tape": rt.tape_stats(),
                             "note": "each rank's own wall time of the K timed steps (its synchronize + the closing barrier included); a "
                                     "straggler shows as min << max"}
         if sampler is not None:
@@ -632,6 +727,12 @@ def main():
         if world == 1 and args.math == "fp32" and args.weights == "init" and not args.no_extras:
             ex = extras(args)
             out.update(ex)
+            sw = ex.get("synthetic_trained_like_weights", {})
+            if isinstance(sw.get("ms_per_step"), (int, float)):
+                # next to `value`: the same step on NON-degenerate operands (the reference's init zeroes every Bottleneck's
+                # norm3.weight, backbones/resnet.py:600-618, so a third of the headline's bottleneck convs multiply zeros)
+                out["value_trained_like_weights"] = sw["value"]
+                out["ms_per_step_trained_like_weights"] = sw["ms_per_step"]
             # the secondary numbers once more inside `config` (numbers only): the driver's record keeps `config` verbatim
             sec = {}
             for key, fields in (("infer", ("value",)), ("r101", ("ms_per_step", "value")), ("bf16_storage", ("value", "ms_per_step")),

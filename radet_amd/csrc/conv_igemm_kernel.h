@@ -536,8 +536,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
                 // (h2: the slice started with only the hi fragments waited for -- the lo fragments, read behind them, are due now;
                 // the reads issued behind group 0 may stay in flight)
                 // in order: [A hi, B hi | B lo | A lo] of this set, then the NRD / 2 reads issued behind each earlier group
-                if constexpr (H2 && t == 1) { if (do_read) lds_wait<TM + NRD / (NT - 1)>(); else lds_wait<TM>(); }
-                if constexpr (H2 && t == 2) { if (do_read) lds_wait<2 * (NRD / (NT - 1))>(); else lds_wait<0>(); }
+                // (the fragments a wait releases are pinned BEHIND it: an MFMA has no other tie to the wait, and the compiler hoisted
+                // the first MFMA of groups 1 / 2 above it -- a lo fragment could be consumed before its ds_read had returned: rare
+                // last-bit differences from run to run in the 64 x 64 tile, whose group is a single MFMA; round 6)
+                if constexpr (H2 && t == 1) {
+                    if (do_read) lds_wait<TM + NRD / (NT - 1)>(); else lds_wait<TM>();
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(fb[PP][1][j]));
+                }
+                if constexpr (H2 && t == 2) {
+                    if (do_read) lds_wait<2 * (NRD / (NT - 1))>(); else lds_wait<0>();
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[PP][1][i]));
+                }
                 if (!RADET_P3_DBG || !(a.dbg & 2)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)

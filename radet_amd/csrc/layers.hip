@@ -546,24 +546,29 @@ __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __r
     __shared__ float red[4];
     if (d.w_l1t) {
         // largest L1 norm of an input channel, max_c sum_{o,t} |wf[o][t][c]|: bounds the dgrad's output (its GEMM sums over
-        // o and t).  One workgroup per channel, fixed order; the reads stride through the OIHW tensor (small: once per fold)
-        const int KT = d.kh * d.kw, n = d.cout * KT;
+        // o and t).  A workgroup owns 64 consecutive channels: thread (rg, cl) sums rows o = rg, rg + 4, ... of channel cl --
+        // a wave reads 64 neighbouring channels of one OIHW row (coalesced) -- and the four row groups are added in a fixed order
+        const int KT = d.kh * d.kw;
+        __shared__ float part[4][64];
+        const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
         float l1t = 0.f;
-        for (int c = blockIdx.x; c < d.cin; c += gridDim.x) {
+        for (int c0 = blockIdx.x * 64; c0 < d.cin; c0 += gridDim.x * 64) {
+            const int c = c0 + cl;
             float sc_ = 0.f;
-            for (int i = threadIdx.x; i < n; i += 256) {
-                const int o = i / KT, t = i - o * KT;
-                float s = 1.f;
-                if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
-                sc_ += fabsf(d.w[((size_t)o * d.cin + c) * KT + t] * s);
-            }
-            sc_ = wave_sum(sc_);
+            if (c < d.cin)
+                for (int o = rg; o < d.cout; o += 4) {
+                    float s = 1.f;
+                    if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
+                    const float* w = d.w + ((size_t)o * d.cin + c) * KT;
+                    float so = 0.f;
+                    for (int t = 0; t < KT; ++t) so += fabsf(w[t] * s);
+                    sc_ += so;
+                }
             __syncthreads();
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sc_;
+            part[rg][cl] = sc_;
             __syncthreads();
-            l1t = fmaxf(l1t, (red[0] + red[1]) + (red[2] + red[3]));
+            if (rg == 0) l1t = fmaxf(l1t, (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]));
         }
-        __syncthreads();
         radet_amax_publish(l1t, reinterpret_cast<unsigned*>(d.w_l1t));
     }
     if (d.w_amax == nullptr || (d.w16 != 3 && !d.wfq && !d.w_l1)) return;

@@ -95,18 +95,24 @@ class Engine:
         # and the tests stay).  [A first measurement showed 8.73: the first pair stage was reading a copy nobody had written
         # -- zeros -- and the matrix cores clock higher on zeros.  Timings are only comparable on live data.]
         self.pairs = self.h2 and os.environ.get("RADET_PAIRS", "0") == "1"
-        # Pairs-ONLY tensors in the bottleneck blocks (round 6, default): a tensor that nothing but conv GEMMs and a ReLU mask
-        # read is written by its producer's epilogue as fp16 plane pairs and NOT as fp32 (the towers' activations have been
-        # stored that way since round 3) -- the same 4 bytes per element leave the CU, the consumers' K loops run without an
-        # operand split (25-40 % less time per launch alone, profiles/round5_bench_h2.txt), and unlike RADET_PAIRS=1 there is
-        # no second write.  In a stride-1 bottleneck block: o1 = relu(bn1(conv1 x)) is read by conv2 (forward and weight
-        # gradient) and as the mask of conv2's dgrad; d_o2 = dL/d(o2) is read by conv2's dgrad and weight gradient; conv2's
-        # folded weights exist as pairs in both orientations.  The residual path (block inputs / outputs, d_pre) stays fp32,
-        # and so do o2 / d_o1: their weight gradients pair them with an fp32 tensor (a mixed-operand kernel is the next step).
-        # Strided blocks (the first of stages 2-4) keep fp32 tensors: their dgrad runs as parity-class launches.
-        # RADET_PAIRS_ONLY=0: every tensor fp32, operands split in registers (the round-5 step).
-        self.po = self.h2 and not self.pairs and os.environ.get("RADET_PAIRS_ONLY", "1") != "0"
-        self.pairs_from = int(os.environ.get("RADET_PAIRS_FROM", "2"))          # first ResNet stage (1-based) that reads pairs
+        # Pairs-ONLY tensors in the bottleneck blocks (round 6; built, measured, OFF by default -- RADET_PAIRS_ONLY=1 selects it):
+        # a tensor that nothing but conv GEMMs and a ReLU mask read is written by its producer's epilogue as fp16 plane pairs
+        # and NOT as fp32 (as the towers' activations have been since round 3): the same 4 bytes per element leave the CU, the
+        # consumers' K loops run without an operand split, and unlike RADET_PAIRS=1 there is no second write.  In a stride-1
+        # bottleneck block: o1 = relu(bn1(conv1 x)) is read by conv2 (forward and weight gradient) and as the ReLU mask of
+        # conv2's dgrad; d_o2 = dL/d(o2) is read by conv2's dgrad and weight gradient; conv2's folded weights exist as pairs
+        # in both orientations.  The residual path (block inputs / outputs, d_pre) stays fp32, and so do o2 / d_o1 (their
+        # weight gradients pair them with an fp32 tensor).  Strided blocks keep fp32 tensors (parity-class dgrad launches).
+        # What it measured (r50 640 x 480 bs 4, per launch, serialised, tools/prof_layers.py, pairs-only against fp32 tensors):
+        #   conv2 forward   64 ch 34.8 / 48.4 us, 128 ch 39.5 / 47.9, 256 ch 47.7 / 42.6, 512 ch 48.6 / 50.5
+        #   conv2 dgrad     128 ch 40.0 / 48.0, 256 ch 48.4 / 41.7, 512 ch 50.1 / 49.2
+        #   conv2 wgrad     (one-tap pair kernel) 128 ch 65.7 / 46.8, 256 ch 50.9 / 47.6, 512 ch 57.3 / 54.5
+        #   producers       +2-4 us per launch for the pair epilogue (conv1 forward, conv3 dgrad)
+        # i.e. the K-divided in-register tiles of round 5 beat the 4-wave pair tiles from K = 2304 on, and the step does not
+        # move: 8.35-8.43 ms with every stride-1 block (or those of <= 128 planes: RADET_PAIRS_ONLY_MAX) on pairs against
+        # 8.32-8.45 without, same box.  The kernels, the bound logic and the tests stay.
+        self.po = self.h2 and not self.pairs and os.environ.get("RADET_PAIRS_ONLY", "0") == "1"
+        self.po_max_planes = int(os.environ.get("RADET_PAIRS_ONLY_MAX", "512"))
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
         # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only
@@ -211,7 +217,7 @@ class Engine:
                     c2=self._add(Conv(pfx + ".conv2", planes, planes, 3, stride, 1, bn=pfx + ".bn2", trainable=train, dgrad=train)),
                     c3=self._add(Conv(pfx + ".conv3", planes, planes * 4, 1, 1, 0, bn=pfx + ".bn3", trainable=train, dgrad=train)),
                     ds=None, stride=stride, train=train,
-                    po=self.po and stride == 1 and planes % 32 == 0)       # o1 / d_o2 exist only as plane pairs (see __init__)
+                    po=self.po and stride == 1 and planes % 32 == 0 and planes <= self.po_max_planes)   # o1 / d_o2 only as plane pairs
                 if b == 0:
                     blk["ds"] = self._add(Conv(pfx + ".downsample.0", inpl, planes * 4, 1, stride, 0, bn=pfx + ".downsample.1",
                                                trainable=train, dgrad=in_dgrad))
@@ -281,7 +287,7 @@ class Engine:
                     o_t += n
             if c.w16 >= 2:            # planes: rows (o, tap) x Cin and (c, tap) x Cout (include/radet_hip.h, "planes" / "plane pairs")
                 c.wf = K.Planes(c.cout * c.k * c.k, c.cin, device=dev, kind=pkind, amax=c.w_amax)
-                c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev, kind=pkind, amax=c.w_amax)
+                c.wft = K.Planes(c.cin * c.k * c.k, c.cout, device=dev, kind=pkind, amax=c.w_amax) if c.need_dgrad else None
             elif self.h2 and c is not self.convs[0]:
                 if self.pairs and c.name.startswith(("backbone.layer", "neck.lateral")) and c.cin % 32 == 0 and \
                         (not c.name.startswith("backbone.layer") or int(c.name[14]) >= self.pairs_from):
@@ -1044,13 +1050,29 @@ class Engine:
             self.side_collect()
             self._join(self._side_stream)
 
+    # GroupNorm + ReLU of the towers on fp32 tensors (every path but the default plane-pair one: RADET_P3=0, RADET_TOWER_MODE).
+    # With the fp16 hi / lo arithmetic the tensors they write are conv operands and need their amax slots raised: the forward
+    # kernel's _q variant does it for y, the backward's dz gets a stand-alone pass (these are comparison modes, not the default).
+    def _gn_fwd(self, z, gamma, beta, y, stats, ws):
+        if self.h2 and not K._isp(y):
+            K.gn_relu_fwd_q(self.plv, z, gamma, beta, y, None, stats, ws)
+        else:
+            K.gn_relu_fwd(self.plv, z, gamma, beta, y, stats, ws)
+
+    def _gn_bwd(self, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws):
+        K.gn_relu_bwd(self.plv, dy, z, stats, gamma, beta, dz, dgamma, dbeta, ws)
+        if self.h2 and not K._isp(dz) and dz.dtype == torch.float32:
+            sl = K.amax_slot(dz)
+            if sl is not None:
+                K.absmax(dz, sl)
+
     def _tower_fwd_layer(self, t, tower, i, x, ws):
         b, p = self.buf, self.p
         c = tower[i]
         z, y = b[f"{t}.z{i}"], b[f"{t}.y{i}"]
         self._tower_launch(K.conv_fwd, c.geom, x, c.wf, None, z, tile=self._ttile(c))
         gn = f"bbox_head.{t}_convs.{i}.gn"
-        K.gn_relu_fwd(self.plv, z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], ws)
+        self._gn_fwd(z, p[gn + ".weight"], p[gn + ".bias"], y, b[f"{t}.stats{i}"], ws)
         return y
 
     tower_fwd_streams = os.environ.get("RADET_TOWER_FWD_STREAMS", "1") != "0"
@@ -1102,6 +1124,10 @@ class Engine:
             return yc, yr
         # both GroupNorms in one pair of launches (on two streams the fork and the join idled the device for longer
         # than the 23 us of kernels they overlapped)
+        if self.h2:       # (fp32 y: the _q kernel raises its amax slot)
+            K.gn_relu_fwd_pair_q(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], yc, None, b[f"cls.stats{i}"], self.gn_ws, None),
+                                 (zr, p[gr + ".weight"], p[gr + ".bias"], yr, None, b[f"reg.stats{i}"], self.gn_ws2, None))
+            return yc, yr
         K.gn_relu_fwd_pair(self.plv, (zc, p[gc + ".weight"], p[gc + ".bias"], yc, b[f"cls.stats{i}"], self.gn_ws),
                            (zr, p[gr + ".weight"], p[gr + ".bias"], yr, b[f"reg.stats{i}"], self.gn_ws2))
         return yc, yr
@@ -1248,8 +1274,8 @@ class Engine:
         c = tower[i]
         dy, dz = b[f"{t}.dy"], b[f"{t}.dz"]
         gn = f"bbox_head.{t}_convs.{i}.gn"
-        K.gn_relu_bwd(self.plv, dy, b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"], p[gn + ".bias"], dz,
-                      g[gn + ".weight"], g[gn + ".bias"], ws)
+        self._gn_bwd(dy, b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"], p[gn + ".bias"], dz,
+                     g[gn + ".weight"], g[gn + ".bias"], ws)
         x = b[f"{t}.y{i - 1}"] if i > 0 else b["P"]
         # the weight-gradient GEMM stays ON the tower's chain: moved to a stream of its own (overlapping the other
         # tower's dgrad and GroupNorm) the all-taps kernel's large workgroups starve the dependent chain -- measured
@@ -1335,8 +1361,8 @@ class Engine:
                         K.gn_relu_bwd_p(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
                                         p[gn + ".bias"], None, b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
                     else:
-                        K.gn_relu_bwd(self.plv, b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
-                                      p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
+                        self._gn_bwd(b[f"{t}.dy"], b[f"{t}.z{i}"], b[f"{t}.stats{i}"], p[gn + ".weight"],
+                                     p[gn + ".bias"], b[f"{t}.dz{i & 1}"], g[gn + ".weight"], g[gn + ".bias"], self.gn_ws)
                     x = b[f"{t}.y{i - 1}"] if i > 0 else (b["Pp"] if self.p3 else b["P"])
                     if gn_first:
                         pending.append((t, tower, x))

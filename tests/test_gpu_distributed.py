@@ -123,3 +123,34 @@ def test_bench_script_two_ranks_on_one_gpu(launcher):
     names = [b["bucket"] for b in d["comm"]["buckets"]]
     assert names == ["bbox_head.", "neck.", "backbone.layer4.2.", "backbone.layer4.1.", "backbone.layer4.0.", "backbone.layer3.",
                      "backbone.layer2."]
+    # the schema the SCALE record is read with (round 6): per-rank step and host-enqueue times, the core set each rank bound
+    # itself to (disjoint, before its first GPU call), the traced exchange per bucket, the exposed part of it
+    assert len(rk["per_rank_host_enqueue_ms_per_step"]) == 2 and all(0 < v < 1e3 for v in rk["per_rank_host_enqueue_ms_per_step"])
+    cores = rk["per_rank_cores"]
+    assert len(cores) == 2
+    if cores[0] is not None:                              # (None: fewer than two cores allowed, or RADET_BENCH_AFFINITY=0)
+        lo = [tuple(int(x) for x in c.split("-")) for c in cores]
+        assert lo[0][1] < lo[1][0] or lo[1][1] < lo[0][0], cores
+    for key in ("steps", "forward_loss_ms", "backward_ms", "exposed_comm_ms", "bf16_buckets"):
+        assert key in d["comm"], key
+    for b in d["comm"]["buckets"]:
+        assert b["mbytes"] > 0 and 0 <= b["ready_ms"] <= b["done_by_ms"] + 1e-6
+    assert d["config"]["step_algorithmic_tflops"] > 0 and "step_frac_of_fp32_mfma_peak" not in d["config"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_script_fails_fast_when_a_rank_is_missing():
+    """A rank whose process group cannot form (here: WORLD_SIZE = 2 with only rank 0 started, 6-second limit) leaves with one
+    line that names the rank and the phase and a non-zero exit code -- it does not hang until the caller's timeout."""
+    import json
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, RADET_BENCH_SHARE_GPU="1", RADET_BENCH_BACKEND="gloo", RADET_BENCH_COMM_TIMEOUT="6",
+               WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=500, env=env, cwd=REPO)
+    assert r.returncode in (3, 4) and time.time() - t0 < 300, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "rank 0" in json.loads(lines[0])["error"] and "init_process_group" in json.loads(lines[0])["error"]

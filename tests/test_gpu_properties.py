@@ -204,7 +204,8 @@ def test_tape_replay_is_bit_identical(math):
 
 def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
     """The default fp32 arithmetic (fp16 hi / lo pairs, three products on the fp16 matrix cores), the same with the backbone
-    forward on producer-written plane pairs (RADET_PAIRS=1), the former one (three bf16 planes, six products) and the native
+    forward on producer-written plane pairs (RADET_PAIRS=1) and with o1 / d_o2 of the stride-1 bottleneck blocks stored ONLY
+    as pairs (RADET_PAIRS_ONLY=1, round 6), the former one (three bf16 planes, six products) and the native
     fp32 MFMA run the same forward + loss + backward on the headline batch.  Yardstick: the native arithmetic against ITSELF with
     other tiles / split-K factors (launcher heuristics instead of the tune file), i.e. another fp32 summation order --
     ReLU masks and GroupNorm amplify last-bit differences through ~60 layers.  The plane arithmetic must sit within 3x of
@@ -217,10 +218,14 @@ def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
     img, boxes, labels, p2g, pw = bench.make_batch(0, 4, torch.device("cuda"))
     out = {}
     for tag, math, tune, env in (("planes", "fp32", "1", {}), ("pairs", "fp32", "1", {"RADET_PAIRS": "1"}),
+                                 ("pairs-only", "fp32", "1", {"RADET_PAIRS_ONLY": "1"}),
+                                 # the towers on fp32 tensors (no plane-pair operands): grouped launches / two-stream backward --
+                                 # their GroupNorm outputs and gradients are conv operands whose amax slots must be raised
+                                 ("p3-off", "fp32", "1", {"RADET_P3": "0"}), ("hybrid", "fp32", "1", {"RADET_TOWER_MODE": "hybrid"}),
                                  ("bf16x6", "fp32", "1", {"RADET_X3": "bf16"}), ("mfma", "fp32-mfma", "1", {}),
                                  ("mfma-heur", "fp32-mfma", "0", {}), ("bf16", "bf16", "1", {})):
         monkeypatch.setenv("RADET_AUTOTUNE", tune)
-        for k in ("RADET_PAIRS", "RADET_X3"):
+        for k in ("RADET_PAIRS", "RADET_X3", "RADET_PAIRS_ONLY", "RADET_P3", "RADET_TOWER_MODE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -229,7 +234,9 @@ def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
         torch.manual_seed(0)
         det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
         rt = det.runtime(math=math)
-        assert rt.engine.x3 == (math == "fp32") and rt.engine.pairs == (tag == "pairs") and rt.engine.h2 == (tag in ("planes", "pairs"))
+        assert rt.engine.x3 == (math == "fp32") and rt.engine.pairs == (tag == "pairs") and rt.engine.h2 == (tag in ("planes", "pairs", "pairs-only", "p3-off", "hybrid"))
+        assert rt.engine.p3 == (tag in ("planes", "pairs", "pairs-only", "bf16x6"))
+        assert rt.engine.po == (tag == "pairs-only") and (not rt.engine.po or sum(blk["po"] for st in rt.engine.stages for blk in st) == 13)
         tg = rt.pack_targets([torch.from_numpy(b) for b in boxes], [torch.from_numpy(l) for l in labels], list(p2g), list(pw))
         rt.forward(img)
         losses = rt.loss(tg).clone()
@@ -240,7 +247,7 @@ def test_both_fp32_arithmetics_agree_on_losses_and_gradients(monkeypatch):
     ref_l, ref_g = out["mfma"]
     dist = {k: float((g - ref_g).norm() / ref_g.norm()) for k, (_, g) in out.items() if k != "mfma"}
     print("gradient distance to the tuned native-fp32 run:", dist)
-    for tag in ("planes", "pairs", "bf16x6"):
+    for tag in ("planes", "pairs", "pairs-only", "p3-off", "hybrid", "bf16x6"):
         assert ((out[tag][0] - ref_l).abs() / ref_l.abs()).max() < 1e-6, (tag, out[tag][0], ref_l)
         assert dist[tag] <= 3 * dist["mfma-heur"] + 1e-6, dist
     assert dist["bf16"] > 20 * dist["planes"], dist

@@ -39,6 +39,12 @@ def infer(n_images=1000, B=16):        # (the reference config's samples_per_gpu
         det.bbox_head.atss_cls.bias += float(np.log(0.05 / 0.95)) - float(q)
     for _ in range(3):
         out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
+    # BASELINE configs[3] asks for 1000 images: n_images // B full batches + one tail batch of the remainder (1000 = 62 x 16 + 8)
+    tail = n_images % B
+    batches = [(imgs, metas)] * (n_images // B) + ([(imgs[:tail].contiguous(), metas[:tail])] if tail else [])
+    if tail:                                                # the tail's geometry plan (buffers, tuned tiles) exists before the clock starts
+        rt.detect(batches[-1][0], batches[-1][1], det.test_cfg, rescale=True)
+        rt.detect(imgs, metas, det.test_cfg, rescale=True)
     passed = float((torch.sigmoid(rt.engine.buf["cls"]) > 0.05).float().mean())
     if os.environ.get("RADET_INFER_SYNC") != "1":           # warm the streamed path (its streams, second set of head buffers)
         for _ in rt.detect_stream(((imgs, metas) for _ in range(3)), det.test_cfg, rescale=True):
@@ -47,20 +53,20 @@ def infer(n_images=1000, B=16):        # (the reference config's samples_per_gpu
     t0 = time.perf_counter()
     ndet = 0
     if os.environ.get("RADET_INFER_SYNC") == "1":           # one batch at a time (the host waits for every batch's counts)
-        for _ in range(n_images // B):
-            out = rt.detect(imgs, metas, det.test_cfg, rescale=True)
+        for im, mt in batches:
+            out = rt.detect(im, mt, det.test_cfg, rescale=True)
             ndet += sum(int(d.shape[0]) for d, _ in out)
     else:                                                   # the host one batch behind the device (rt.detect_stream)
-        for out in rt.detect_stream(((imgs, metas) for _ in range(n_images // B)), det.test_cfg, rescale=True):
+        for out in rt.detect_stream(iter(batches), det.test_cfg, rescale=True):
             ndet += sum(int(d.shape[0]) for d, _ in out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    post = next(iter(rt._posts.values()))           # the decode / NMS buffers of this (B, nms_pre)
+    post = max(rt._posts.values(), key=lambda p_: p_["count"].numel())           # the decode / NMS buffers of the full batches
     cand = int(post["count"].sum().item())
     if os.environ.get("RADET_DBG_LABELS"):
         c0 = int(post["count"][0].item())
         print("label histogram img0:", torch.bincount(post["labels"][0, :c0], minlength=21).tolist())
-    n_run = n_images // B * B
+    n_run = n_images
     print(f"config4 inference: {n_run / dt:.1f} images/sec ({n_run} images), {ndet / dt:.0f} detections/sec "
           f"(B={B}, {100 * passed:.1f} % of cls scores > 0.05, {cand / B:.0f} candidates/img into vote-NMS, "
           f"{ndet / n_run:.0f} dets/img)")

@@ -113,6 +113,7 @@ class Engine:
         # 8.32-8.45 without, same box.  The kernels, the bound logic and the tests stay.
         self.po = self.h2 and not self.pairs and os.environ.get("RADET_PAIRS_ONLY", "0") == "1"
         self.po_max_planes = int(os.environ.get("RADET_PAIRS_ONLY_MAX", "512"))
+        self.pairs_from = int(os.environ.get("RADET_PAIRS_FROM", "2"))          # first ResNet stage (1-based) that reads pairs
         if self.x3 and "RADET_TOWER_MODE" not in os.environ:
             self.tower_mode = "pairbwd"
         # plane operands for the head towers (RADET_P3=0: split in the GEMMs' registers as everywhere else): the tensors only

@@ -527,6 +527,10 @@ int radet_tape_fn_index(const char* name);    /* index of an `int radet_*(...)` 
 int radet_tape_replay(const RadetTapeOp* ops, int first, int last, int* failed);
 /* stream-ordered helpers a taped step uses instead of torch's fill / copy (hipMemsetAsync / hipMemcpyAsync device to device) */
 int radet_fill_zero(void* dst, size_t nbytes, void* stream);
+/* a HIP stream whose kernels may only run on the compute units whose bit is set in cu_mask (host array of nwords 32-bit words, bit i
+ * of word w = CU 32 w + i; hipExtStreamCreateWithCUMask): the engine's weight-gradient streams can be kept off a share of the CUs
+ * so that the dependent dgrad chain always finds free ones (experiment switch RADET_WGRAD_CU_MASK).  *stream_out: hipStream_t (host) */
+int radet_stream_create_cumask(const uint32_t* cu_mask, int nwords, void** stream_out);
 int radet_copy_d2d(void* dst, const void* src, size_t nbytes, void* stream);
 
 #ifdef __cplusplus

@@ -142,6 +142,7 @@ SIGNATURES = {
     "radet_tape_replay": (_i, [_p, _i, _i, _p]),
     "radet_fill_zero": (_i, [_p, _sz, _p]),
     "radet_copy_d2d": (_i, [_p, _p, _sz, _p]),
+    "radet_stream_create_cumask": (_i, [_p, _i, _p]),
 }
 
 _lib = None

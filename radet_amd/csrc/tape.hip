@@ -53,3 +53,11 @@ extern "C" int radet_copy_d2d(void* dst, const void* src, size_t nbytes, void* s
     if (!nbytes) return 0;
     return hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? 0 : -2;
 }
+
+extern "C" int radet_stream_create_cumask(const uint32_t* cu_mask, int nwords, void** stream_out) {
+    if (!cu_mask || nwords < 1 || !stream_out) return -1;
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, cu_mask) != hipSuccess) return -2;
+    *stream_out = (void*)s;
+    return 0;
+}

@@ -167,10 +167,17 @@ class Engine:
             # for 128 x 64) and backward (-0.15 ms per step)
             t = 0x200 | 1
         elif bwd:
-            t = (self.TOWER_TAG & ~0x100) if fp32 else c.geom.bwd_tile
+            t = (self.TOWER_TAG & ~0x100) if fp32 else (self.tower_bwd_tile_h16 or c.geom.bwd_tile)
         else:
             t = (self.TOWER_TAG_FWD & ~0x100) | (K.STAGES3 if fp32 else 0)
+            if not fp32 and self.tower_fwd_tile_h16:
+                t = self.tower_fwd_tile_h16
         return t | (0x100 if tag else 0)
+    tower_fwd_tile_h16 = int(os.environ.get("RADET_TOWER_FWD_TILE", "0"), 0)     # bf16 modes: tower forward tile (0: 128 x 64, K step 32)
+    # bf16 modes: tower dgrad tile.  The tuner times a launch ALONE and picks 64 x 64 / K step 16 for M = 25 600, K = 2304; in the
+    # step the two towers' dgrads run next to each other and to the weight gradients, where 128 x 128 / K step 32 is the faster
+    # one: bf16-storage step 5.35 -> 5.11 ms (round 6, same box: 0x203 5.24, 0x202 5.18, 0x1 5.16).  0: the tuner's pick
+    tower_bwd_tile_h16 = int(os.environ.get("RADET_TOWER_BWD_TILE", "0x201"), 0)
     tower_events = None  # when a list: (start, end) torch.cuda.Event pairs around every tower GEMM launch
     _pfx_ready = None    # (image key, buffer set, event) of a frozen prefix computed ahead of its step (prefetch_prefix)
 
@@ -912,7 +919,16 @@ class Engine:
         key = (torch.device(self.dev).index if torch.device(self.dev).index is not None else torch.cuda.current_device(), role)
         st = Engine._SHARED_STREAMS.get(key)
         if st is None:
-            st = Engine._SHARED_STREAMS[key] = torch.cuda.Stream(device=self.dev)
+            mask = os.environ.get("RADET_WGRAD_CU_MASK")          # experiment: 32-bit pattern, repeated over the device's CUs
+            if mask and role in ("side", "side2"):
+                words = (C.c_uint32 * 8)(*([int(mask, 0) & 0xFFFFFFFF] * 8))
+                out = C.c_void_p()
+                with torch.cuda.device(self.dev):
+                    _lib.check(_lib.load().radet_stream_create_cumask(words, 8, C.byref(out)), "radet_stream_create_cumask")
+                st = torch.cuda.ExternalStream(out.value, device=self.dev)
+            else:
+                st = torch.cuda.Stream(device=self.dev)
+            Engine._SHARED_STREAMS[key] = st
         return st
 
     def caller_stream(self):

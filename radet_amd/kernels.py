@@ -118,7 +118,7 @@ _TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometr
 EVENTS = None
 STAGE = ""          # part of the detector the engine is enqueueing (stem, layer1..4, neck, head): recorded with every event
 _TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2",
-          7: "64, 64, 2, 2", 8: "64, 64, 2, 2"}
+          7: "64, 64, 2, 2", 8: "64, 64, 2, 2", 9: "256, 128, 2, 2"}
 
 
 def _igemm_key(t, x):
@@ -151,7 +151,7 @@ def _igemm_key(t, x):
     return f"conv_igemmg_kernel<{_TILES.get(tid, '?')}, {tag}, {bk}, {stages}, {'true' if skw and tag == 0 else 'false'}>"
 
 
-def _timed(key, flops, fn, nbytes=0.0, kind="fwd"):
+def _timed(key, flops, fn, nbytes=0.0, kind="fwd", geom=None):
     """key: the kernel's name, or a callable producing it (only evaluated when a measurement is running); kind: fwd / dgrad /
     wgrad; the engine's STAGE at the time of the call goes into the record (bench.py's per-stage table)"""
     ev = EVENTS
@@ -162,7 +162,7 @@ def _timed(key, flops, fn, nbytes=0.0, kind="fwd"):
     fn()
     e.record()
     ev.append(dict(key=key() if callable(key) else key, flops=float(flops), bytes=float(nbytes), start=s, end=e, replay=fn,
-                   stage=STAGE, kind=kind))
+                   stage=STAGE, kind=kind, geom=geom))
 
 
 def _conv_bytes(g, groups=1):
@@ -809,7 +809,7 @@ def conv_fwd(g, x, wf, bias, y, addend=None, mask=None, relu=False, tile=0, spli
         _lib.call("radet_conv2d_igemm_s", _ptr_any(x), _ptr_any(wf), _ptr(bias), _ptr(addend), _ptr(mask), _ptr(y), _ptr(table),
                   g.lout.rows, g.cin, g.cout, g.k, g.k, int(relu), tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0),
                   _stream(), sc)
-    _timed(lambda: _igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g))
+    _timed(lambda: _igemm_key(tile, x), 2.0 * g.lout.rows * g.cout * g.cin * g.k * g.k, launch, _conv_bytes(g), geom=g)
 
 
 def _pred_tiles(lv):
@@ -950,7 +950,7 @@ def conv_dgrad(g, dy, wft, dx, addend=None, mask=None, k_channels=None, tile=0, 
         _timed(_igemm_key(tile, dy) + (" [strided dgrad, class launch]" if g.stride > 1 else ""),
                2.0 * g.lout.rows * real_k * g.cin * g.k * g.k,
                lambda: _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows, yq, wmeta),
-               _conv_bytes(g), kind="dgrad")
+               _conv_bytes(g), kind="dgrad", geom=g)
         return
     _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_rows, yq, wmeta)
 
@@ -1009,7 +1009,7 @@ def conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
         co_ = g.cout if cout is None else cout
         _timed(_wgrad_key(g, dy, co_), 2.0 * g.lout.rows * co_ * g.cin * g.k * g.k,
                lambda: _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy),
-               4.0 * (g.lout.rows * co_ + g.lin.rows * g.cin + g.nsplit * co_ * g.k * g.k * g.cin), kind="wgrad")
+               4.0 * (g.lout.rows * co_ + g.lin.rows * g.cin + g.nsplit * co_ * g.k * g.k * g.cin), kind="wgrad", geom=g)
         return
     _conv_wgrad(g, dy, x, slabs, dbias_partials, cout, ld_dy)
 

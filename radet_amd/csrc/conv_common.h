@@ -572,6 +572,5 @@ __device__ __forceinline__ void h2_combine(f32x16& acc0, const f32x16& acc1, flo
 // ---- launchers of the fp16 hi / lo instantiations (conv_h2.hip: their own translation unit, compiled next to conv_igemm.hip)
 bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
                            bool no_tail_split);
-bool radet_launch_igemm_h2_big(const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, bool no_tail_split);
 struct WgradArgs;
 int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStream_t st);

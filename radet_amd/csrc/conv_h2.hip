@@ -49,7 +49,6 @@ bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int ta
             case 3: launch_h2<64, 64, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
             case 5: launch_h2<128, 128, 2, 4, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
             case 6: launch_h2<256, 128, 4, 2, 2>(a, st, tag, bk, ws_floats, stages, no_tail_split); return true;
-            case 9: return radet_launch_igemm_h2_big(a, st, tag, bk, ws_floats, no_tail_split);     // (conv_h2_big.hip)
             default: return false;
         }
     }

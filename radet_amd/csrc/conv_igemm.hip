@@ -884,8 +884,8 @@ static void launch_igemm(const ConvArgs& a_in, hipStream_t st, int tag, int bk, 
 }
 
 static long igemm_tiles(int M, int N, int choice) {
-    const int bm = (choice == 3 || choice == 7 || choice == 8) ? 64 : ((choice == 6 || choice == 9) ? 256 : 128);
-    const int bn = (choice == 1 || choice == 5 || choice == 6 || choice == 9) ? 128 : (choice == 4 ? 32 : 64);
+    const int bm = (choice == 3 || choice == 7 || choice == 8) ? 64 : (choice == 6 ? 256 : 128);
+    const int bn = (choice == 1 || choice == 5 || choice == 6) ? 128 : (choice == 4 ? 32 : 64);
     return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
 }
 
@@ -1116,8 +1116,7 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         tag |= 32; bk = kbk;
     } else
     if (choice > 4 && !p3) return RADET_ERR_ARG;               // the 8-wave tiles exist for plane operands only
-    if ((choice == 6 || choice == 9) && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
-    if (choice == 9 && !(p3 && ((tile_override >> 27) & 1))) return RADET_ERR_ARG;   // (fp16 plane pairs only: conv_h2_big.hip)
+    if (choice == 6 && cls != nullptr) return RADET_ERR_ARG;   // class boundaries are multiples of 128 rows
     if (choice <= 0) {
         if (Cout <= 32) choice = 4;
         else {

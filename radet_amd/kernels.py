@@ -118,7 +118,7 @@ _TABLE_CACHE = _LRU(1024)      # gather tables / parity classes per conv geometr
 EVENTS = None
 STAGE = ""          # part of the detector the engine is enqueueing (stem, layer1..4, neck, head): recorded with every event
 _TILES = {1: "128, 128, 2, 2", 2: "128, 64, 2, 2", 3: "64, 64, 2, 2", 4: "128, 32, 4, 1", 5: "128, 128, 2, 4", 6: "256, 128, 4, 2",
-          7: "64, 64, 2, 2", 8: "64, 64, 2, 2", 9: "256, 128, 2, 2"}
+          7: "64, 64, 2, 2", 8: "64, 64, 2, 2"}
 
 
 def _igemm_key(t, x):

@@ -515,16 +515,19 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
         return radet_check_launch();
     }
     const int KT = a.KH * a.KW;
+    // experiment (RADET_WGRAD_LDS_PAD = bytes of unused dynamic LDS per workgroup): fewer weight-gradient workgroups fit a CU,
+    // so the dgrad chain's workgroups find LDS there -- see DESIGN.md 7 for what it measured
+    static const int pad = getenv("RADET_WGRAD_LDS_PAD") ? atoi(getenv("RADET_WGRAD_LDS_PAD")) : 0;
     if (bm == 64 && (flags & 0xC00)) {
         const int tiles = ((a.Cout + 63) / 64) * ((a.Cin + 63) / 64) * KT * a.S;
-        if (flags & 0x400) hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 64, 4>), dim3(tiles), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 32, 2>), dim3(tiles), dim3(256), 0, st, a);
+        if (flags & 0x400) hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 64, 4>), dim3(tiles), dim3(256), pad, st, a);
+        else hipLaunchKernelGGL((conv_wgradg_kernel<64, 64, 2, 2, 3, 32, 2>), dim3(tiles), dim3(256), pad, st, a);
         return radet_check_launch();
     }
     const int tiles = ((a.Cout + bm - 1) / bm) * ((a.Cin + bn - 1) / bn) * KT * a.S;
 #define RADET_WG_H2(BMV, BNV, WMV, WNV) \
-    do { if (a.bp32 && BMV >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3, 32>), dim3(tiles), dim3(256), 0, st, a); \
-         else hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3>), dim3(tiles), dim3(256), 0, st, a); } while (0)
+    do { if (a.bp32 && BMV >= 64) hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3, 32>), dim3(tiles), dim3(256), pad, st, a); \
+         else hipLaunchKernelGGL((conv_wgradg_kernel<BMV, BNV, WMV, WNV, 3>), dim3(tiles), dim3(256), pad, st, a); } while (0)
     if (bm == 32) RADET_WG_H2(32, 128, 1, 4);
     else if (bm == 64) RADET_WG_H2(64, 64, 2, 2);
     else if (bn == 64) RADET_WG_H2(128, 64, 2, 2);

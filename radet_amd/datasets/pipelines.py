@@ -199,6 +199,9 @@ class LabelAssignment:
             if (used_h == -1).any() and U < U_max:         # stream exhausted (a shuffle of thousands of candidates): more words,
                 U = min(4 * U, U_max)                      # same results -- the kernel is a function of the stream's prefix
                 continue
+            if (used_h == -1).any() and U < (1 << 24):     # the rejection redraws of a weighted choice are bounded heuristically
+                U = U_max = 1 << 24                        # only: one last pass at the former hard cap before giving up
+                continue
             break
         for g, st in zip(gens, states):
             g.set_state(st)

@@ -678,7 +678,9 @@ class Engine:
         do_f = nf > 0 and vf != self._folded[0]
         do_t = nf < n and vt != self._folded[1]
         if do_f:
-            self._pfx_ready = None            # a prefix prefetched with the previous frozen weights is stale
+            self._pfx_ready = None            # a prefix prefetched with the previous frozen weights is stale -- in every plan
+            for plan in getattr(self, "_plans", {}).values():
+                plan["attrs"]["_pfx_ready"] = None
         tail = self.table[nf * C.sizeof(_lib.RadetConvDesc):]
         if do_t and self.use_streams and nf > 0 and os.environ.get("RADET_FOLD_SIDE", "1") != "0":
             side = self._side()
@@ -838,13 +840,19 @@ class Engine:
         cs = self._chain_stream()
         self._fork(cs)                                         # (the frozen convs' folded weights are complete on this stream)
         stage = K.STAGE
+        if self._pfx_event is None:
+            self._pfx_event = torch.cuda.Event()   # (its own event: one of the ring's could be re-recorded by a long step)
+        ev = self._pfx_event
         with torch.cuda.stream(cs):
             self._prefix_forward(next_img, other)
-            ev = self._event()
             K.ev_record(ev)
         K.STAGE = stage
-        self._pfx_ready = (self._img_key(next_img, self.geo_key), other, ev)
+        # the hand-over is keyed by the tensor OBJECT (kept alive here) as well as by its address / version / geometry: a
+        # freed tensor's address may be handed to a new version-0 tensor by the caching allocator
+        self._pfx_ready = (self._img_key(next_img, self.geo_key), other, ev, next_img)
         return True
+
+    _pfx_event = None
 
     def backbone_forward(self, img):
         b = self.buf
@@ -853,7 +861,7 @@ class Engine:
             K.fill_zero(self.amax_act)            # every producer of this pass raises its buffer's slot from zero
         nf = self._n_frozen_stages() if not self.stem.trainable else 0
         rdy, self._pfx_ready = self._pfx_ready, None
-        if not self.stem.trainable and rdy is not None and rdy[0] == self._img_key(img, self.geo_key):
+        if not self.stem.trainable and rdy is not None and rdy[3] is img and rdy[0] == self._img_key(img, self.geo_key):
             K.ev_wait(rdy[2])                                 # prefetched during the previous step's backward pass
             self._pfx_active = rdy[1]
             pb = self._pfx_sets[self._pfx_active]

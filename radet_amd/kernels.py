@@ -500,7 +500,7 @@ def autotune(g, need_dgrad=True, reps=None):
         x = torch.randn(g.lin.rows, g.cin, device=dev).to(dt)
         w = (torch.randn(g.cout * g.k * g.k * g.cin, device=dev) * 0.05).to(dt)
         y = torch.empty(g.lout.rows, g.cout, device=dev, dtype=dt)
-        tmp_keys = _tune_slots(g, x, w, y)
+        tmp_keys = _tune_slots(g, x, w, outputs=(y,))
         fc = cands(g.cin, g.cout, g.lout.rows, g.k * g.k)
         if not g.math and not g.h16:      # forward launches run alone on the device: 3 LDS stages may pay (0x20000)
             fc = fc + [t | STAGES3 for t in fc if (t & 0xFF) < 7 and not t & (STAGES3 | STAGES4)]
@@ -508,7 +508,7 @@ def autotune(g, need_dgrad=True, reps=None):
         bt = 0
         if need_dgrad and g.cout % 16 == 0:
             dx = torch.empty(g.lin.rows, g.cin, device=dev, dtype=dt)
-            tmp_keys += _tune_slots(g, dx)
+            tmp_keys += _tune_slots(g, outputs=(dx,))
             # (no 3-stage candidates for dgrad: timed alone they win, next to the wgrad streams they lose -- a tune file
             # that allowed them made the step 1 % slower)
             bt = best_of(lambda t: conv_dgrad(g, y, w, dx, mask=x, tile=t), cands(g.cout, g.cin, g.lin.rows, g.k * g.k))
@@ -542,7 +542,7 @@ def autotune(g, need_dgrad=True, reps=None):
                 dyq = Planes.from_float(torch.randn(g.lout.rows, g.cout, device=dev), kind="h2")
                 wtq = Planes.from_float(torch.randn(g.cin * g.k * g.k, g.cout, device=dev) * 0.05, kind="h2")
                 dx = torch.empty(g.lin.rows, g.cin, device=dev)
-                tmp_q = _tune_slots(g, dx)
+                tmp_q = _tune_slots(g, outputs=(dx,))
                 cb = [1, 2, 3]
                 for t in list(cb):
                     bm = 64 if (t & 0xFF) == 3 else 128
@@ -566,16 +566,23 @@ def _h2key(g):
     return ("h2",) if (getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not g.h16) else ()
 
 
-def _tune_slots(g, *tensors):
-    """amax slots for the tuner's scratch tensors (fp16 hi / lo arithmetic): measured once, registered by address, so that
-    the timed launches do not each run a stand-alone absmax pass.  Returns the registry keys."""
+def _tune_slots(g, *tensors, outputs=()):
+    """amax slots for the tuner's scratch tensors (fp16 hi / lo arithmetic): the operands' slots are MEASURED once (a constant
+    would overflow fp16 for a K or an init whose sums leave its range), the outputs' start at zero and are raised by the timed
+    launches' epilogues; registered by address, so that the timed launches do not each run a stand-alone absmax pass.
+    Returns the registry keys."""
     keys = []
     if _h2key(g):
         for t in tensors:
             s = new_amax(t.device)
-            if t.is_floating_point() and t.dtype == torch.float32:
-                s.fill_(0x42000000)                 # 32.0: above every |element| of the N(0, 1) / N(0, 0.05) scratch operands and
-            keys.append(register_amax(t, s))        # of what the timed convs write from them
+            if t.is_floating_point() and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0:
+                absmax(t, s)
+            elif t.is_floating_point() and t.dtype == torch.float32:
+                s.fill_(int(t.abs().max().view(torch.int32)) if t.numel() else 0)
+            keys.append(register_amax(t, s))
+        for t in outputs:
+            t.zero_()                               # (an uninitialised output may hold NaN bit patterns: they must not be read back)
+            keys.append(register_amax(t, new_amax(t.device)))
     return keys
 
 

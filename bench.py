@@ -301,6 +301,12 @@ def kernel_report(events, steps, rt, x3, dt_ev, ms_clean, value, math="fp32"):
             tj = json.load(f)
 
     def pmc_traffic(k):                      # (the same PMC passes cover every kernel of the step: "all_kernels")
+        if k.startswith("conv_wgradg_kernel<") and "fp16 hi/lo in registers" in k:
+            # the launchers' readable key -> the symbol rocprofv3 reports: <BM, BN, WM, WN, 3 (= fp16 hi / lo), pixels per stage, pixel groups>
+            bm, bn = k.split("<")[1].split(">")[0].split(", ")
+            px, pg = (64, 4) if "64 px / 4 waves" in k else ((32, 2) if "32 px / 2 waves" in k else ((32, 1) if ", 32 px" in k else (16, 1)))
+            wm, wn = (1, 4) if bm == "32" else (2, 2)
+            k = f"conv_wgradg_kernel<{bm}, {bn}, {wm}, {wn}, 3, {px}, {pg}>"
         kk = k.split(" (")[0].replace(" ", "")
         for name, v in tj.get("all_kernels", {}).items():
             nn = name.replace(" ", "")

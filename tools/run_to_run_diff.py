@@ -1,5 +1,13 @@
+"""Run-to-run comparison of the train step (round 6): the same model, the same batch, N optimisation steps, several times in
+one process -- after every step EVERY engine buffer (plane tensors incl. their amax / true-amax slots), the weight-gradient
+slabs, the folded weights, the gradient and parameter arenas are compared bit for bit with the first run's, and for a
+differing activation the pattern of the difference is printed (which 64-row tiles, which 32-column blocks, how large).
+This is what found the lo-fragment race of the plane-pair GEMM: one wave's 32 x 32 block off by 4e-5 in a few
+tiles of a few runs.  Benign differences it reports: WHICH of a slot's 64 words holds the maximum (the last arriver of an
+in-launch split-K reduction raises it), buffers nobody writes.     python tools/run_to_run_diff.py
+"""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from radet_amd import kernels as K
 from radet_amd.models import build_detector
@@ -7,7 +15,7 @@ from radet_amd.utils import Config
 img, boxes, labels, p2g, pw = bench.make_batch(0, 4, torch.device("cuda"))
 
 def run(nsteps):
-    cfg = Config.fromfile("/root/repo/configs/bop/r50_ycbv_pbr.py"); cfg.model["pretrained"] = None
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "bop", "r50_ycbv_pbr.py")); cfg.model["pretrained"] = None
     torch.manual_seed(0)
     det = build_detector(cfg.model, train_cfg=cfg.train_cfg, test_cfg=cfg.test_cfg).cuda().train()
     rt = det.runtime(); rt.tape_mode = "0"; rt.init_optimizer(); rt.set_loss_from_head(det.bbox_head)

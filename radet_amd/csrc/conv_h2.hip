@@ -26,7 +26,8 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
         else { if (tag & 1) RADET_H2(73, 32, 2); else RADET_H2(72, 32, 2); }
     } else if constexpr (KIND == 1) {
         // (untagged symbols only: the K-divided tiles serve the backbone / neck, the profiling tag marks the head towers)
-        if (bk == 64) RADET_H2(104, 64, 2);                          // 32 KiB per stage: two stages, two workgroups per CU
+        if (tag & 128) RADET_H2(232, 64, 2);                         // ... on fp16 plane pairs (round 6): 64-channel stages only
+        else if (bk == 64) RADET_H2(104, 64, 2);                     // 32 KiB per stage: two stages, two workgroups per CU
         else if (stages >= 4) RADET_H2(104, 32, 4);                  // 16 KiB per stage: loads up to three stages ahead
         else if (stages == 3) RADET_H2(104, 32, 3);
         else RADET_H2(104, 32, 2);
@@ -42,7 +43,7 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
 
 bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
                            bool no_tail_split) {
-    if (tag & 16) {                                                  // plane pairs: the 8-wave tiles (+ the 4-wave tiles 1-3)
+    if ((tag & 16) && !(tag & 128)) {                                // plane pairs: the 8-wave tiles (+ the 4-wave tiles 1-3)
         switch (choice) {
             case 1: launch_h2<128, 128, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
             case 2: launch_h2<128, 64, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;

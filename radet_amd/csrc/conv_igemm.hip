@@ -1109,6 +1109,14 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         tag |= 64;
     }
     int choice = tile_override & 0xFF;
+    if (choice == 7 && p3 && h2) {
+        // K-divided 64 x 64 tile on fp16 plane PAIRS (round 6): a pair row has the fp32 row's byte length, so the launch is
+        // the fp32 K-divided one (K counted in channels again, 64-channel stages) with the reader's pair flag (TAG bit 7)
+        Cin *= 2;
+        a.Cin = Cin;
+        if (Cin % 64 != 0 || ((tile_override >> 20) & 7) || a.groups != 1) return RADET_ERR_ARG;
+        tag = 8 | 32 | 64 | 128; bk = 64;
+    } else
     if (choice == 7 || choice == 8) {                          // 64 x 64 tiles whose four waves divide the K step (see TAG bit 5):
         // 7: four k-groups of a 64-channel stage; 8: two k-groups x two column halves of a 32-channel stage
         const int kbk = choice == 7 ? 64 : 32;

@@ -50,6 +50,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     // 64 x 64 tile 1 split per 6 MFMAs with KD = 4 (2 x 2 blocks per wave) or 1.5 with KD = 2 (2 x 1), against 2 for the
     // 2 x 2-wave tile whose waves each split one A and one B fragment per 6 MFMAs
     constexpr bool KW = (TAG & 32) != 0;
+    // bit 7 (with bits 3 + 5 + 6, round 6): K-divided tile on fp16 plane PAIRS.  A pair row is as long as the fp32 row (4 bytes
+    // per channel: 32-channel groups [hi x 32 | lo x 32]), so a 64-channel stage is the same 256 contiguous bytes per tile row and
+    // the fp32 loaders / LDS images are used unchanged; only the reader differs -- wave kg takes the hi and the lo 16-byte slot of
+    // ITS 16 channels (group kg / 2, half kg % 2) straight into the MFMA: no operand split, the same two ds_read_b128 per block
+    constexpr bool PQ = (TAG & 128) != 0;
+    static_assert(!PQ || (KW && H2 && BK == 64), "pair operands in the K-divided tile: 64-channel stages");
     constexpr int KD = KW ? BK / 16 : 1;                                  // k-groups per stage
     constexpr int WNK = NW / KD;                                          // column groups of waves
     constexpr int TMA = KW ? BM / 32 : TM, TNA = KW ? BN / (32 * WNK) : TN;      // accumulator blocks of a wave
@@ -421,8 +427,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         unsigned kaa[2], kba[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            kaa[h] = ka + 16u * (unsigned)((4 * kg + 2 * h + lh) ^ rswz);
-            kba[h] = kb + 16u * (unsigned)((4 * kg + 2 * h + lh) ^ rswz);
+            // fp32 rows: k half h of this wave's 16 channels; pair rows (PQ): plane h (0 hi, 1 lo) of them -- slot
+            // 8 (kg / 2) + 4 h + 2 (kg % 2) + lh of the 16 slots of a 64-channel row
+            const int slot = PQ ? (8 * (kg >> 1) + 4 * h + 2 * (kg & 1) + lh) : (4 * kg + 2 * h + lh);
+            kaa[h] = ka + 16u * (unsigned)(slot ^ rswz);
+            kba[h] = kb + 16u * (unsigned)(slot ^ rswz);
         }
         f32x4 fa[2][2][TMA], fb[2][2][TNA];              // [fragment set][k half][block]
         constexpr int NRD = 2 * (TMA + TNA);
@@ -457,10 +466,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             pin(ppc);
             if constexpr (H2) {
                 f16x8 ah[TMA], al[TMA], bh[TNA], bl[TNA];
+                if constexpr (PQ) {                              // the fragments ARE the planes
+#pragma unroll
+                    for (int i = 0; i < TMA; ++i) { ah[i] = __builtin_bit_cast(f16x8, fa[PP][0][i]); al[i] = __builtin_bit_cast(f16x8, fa[PP][1][i]); }
+#pragma unroll
+                    for (int j = 0; j < TNA; ++j) { bh[j] = __builtin_bit_cast(f16x8, fb[PP][0][j]); bl[j] = __builtin_bit_cast(f16x8, fb[PP][1][j]); }
+                } else {
 #pragma unroll
                 for (int i = 0; i < TMA; ++i) split2_f16(fa[PP][0][i], fa[PP][1][i], sx, ah[i], al[i]);
 #pragma unroll
                 for (int j = 0; j < TNA; ++j) split2_f16(fb[PP][0][j], fb[PP][1][j], sw, bh[j], bl[j]);
+                }
 #pragma unroll
                 for (int i = 0; i < TMA; ++i)
 #pragma unroll

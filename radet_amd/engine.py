@@ -108,9 +108,11 @@ class Engine:
         #   conv2 dgrad     128 ch 40.0 / 48.0, 256 ch 48.4 / 41.7, 512 ch 50.1 / 49.2
         #   conv2 wgrad     (one-tap pair kernel) 128 ch 65.7 / 46.8, 256 ch 50.9 / 47.6, 512 ch 57.3 / 54.5
         #   producers       +2-4 us per launch for the pair epilogue (conv1 forward, conv3 dgrad)
-        # i.e. the K-divided in-register tiles of round 5 beat the 4-wave pair tiles from K = 2304 on, and the step does not
-        # move: 8.35-8.43 ms with every stride-1 block (or those of <= 128 planes: RADET_PAIRS_ONLY_MAX) on pairs against
-        # 8.32-8.45 without, same box.  The kernels, the bound logic and the tests stay.
+        # i.e. the K-divided in-register tiles of round 5 beat the 4-wave pair tiles from K = 2304 on; a K-divided PAIR tile
+        # (tile 7 on plane operands) then gives 40.6 / 43.3 us forward and 41.0 / 44.0 us dgrad at 256 / 512 ch -- 2-14 % under
+        # the in-register tile: these launches are latency-bound, not split-bound.  The step does not move: 8.33-8.43 ms with
+        # every stride-1 block (or those of <= 128 planes: RADET_PAIRS_ONLY_MAX) on pairs against 8.30-8.45 without, same
+        # box.  The kernels, the bound logic and the tests stay.
         self.po = self.h2 and not self.pairs and os.environ.get("RADET_PAIRS_ONLY", "0") == "1"
         self.po_max_planes = int(os.environ.get("RADET_PAIRS_ONLY_MAX", "512"))
         self.pairs_from = int(os.environ.get("RADET_PAIRS_FROM", "2"))          # first ResNet stage (1-based) that reads pairs

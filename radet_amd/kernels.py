@@ -127,6 +127,8 @@ def _igemm_key(t, x):
     if tid == 0:
         return "conv_igemmg_kernel<launcher heuristic>"
     if t & H2 and (t & P3 or t & X3):
+        if t & P3 and tid == 7:                 # K-divided 64 x 64 tile on plane pairs (round 6)
+            return "conv_igemmg_kernel<64, 64, 2, 2, 232, 64, 2, false>"
         if t & P3:
             tag, bk = 80 | ((t >> 8) & 1), 16
         else:
@@ -527,12 +529,12 @@ def autotune(g, need_dgrad=True, reps=None):
             w = torch.randn(g.cout * g.k * g.k, g.cin, device=dev) * 0.05
             xq, wq = Planes.from_float(x, kind="h2"), Planes.from_float(w, kind="h2")
             y = torch.empty(g.lout.rows, g.cout, device=dev)
-            cq = [1, 2, 3, 1 | STAGES3, 2 | STAGES3, 3 | STAGES3]
+            cq = [1, 2, 3, 1 | STAGES3, 2 | STAGES3, 3 | STAGES3] + ([7] if g.cin % 64 == 0 else [])
             for t in list(cq):
-                bm = 64 if (t & 0xFF) == 3 else 128
-                bn = {1: 128, 2: 64, 3: 64}[t & 0xFF]
+                bm = 64 if (t & 0xFF) in (3, 7) else 128
+                bn = {1: 128, 2: 64, 3: 64, 7: 64}[t & 0xFF]
                 ntiles = -(-g.lout.rows // bm) * -(-g.cout // bn)
-                nk = g.k * g.k * g.cin // 32
+                nk = g.k * g.k * g.cin // (64 if (t & 0xFF) == 7 else 32)
                 if ntiles < 1024:
                     cq += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
             ftq = best_of(lambda t: conv_fwd(g, xq, wq, None, y, relu=True, tile=t), cq)
@@ -543,12 +545,12 @@ def autotune(g, need_dgrad=True, reps=None):
                 wtq = Planes.from_float(torch.randn(g.cin * g.k * g.k, g.cout, device=dev) * 0.05, kind="h2")
                 dx = torch.empty(g.lin.rows, g.cin, device=dev)
                 tmp_q = _tune_slots(g, outputs=(dx,))
-                cb = [1, 2, 3]
+                cb = [1, 2, 3] + ([7] if g.cout % 64 == 0 else [])
                 for t in list(cb):
-                    bm = 64 if (t & 0xFF) == 3 else 128
-                    bn = {1: 128, 2: 64, 3: 64}[t & 0xFF]
+                    bm = 64 if (t & 0xFF) in (3, 7) else 128
+                    bn = {1: 128, 2: 64, 3: 64, 7: 64}[t & 0xFF]
                     ntiles = -(-g.lin.rows // bm) * -(-g.cin // bn)
-                    nk = g.k * g.k * g.cout // 32
+                    nk = g.k * g.k * g.cout // (64 if (t & 0xFF) == 7 else 32)
                     if ntiles < 1024:
                         cb += [t | (sk << 12) for sk in (1, 2, 3, 4, 5, 6, 8) if nk // sk >= 4]
                 btq = best_of(lambda t: conv_dgrad(g, dyq, wtq, dx, mask=xq, tile=t), cb)
@@ -792,7 +794,7 @@ def _tile(g, tile, default, x=None, y=None):
     """tile_override word: explicit or tuned tile + arithmetic mode flags, derived from the tensors' dtypes"""
     t = (tile or default) | (MATH_BF16 if g.math else 0)
     if _isp(x):                                          # plane operands: 0x200 (the fp32 paths' K-step bit) has no meaning here
-        if (t & 0xFF) in (7, 8):                         # (the K-divided tiles split in registers: fp32 operands only)
+        if (t & 0xFF) == 8:                              # (tile 8 splits in registers: fp32 operands only; tile 7 has a pair reader)
             t = (t & ~0xF0FF) | 3
         return (t & ~(MATH_BF16 | 0x200)) | P3 | (H2 if x.kind == "h2" else 0)
     if getattr(g, "x3", False) and not g.math and not _is16(x):

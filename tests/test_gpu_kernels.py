@@ -1384,10 +1384,23 @@ def test_pairs_only_tensors_of_a_bottleneck_block(K, case):
     # (4) dgrad on pair operands + pair mask against fp64
     dyq = K.Planes.from_float(dy, kind="h2")
     wtq = K.Planes.from_float(wft2.reshape(Ci * k * k, Co), kind="h2")
-    K.conv_dgrad(geom, dyq, wtq, dx_a, mask=actq, tile=(tile & 0xF000) | 3)
     ref = torch.nn.grad.conv2d_input((B, Ci, H, W), w.double(), from_rows(dy.cpu(), B, H, W).double(), stride=1, padding=pad)
     ref = ref * (from_rows(act.cpu(), B, H, W) > 0)
-    assert rel_err(from_rows(dx_a, B, H, W), ref) < 1e-5
+    for t in [(tile & 0xF000) | 3] + ([(tile & 0xF000) | 7] if Co % 64 == 0 else []):     # 4-wave pair tile; K-divided pair tile (round 6)
+        dx_a.fill_(float("nan"))
+        K.conv_dgrad(geom, dyq, wtq, dx_a, mask=actq, tile=t)
+        assert rel_err(from_rows(dx_a, B, H, W), ref) < 1e-5, hex(t)
+    # (5) the K-divided pair tile forward == the 4-wave pair tile's result to fp32 summation order, incl. split-K and the epilogue
+    if Ci % 64 == 0:
+        xq, wq = K.Planes.from_float(xr, kind="h2"), K.Planes.from_float(wf.reshape(Co * k * k, Ci), kind="h2")
+        y3, y7 = torch.empty(R, Co, device=dev), torch.empty(R, Co, device=dev)
+        y_ref = torch.relu(F.conv2d(x.double(), w.double(), bias.double(), padding=pad))
+        K.conv_fwd(geom, xq, wq, br, y3, relu=True, tile=3)
+        for t in (7, 0x2007):
+            y7.fill_(float("nan"))
+            K.conv_fwd(geom, xq, wq, br, y7, relu=True, tile=t)
+            assert rel_err(from_rows(y7, B, H, W), y_ref) < 1e-5, hex(t)
+            assert float((y7 - y3).abs().max()) <= 2e-6 * float(y3.abs().max())
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 20, 24, 1, 1, 3), (2, 256, 128, 18, 22, 3, 2, 2), (1, 128, 256, 17, 23, 3, 1, 1),

@@ -82,6 +82,30 @@ __device__ __forceinline__ void st_out(float* p, size_t o, float v, int io) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// ---- global -> LDS tile loads (LDS-DMA, 1 KiB per wave instruction).  Round 6: issued as `buffer_load_dwordx4 ... lds` -- one
+// 32-bit offset VGPR per lane against an SGPR resource of the tensor, a lane without a source (padding row, channel beyond
+// the tensor) gets an out-of-range offset and the buffer unit returns zeros -- instead of `global_load_lds_dwordx4` with a
+// 64-bit address pair per lane and a select against a zero page.  An ablation of the tower GEMM (tools/dbg_tower_h2.py) had
+// put the ISSUE of these loads, not their latency, at a third of the launch; with the buffer form the tower GEMM takes 90
+// instead of 98 us alone, the K-divided backbone tile 42.0 instead of 43.6 us in the step, the bf16-storage step 4.95 instead
+// of 5.07 ms (bit-identical results).  RADET_BUFLDS=0 builds the former loads.  Tensors are addressed up to 4 GiB - 256 B.
+#ifndef RADET_BUFLDS
+#define RADET_BUFLDS 1
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t radet_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFF00u, 0x00020000);
+}
+// (a macro, not a function template: the host pass cannot substitute the LDS-pointer parameter)
+#if RADET_BUFLDS
+#define radet_lds_load16(base, ok, elem_off, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(radet_rsrc(base), (dst), 16, \
+        (int)((ok) ? (unsigned)((elem_off) * sizeof(*(base))) : 0xFFFFFFFFu), 0, 0, 0)
+#else
+#define radet_lds_load16(base, ok, elem_off, dst) \
+    __builtin_amdgcn_global_load_lds((gptr_t)((ok) ? (const void*)((base) + (elem_off)) : (const void*)(radet_zero_page + (threadIdx.x & 63) * 4)), \
+                                     (dst), 16, 0, 0)
+#endif
+
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
     int l = 0;
 #pragma unroll

@@ -32,6 +32,9 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
         else if (stages == 3) RADET_H2(104, 32, 3);
         else RADET_H2(104, 32, 2);
     } else {
+        if constexpr (WM * WN == 8) {                                // row-interleaved pairs (TAG bit 7): the 8-wave tiles
+            if (tag & 128) { if (tag & 1) RADET_H2(209, 32, 2); else RADET_H2(208, 32, 2); return; }
+        }
         constexpr int STG = 2 * (BM + BN) * 16 * 4;                  // LDS bytes per stage: two planes x 64 bytes per tile row
         if constexpr (3 * STG <= 160 * 1024) {
             if (stages >= 3) { if (tag & 1) RADET_H2(81, 16, 3); else RADET_H2(80, 16, 3); return; }
@@ -43,7 +46,7 @@ static void launch_h2(const ConvArgs& a_in, hipStream_t st, int tag, int bk, siz
 
 bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
                            bool no_tail_split) {
-    if ((tag & 16) && !(tag & 128)) {                                // plane pairs: the 8-wave tiles (+ the 4-wave tiles 1-3)
+    if (tag & 16) {                                                  // plane pairs: the 8-wave tiles (+ the 4-wave tiles 1-3)
         switch (choice) {
             case 1: launch_h2<128, 128, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
             case 2: launch_h2<128, 64, 2, 2, 2>(a, st, tag & ~1, bk, ws_floats, stages, no_tail_split); return true;
@@ -146,10 +149,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
                 const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
-                const void* src = (bok[s][k] && brow[s][k] >= 0)
-                                      ? (const void*)(xh + (size_t)brow[s][k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2))
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf * SUB + s][bi * B_PL]), 16, 0, 0);
+                radet_lds_load16(xh, (bok[s][k] && brow[s][k] >= 0), (size_t)((size_t)brow[s][k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2)), (lptr_t)(&Bs[buf * SUB + s][bi * B_PL]));
             }
         }
 #pragma unroll
@@ -159,10 +159,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
                 const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
                 const int m = p0 + 4 * (blk / CBA) + l_prow;
                 const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                const void* src = (m < p_end && o < a.Cout)
-                                      ? (const void*)(dyh + (size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl)
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf * SUB + s][ins * 512]), 16, 0, 0);
+                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl), (lptr_t)(&As[buf * SUB + s][ins * 512]));
             }
         }
 #pragma unroll
@@ -357,10 +354,7 @@ __global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
                 const int bi = ins - A_INSTR;
                 const int pl = bi / B_Q, blk = (bi % B_Q) * 8 + l_blk;
                 const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
-                const void* src = (bok[k] && brow[k] >= 0 && c < a.Cin)
-                                      ? (const void*)(xh + (size_t)brow[k] * 2 * a.Cin + radet_pair_off(c) + 32 * pl)
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+                radet_lds_load16(xh, (bok[k] && brow[k] >= 0 && c < a.Cin), (size_t)((size_t)brow[k] * 2 * a.Cin + radet_pair_off(c) + 32 * pl), (lptr_t)(&Bs[buf][bi * 512]));
             }
         }
 #pragma unroll
@@ -370,10 +364,7 @@ __global__ __launch_bounds__(256) void conv_wgradq_kernel(const WgradArgs a) {
                 const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
                 const int m = p0 + 4 * (blk / CBA) + l_prow;
                 const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                const void* src = (m < p_end && o < a.Cout)
-                                      ? (const void*)(dyh + (size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl)
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl), (lptr_t)(&As[buf][ins * 512]));
             }
         }
 #pragma unroll

@@ -288,9 +288,7 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
                 const int bi = ins - A_INSTR;
                 const int blk = bi * 8 + l_blk;
                 const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
-                const void* src = (bok[k] && brow[k] >= 0 && c < a.Cin) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
-                                                                        : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+                radet_lds_load16(xh, (bok[k] && brow[k] >= 0 && c < a.Cin), (size_t)((size_t)brow[k] * a.Cin + c), (lptr_t)(&Bs[buf][bi * 512]));
             }
         }
 #pragma unroll
@@ -300,9 +298,7 @@ __global__ __launch_bounds__(256) void conv_wgradh_kernel(const WgradArgs a) {
                 const int blk = ins * 8 + l_blk;
                 const int m = p0 + 4 * (blk / CBA) + l_prow;
                 const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
-                                                            : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * a.ld_dy + o), (lptr_t)(&As[buf][ins * 512]));
             }
         }
 #pragma unroll
@@ -476,9 +472,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
                 const int bi = ins - A_INSTR;
                 const int blk = (bi % B_TAP) * 8 + l_blk;
                 const int c = c0 + 16 * (blk % CBB) + 8 * l_half;
-                const void* src = (bok[k] && brow[k] >= 0) ? (const void*)(xh + (size_t)brow[k] * a.Cin + c)
-                                                           : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 512]), 16, 0, 0);
+                radet_lds_load16(xh, (bok[k] && brow[k] >= 0), (size_t)((size_t)brow[k] * a.Cin + c), (lptr_t)(&Bs[buf][bi * 512]));
             }
         }
 #pragma unroll
@@ -488,9 +482,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9h_kernel(const WgradArgs a) {
                 const int blk = ins * 8 + l_blk;
                 const int m = p0 + 4 * (blk / CBA) + l_prow;
                 const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                const void* src = (m < p_end && o < a.Cout) ? (const void*)(dyh + (size_t)m * a.ld_dy + o)
-                                                            : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * a.ld_dy + o), (lptr_t)(&As[buf][ins * 512]));
             }
         }
 #pragma unroll
@@ -642,10 +634,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
                 const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
-                const void* src = (bok[k] && brow[k] >= 0)
-                                      ? (const void*)(xh + (size_t)brow[k] * 3 * a.Cin + radet_plane_off(c) + 32 * (bi % 3))
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * B_PL]), 16, 0, 0);
+                radet_lds_load16(xh, (bok[k] && brow[k] >= 0), (size_t)((size_t)brow[k] * 3 * a.Cin + radet_plane_off(c) + 32 * (bi % 3)), (lptr_t)(&Bs[buf][bi * B_PL]));
             }
         }
 #pragma unroll
@@ -655,10 +644,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9p_kernel(const WgradArgs a) {
                 const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
                 const int m = p0 + 4 * (blk / CBA) + l_prow;
                 const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                const void* src = (m < p_end && o < a.Cout)
-                                      ? (const void*)(dyh + (size_t)m * 3 * a.ld_dy + radet_plane_off(o) + 32 * pl)
-                                      : (const void*)(radet_zero_page + lane * 4);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 512]), 16, 0, 0);
+                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 3 * a.ld_dy + radet_plane_off(o) + 32 * pl), (lptr_t)(&As[buf][ins * 512]));
             }
         }
 #pragma unroll
@@ -1109,6 +1095,15 @@ static int igemm_impl(const float* x, const float* w, const float* bias, const f
         tag |= 64;
     }
     int choice = tile_override & 0xFF;
+    if (p3 && h2 && ((tile_override >> 19) & 1) && (choice == 5 || choice == 6)) {
+        // 0x80000: row-interleaved plane pairs for the 8-wave tiles (TAG bit 7 with bit 4): one wave load fetches both planes
+        // of 8 tile rows (128 contiguous bytes per row) instead of one plane of 16 -- the launch counts K in channels again
+        // (a pair row is as long as the fp32 row) and its stage is 32 four-byte units
+        Cin *= 2;
+        a.Cin = Cin;
+        if (Cin % 32 != 0) return RADET_ERR_ARG;
+        tag |= 128; bk = 32;
+    }
     if (choice == 7 && p3 && h2) {
         // K-divided 64 x 64 tile on fp16 plane PAIRS (round 6): a pair row has the fp32 row's byte length, so the launch is
         // the fp32 K-divided one (K counted in channels again, 64-channel stages) with the reader's pair flag (TAG bit 7)

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
     constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
-    constexpr int NS = BK / 8;
+    constexpr int NS = ((TAG & 128) && (TAG & 16)) ? 2 : BK / 8;   // K = 8-wide k slices per stage (row-interleaved pairs: two K = 16 slices of a 32-channel group)
     constexpr bool BF16 = (TAG & 2) != 0;                     // TAG bit 0: profiling symbol, bit 1: bf16 math mode
     constexpr bool H16 = (TAG & 4) != 0;                      // bit 2: bf16 storage (a 16-byte slot = 8 bf16 = one MFMA operand)
     // bit 3: fp32 tensors, fp32-accurate products on the bf16 matrix cores: every operand is split into three bf16 planes
@@ -42,7 +42,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     // groups [hi x 32 | lo x 32], 4 bytes per element.
     constexpr bool H2 = (TAG & 64) != 0;
     static_assert(!H2 || X3 || P3, "fp16 hi / lo arithmetic: in-register split (bit 3) or plane pairs (bit 4)");
-    constexpr int NPL = P3 ? (H2 ? 2 : 3) : 1;
+    // bit 7 with bit 4 (round 6): ROW-INTERLEAVED plane pairs.  A stage of the plane-pair tiles is one 32-channel group = 128
+    // contiguous bytes [hi x 32 | lo x 32] of every tile row; fetched plane by plane (two 64-byte pieces per row in two wave
+    // loads) the global -> LDS path runs at its 64-byte-chunk rate, 52-55 GB/s per CU for one 8-wave workgroup per CU, against
+    // 73-84 GB/s for 128-byte chunks (profiles/round3_fill_probe.txt) -- and the tower GEMM's 48 KiB per stage at 52 GB/s are
+    // 0.92 us next to 0.66 us of MFMA issue.  With this bit a wave load fetches 8 rows x 128 bytes (both planes of a row in
+    // one line-sized piece): the loaders and LDS images are those of an fp32 tile with a 32-deep K step (BK = 32: 128-byte
+    // rows, 8 swizzled 16-byte slots), the reader takes slots 2 s + lh (hi) and 4 + 2 s + lh (lo) of K = 16 slice s
+    constexpr bool RI = P3 && (TAG & 128) != 0;
+    static_assert(!RI || (H2 && BK == 32), "row-interleaved pairs: fp16 hi / lo planes, 128-byte tile rows");
+    constexpr int NPLC = P3 ? (H2 ? 2 : 3) : 1;              // planes of an operand (compute side)
+    constexpr int NPL = RI ? 1 : NPLC;                       // plane tiles per LDS stage / loads per row (loader side)
     // bit 5 (with bit 3): the waves divide the K step as well as the tile.  A stage of BK = 16 KD channels is cut into KD
     // k-groups; wave (kg, nh) accumulates ALL BM rows x its BN / WNK columns over k-group kg, and the KD partial tiles of a
     // column group are added through LDS after the K loop.  A wave's operand splits (VALU work) and fragment reads (LDS
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     // per channel: 32-channel groups [hi x 32 | lo x 32]), so a 64-channel stage is the same 256 contiguous bytes per tile row and
     // the fp32 loaders / LDS images are used unchanged; only the reader differs -- wave kg takes the hi and the lo 16-byte slot of
     // ITS 16 channels (group kg / 2, half kg % 2) straight into the MFMA: no operand split, the same two ds_read_b128 per block
-    constexpr bool PQ = (TAG & 128) != 0;
+    constexpr bool PQ = (TAG & 128) != 0 && (TAG & 32) != 0;    // (bit 7 with bit 4 instead of bit 5: row-interleaved pairs, below)
     static_assert(!PQ || (KW && H2 && BK == 64), "pair operands in the K-divided tile: 64-channel stages");
     constexpr int KD = KW ? BK / 16 : 1;                                  // k-groups per stage
     constexpr int WNK = NW / KD;                                          // column groups of waves
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     static_assert(!KW || (X3 && !SK && NW == 4 && KD * WNK == NW && TM == 1 && TN == 1 && TMA * TNA == KD && NSTG >= 2 && NSTG <= 4),
                   "K-divided tile: one 32 x 32 block per wave after the reduction");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-    static_assert(!P3 || BK == 16, "plane rows are laid out in 32-channel groups: one group per K stage");
+    static_assert(!P3 || BK == 16 || RI, "plane rows are laid out in 32-channel groups: one group per K stage");
     // NSTG LDS stages: loads run NSTG - 1 K steps ahead of the MFMAs.  3 stages hide more L2 latency (+8 % on the
     // tower GEMM running alone) but cost LDS occupancy, which loses when dgrad and wgrad kernels share the CUs: used
     // for forward launches only (tile_override 0x20000), chosen per shape by the autotuner
@@ -190,9 +200,28 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     const float* wbase[B_PW];
     unsigned amask[A_PW], wmask[B_PW];
     constexpr bool BMASK = P3 || KW;
+    // BL (round 6, plane-pair tiles): the tile loads as `buffer_load_dwordx4 ... lds` -- a 32-bit offset VGPR per lane against an
+    // SGPR resource of the tensor instead of a 64-bit address pair, padding rows as out-of-range offsets (the buffer returns
+    // zeros: no zero page, no pointer select).  The ablation of the tower GEMM (tools/dbg_tower_h2.py) puts the ISSUE of its 48
+    // LDS-DMA wave loads per stage at a third of the launch: they add to the MFMA time instead of hiding under it
+    constexpr bool BL = RADET_BUFLDS != 0;                  // (every instantiation; RADET_BUFLDS=0 builds the former loads for comparison)
+    __amdgpu_buffer_rsrc_t rs_x, rs_w;
+    unsigned aoffb[A_PW], woffb[B_PW];
+    if constexpr (BL) {
+        // (range 4 GiB - 256 B: the out-of-range marker is offset 0xFFFFFFFF; the launchers refuse tensors beyond that)
+        rs_x = radet_rsrc(P.x);
+        rs_w = radet_rsrc(P.w);
+    }
     int pc0 = 0, pwt = 0;                 // (channel chunk, weight tap) of the stage whose pieces are being issued
     auto set_abase = [&]() {
         pc0 = ld_c0; pwt = wtap;
+        if constexpr (BL) {
+#pragma unroll
+            for (int k = 0; k < A_PW; ++k) {
+                amask[k] = arow[k] >= 0 ? 0xFFFFFFFFu : 0u;
+                aoffb[k] = ((unsigned)(arow[k] & (int)amask[k]) * (unsigned)xld + (unsigned)akq[k]) * 4u;
+            }
+        } else
         if constexpr (BMASK) {
 #pragma unroll
             for (int k = 0; k < A_PW; ++k) {
@@ -204,11 +233,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             }
         }
     };
-    if constexpr (BMASK) {
+    if constexpr (BMASK || BL) {
 #pragma unroll
         for (int k = 0; k < B_PW; ++k) {
             wmask[k] = wp[k] ? 0xFFFFFFFFu : 0u;
             wbase[k] = wp[k] ? wp[k] : radet_zero_page + lane * 4;
+            if constexpr (BL) woffb[k] = wp[k] ? (unsigned)((const char*)wp[k] - (const char*)P.w) : 0u;
         }
     }
     set_abase();
@@ -219,19 +249,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             const int ins = wave + NW * k;
             if (A_FULL || ins < A_INSTR) {
                 // plane rows: 32-channel groups of [hi | mid | lo] x 16 units -> chunk ld_c0 starts at unit 3 * ld_c0
+                if constexpr (BL) {
+                    const unsigned voff = (aoffb[k] + 4u * (unsigned)(NPL * pc0 + p * BK)) | ~amask[k];     // padding row: out of range -> zeros
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(&As[buf][p * BM * BK + ins * 256]), 16, (int)voff, 0, 0, 0);
+                } else {
                 const float* src;
                 if constexpr (BMASK) src = abase[k] + ((unsigned)(NPL * pc0 + p * BK) & amask[k]);
                 else src = arow[k] >= 0 ? P.x + (size_t)arow[k] * xld + NPL * pc0 + akq[k] + p * BK : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][p * BM * BK + ins * 256]), 16, 0, 0);
+                }
             }
         } else {
             constexpr int k = (q - NPL * A_PW) / NPL, p = (q - NPL * A_PW) % NPL;
             const int ins = wave + NW * k;
             if (B_FULL || ins < B_INSTR) {
+                if constexpr (BL) {
+                    const unsigned voff = (woffb[k] + 4u * (unsigned)(pwt * xld + NPL * pc0 + p * BK)) | ~wmask[k];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(&Bs[buf][p * BN * BK + ins * 256]), 16, (int)voff, 0, 0, 0);
+                } else {
                 const float* src;
                 if constexpr (BMASK) src = wbase[k] + ((unsigned)(pwt * xld + NPL * pc0 + p * BK) & wmask[k]);
                 else src = wp[k] ? wp[k] + pwt * xld + NPL * pc0 + p * BK : radet_zero_page + lane * 4;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][p * BN * BK + ins * 256]), 16, 0, 0);
+                }
             }
         }
     };
@@ -310,6 +350,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
     // the in-flight LDS-DMA loads (it cannot prove they target the other buffer) and serialise load and compute.
     const int rswz = (li / RPB) % F4;
     unsigned aaddr[NS], baddr[NS];
+    unsigned aaddr_lo[RI ? NS : 1], baddr_lo[RI ? NS : 1];
     {
         const unsigned a_lds = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((wm * TM * 32 + li) * BK * 4);
         const unsigned b_lds = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)((wn * TN * 32 + li) * BK * 4);
@@ -317,6 +358,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         for (int s = 0; s < NS; ++s) {
             aaddr[s] = a_lds + 16u * (unsigned)((2 * s + lh) ^ rswz);
             baddr[s] = b_lds + 16u * (unsigned)((2 * s + lh) ^ rswz);
+            if constexpr (RI) {                                  // the lo plane's slots of the same row
+                aaddr_lo[s] = a_lds + 16u * (unsigned)((4 + 2 * s + lh) ^ rswz);
+                baddr_lo[s] = b_lds + 16u * (unsigned)((4 + 2 * s + lh) ^ rswz);
+            }
         }
     }
     auto stage = [&](auto bufc, int it) {
@@ -520,8 +565,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         // lockstep): issued in a block after the barrier, the loads of both waves idle the SIMD's matrix pipe together.
         // The pipeline is rotated by one slice: the barrier that ends stage `it` sits in front of the MFMAs of its last
         // slice, whose fragments are in registers already.
-        f32x4 fa[2][NPL][TM], fb[2][NPL][TN];
-        constexpr int NRD = NPL * (TM + TN);
+        f32x4 fa[2][NPLC][TM], fb[2][NPLC][TN];
+        constexpr int NRD = NPLC * (TM + TN);
         constexpr int NT = H2 ? 3 : 6;                         // plane products (MFMA groups) per slice
         // fragment read r of slice s of buffer BUF into fragment set pp: order A hi, B hi, A mid, B mid, A lo, B lo
         auto read_one = [&](auto bufc, auto sc, auto ppc, auto rc) {
@@ -530,6 +575,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             // (h2: the lo plane's reads go B first -- group 1 = hi lo' needs B lo, group 2 = lo hi' A lo: see the waits in slice())
             constexpr int pl = r / (TM + TN), e = (H2 && pl == 1) ? (r % (TM + TN) + TM) % (TM + TN) : r % (TM + TN);
             // (the buffer offset goes into the address register: a ds_read immediate holds 16 bits)
+            if constexpr (RI) {                                  // both planes in the row: another slot, not another tile
+                if constexpr (e < TM) lds_read128<e * RO>(fa[pp][pl][e], (pl ? aaddr_lo[s] : aaddr[s]) + (unsigned)AO);
+                else lds_read128<(e - TM) * RO>(fb[pp][pl][e - TM], (pl ? baddr_lo[s] : baddr[s]) + (unsigned)BO);
+            } else
             if constexpr (e < TM) lds_read128<pl * BM * BK * 4 + e * RO>(fa[pp][pl][e], aaddr[s] + (unsigned)AO);
             else lds_read128<pl * BN * BK * 4 + (e - TM) * RO>(fb[pp][pl][e - TM], baddr[s] + (unsigned)BO);
         };
@@ -539,7 +588,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             constexpr int PP = decltype(ppc)::value;
             constexpr bool LD = decltype(ldc)::value;
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
+            for (int pl = 0; pl < NPLC; ++pl) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(fa[PP][pl][i]));
 #pragma unroll

@@ -90,9 +90,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
             const int ins = wave + k * NW;
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
-                const float* src = (bok[k] && brow[k] >= 0) ? a.x + (size_t)brow[k] * a.Cin + c0 + (lane & 7) * 4
-                                                            : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+                radet_lds_load16(a.x, (bok[k] && brow[k] >= 0), (size_t)((size_t)brow[k] * a.Cin + c0 + (lane & 7) * 4), (lptr_t)(&Bs[buf][bi * 256]));
             }
         }
 #pragma unroll
@@ -102,8 +100,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad9g_kernel(const WgradArgs a
                 const int j = ins * ROWS_A + (ROWS_A == 1 ? 0 : (lane * 4) / BM);
                 const int o = o0 + (lane * 4) % BM;
                 const int m = p0 + j;
-                const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
+                radet_lds_load16(a.dy, (m < p_end && o < a.Cout), (size_t)((size_t)m * a.ld_dy + o), (lptr_t)(&As[buf][ins * 256]));
             }
         }
 #pragma unroll
@@ -337,9 +334,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
             if (ins >= A_INSTR && ins < N_INSTR) {
                 const int bi = ins - A_INSTR;
                 const int c = c0 + (lane * 4) % BN;
-                const float* src = (bok[k] && brow[k] >= 0 && c < a.Cin) ? a.x + (size_t)brow[k] * a.Cin + c
-                                                                         : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&Bs[buf][bi * 256]), 16, 0, 0);
+                radet_lds_load16(a.x, (bok[k] && brow[k] >= 0 && c < a.Cin), (size_t)((size_t)brow[k] * a.Cin + c), (lptr_t)(&Bs[buf][bi * 256]));
             }
         }
 #pragma unroll
@@ -348,8 +343,7 @@ __device__ __forceinline__ void wgradg_body(const WgradArgs& a, int id) {
             if (ins < A_INSTR) {
                 const int m = p0 + ins * RA + (lane * 4) / BM;
                 const int o = o0 + (lane * 4) % BM;
-                const float* src = (m < p_end && o < a.Cout) ? a.dy + (size_t)m * a.ld_dy + o : radet_zero_page + lane * 4;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(&As[buf][ins * 256]), 16, 0, 0);
+                radet_lds_load16(a.dy, (m < p_end && o < a.Cout), (size_t)((size_t)m * a.ld_dy + o), (lptr_t)(&As[buf][ins * 256]));
             }
         }
 #pragma unroll

@@ -149,6 +149,8 @@ class Engine:
     # plane-operand tower tiles with three LDS stages (144 KiB; experiment switch)
     tower_stages = K.STAGES3 if os.environ.get("RADET_TOWER_STAGES3", "0") == "1" else 0
     tower_tile = int(os.environ.get("RADET_TOWER_TILE", "6"))       # 6: 256 x 128 (one workgroup per CU), 5: 128 x 128 (two)
+    if os.environ.get("RADET_TOWER_ROWPAIRS", "0") == "1":          # (K.ROWPAIRS: 128-byte pieces, both planes of a row per load)
+        tower_tile |= 0x80000
 
     def _ttile(self, c, bwd=False, tag=True, pair=True):
         """tile_override of a tower conv launch + profiling tag.  Forward: a fixed, measured tile with a 32-deep K step

@@ -129,6 +129,8 @@ def _igemm_key(t, x):
     if t & H2 and (t & P3 or t & X3):
         if t & P3 and tid == 7:                 # K-divided 64 x 64 tile on plane pairs (round 6)
             return "conv_igemmg_kernel<64, 64, 2, 2, 232, 64, 2, false>"
+        if t & P3 and t & ROWPAIRS and tid in (5, 6):
+            return f"conv_igemmg_kernel<{_TILES[tid]}, {208 | ((t >> 8) & 1)}, 32, 2, false>"
         if t & P3:
             tag, bk = 80 | ((t >> 8) & 1), 16
         else:
@@ -601,6 +603,7 @@ STORE_BF16, OUT_F32 = 0x800, 0x10000      # bf16 tensors in HBM / fp32 output fr
 P3 = 0x2000000                            # x / w arrive as plane tensors (bf16 triples, or fp16 pairs with H2); fp32 outputs
 P3_BK8 = 0x4000000                        # ... with a K step of 16 instead of 32 channels
 H2 = 0x8000000                            # fp16 hi / lo arithmetic (with X3 or P3): 3 f16 MFMAs per K = 16 step, needs amax slots
+ROWPAIRS = 0x80000                        # plane-pair operands, 8-wave tiles: both planes of a tile row in one 128-byte piece per load
 MASKQ = 0x10000000                        # the launch's ReLU mask tensor is an fp16 plane-pair tensor (round 6: pairs-only activations)
 
 

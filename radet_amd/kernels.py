@@ -202,6 +202,12 @@ class ConvGeom:
         self.lin, self.cin, self.cout, self.k, self.stride, self.pad = lin, cin, cout, k, stride, pad
         self.lout = lin.conv_out(k, stride, pad)
         self.B = lin.B
+        # the kernels' tile loads address a tensor with 32-bit byte offsets (buffer_load ... lds, round 6): 4 GiB - 256 B per tensor
+        # (5.7x the largest tensor of the reference config at samples_per_gpu = 16: 314 MB)
+        big = max(lin.rows * cin, self.lout.rows * cout) * 4
+        if big >= (1 << 32) - 256:
+            raise _lib.RadetHipError(f"conv geometry {cin}->{cout} k{k} over {lin.rows} rows: a {big / 2 ** 30:.1f} GiB activation tensor "
+                                     "exceeds the 4 GiB the MI355X kernels address per tensor; use a smaller batch per GPU")
         f, b = [], []
         for (hi, wi), (ho, wo), io, oo in zip(lin.hw, self.lout.hw, lin.offsets, self.lout.offsets):
             f.append((hi, wi, ho, wo, io, oo))

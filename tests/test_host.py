@@ -76,6 +76,19 @@ def test_tape_thunks_are_current_and_replay_runs_host_calls():
     assert t.replays == 1 and t.ops[0].args[1] == 0
 
 
+def test_conv_geometry_refuses_tensors_beyond_the_kernels_address_range():
+    """The tile loads address a tensor with 32-bit byte offsets (buffer_load ... lds): a geometry whose activation tensor
+    would exceed 4 GiB is refused when it is built, not mis-addressed at run time."""
+    from radet_amd import _lib
+    from radet_amd.kernels import ConvGeom, Levels
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    ConvGeom(Levels([(120, 160)], 16), 256, 256, 1, 1, 0)                     # the reference config's largest: 314 MB
+    with pytest.raises(_lib.RadetHipError, match="4 GiB"):
+        ConvGeom(Levels([(800, 1344)], 16), 256, 64, 1, 1, 0)                 # 17.6 GB
+
+
 def test_host_only_entry_points():
     """Pure host arithmetic exported by the library (no device access)."""
     from radet_amd import _lib

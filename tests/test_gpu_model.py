@@ -500,11 +500,13 @@ def _oracle_run(dtype, img, gt_b, gt_l, p2g, pw, relu_hook=None, depth=50):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("case", ["r50_640x480_bs2", "r50_640x480_bs4", "r101_800x800_bs2"])
+@pytest.mark.parametrize("case", ["r50_640x480_bs2", "r50_640x480_bs4", "r101_800x800_bs2", "r101_200x264_bs2"])
 def test_gradients_vs_fp64_oracle(golden, case):
     """Whole-model gradients of every trainable parameter against the oracle run in fp64, the yardstick being the SAME
     oracle in fp32 (torch CPU) -- at B = 2 640 x 480 (the reference's golden targets), and, round 6, at the FULL sizes of
-    BASELINE configs[1] (r50, 640 x 480, bs 4: the bench's batch) and configs[4] (R101, 800 x 800, bs 2).
+    BASELINE configs[1] (r50, 640 x 480, bs 4: the bench's batch) and configs[4] (R101, 800 x 800, bs 2), and on the odd
+    sizes of tests/test_gpu_configs.py::test_train_step_vs_oracle (R101, 200 x 264: feature maps 25 x 33 ... 2 x 3, tiles the
+    tuner picks on the spot).
     A ReLU whose pre-activation lies within rounding of zero is decided differently by two correct fp32 implementations, and
     one flipped mask moves a whole row of a weight gradient (why tests/_grads.py accepts 3e-3 per parameter against an fp32
     reference).  Here the discrete part is taken out: the fp64 oracle runs once with its own masks -- every element where
@@ -519,6 +521,10 @@ def test_gradients_vs_fp64_oracle(golden, case):
         B, H, W = 2, 480, 640
         img = synth.synth_images(0, 2)
         gt_b, gt_l, p2g, pw = targets(golden)
+    elif "200x264" in case:
+        from test_gpu_configs import batch
+        B, H, W = 2, 200, 264
+        img, gt_b, gt_l, p2g, pw = batch(H, W, B)                 # (one image of it has no gts)
     else:
         from test_gpu_properties import _synth_batch
         B, H, W = (4, 480, 640) if depth == 50 else (2, 800, 800)

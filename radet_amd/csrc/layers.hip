@@ -406,17 +406,22 @@ extern "C" int radet_stem_wgrad(const float* img_nchw, const float* ds, float* s
 // ------------------------------------------------------------------------------------------ fold / unfold
 // fold: for every conv in the table, s[o] = gamma*rsqrt(var+eps) (1 without BN):
 //   wf[o][t][c] = s[o] * w[o][c][t] ; wft[c][t][o] = same value ; bias_f[o] = beta - mean*s | conv bias | 0
-// One work item = (o-tile of 16, c-tile of 32): the OIHW slab [16][32*KT] is read with contiguous runs,
-// transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
+// One work item = (o-tile of 32, c-tile of 32 * (9 / KT) channels): the OIHW slab [32][c-tile * KT] (up to 288 floats per output
+// channel) is read with contiguous runs, transposed through LDS and written as contiguous runs of both OHWI and [c][t][o].
+// (Round 6: a 1 x 1 conv's item used to be 32 x 32 weights = 4 KiB per load -> barrier -> store -> store round, which left the
+// pass bound by those round trips -- 236 us for 100 MB read + 200 MB written -- while it shared the device with the frozen part of
+// the forward pass; skipping the fold altogether made the step 0.16 ms shorter.  Items of up to 32 x 288 whatever the taps.)
 #define FOLD_TO 32
 #define FOLD_TC 32
+#define FOLD_UNR 8
 // folded weight store: element `col` of row `row` (row length ld): fp32, bf16 (w16 = 1) or bf16 plane triple (w16 = 2:
 // rows of ld / 32 groups [hi | mid | lo] x 32 channels, see common.h; ld % 32 == 0)
-__device__ __forceinline__ void stw(float* p, size_t row, int col, int ld, float v, int w16, float s = 1.f, float s2 = 2048.f) {
+__device__ __forceinline__ void stw(float* p, size_t row_, int col, int ld, float v, int w16, float s = 1.f, float s2 = 2048.f) {
+    const unsigned row = (unsigned)row_;  // (a conv's folded weights are far below 2^31 elements: 32-bit offsets)
     if (w16 == 3) {                       // fp16 plane pair (common.h "h2"), scaled by the conv's power of two
         unsigned h, l;
         radet_split2(v, 0.f, s, s2, h, l);
-        unsigned short* q = reinterpret_cast<unsigned short*>(p) + row * 2 * (size_t)ld + radet_pair_off(col);
+        unsigned short* q = reinterpret_cast<unsigned short*>(p) + (row * 2u * (unsigned)ld + (unsigned)radet_pair_off(col));
         q[0] = (unsigned short)(h & 0xFFFFu);
         q[32] = (unsigned short)(l & 0xFFFFu);
     } else if (w16 == 2) {
@@ -424,12 +429,12 @@ __device__ __forceinline__ void stw(float* p, size_t row, int col, int ld, float
         const float r = v - __uint_as_float(h);
         const unsigned m = __float_as_uint(r) & 0xFFFF0000u;
         const unsigned l = __float_as_uint(r - __uint_as_float(m));
-        unsigned short* q = reinterpret_cast<unsigned short*>(p) + row * 3 * (size_t)ld + radet_plane_off(col);
+        unsigned short* q = reinterpret_cast<unsigned short*>(p) + (row * 3u * (unsigned)ld + (unsigned)radet_plane_off(col));
         q[0] = (unsigned short)(h >> 16);
         q[32] = (unsigned short)(m >> 16);
         q[64] = (unsigned short)(l >> 16);
-    } else if (w16) reinterpret_cast<__bf16*>(p)[row * ld + col] = (__bf16)v;
-    else p[row * ld + col] = v;
+    } else if (w16) reinterpret_cast<__bf16*>(p)[row * (unsigned)ld + (unsigned)col] = (__bf16)v;
+    else p[row * (unsigned)ld + (unsigned)col] = v;
 }
 __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restrict__ table) {
     const RadetConvDesc d = table[blockIdx.y];
@@ -460,11 +465,12 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             if (d.wft) stw(d.wft, (size_t)c * KT + t, d.wft_off + o, d.wft_ld ? d.wft_ld : d.cout, v, d.w16, ps, ps2);
         }
     } else {
-        const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + FOLD_TC - 1) / FOLD_TC;
+        const int TC = FOLD_TC * (9 / KT);                 // channels per item: TC * KT <= 288 floats per output channel
+        const int tiles_o = (d.cout + FOLD_TO - 1) / FOLD_TO, tiles_c = (d.cin + TC - 1) / TC;
         const int ld_t = d.wft_ld ? d.wft_ld : d.cout;
         for (int item = blockIdx.x; item < tiles_o * tiles_c; item += gridDim.x) {
-            const int o0 = (item / tiles_c) * FOLD_TO, c0 = (item % tiles_c) * FOLD_TC;
-            const int nc = min(FOLD_TC, d.cin - c0), no = min(FOLD_TO, d.cout - o0);
+            const int o0 = (item / tiles_c) * FOLD_TO, c0 = (item % tiles_c) * TC;
+            const int nc = min(TC, d.cin - c0), no = min(FOLD_TO, d.cout - o0);
             const int run = nc * KT;                      // contiguous floats per output channel
             __syncthreads();
             if (tid < FOLD_TO) {
@@ -473,19 +479,26 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
                 if (d.bn_gamma && o < d.cout) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
                 ssc[tid] = s;
             }
-            for (int i0 = tid; i0 < no * run; i0 += 4 * 256) {           // 4 loads in flight per thread
-                float v[4];
+            // (index arithmetic: quotients by the item's run-time extents through a float reciprocal -- exact for these ranges
+            // (i < 9216, divisors <= 288: the error of (i + 0.5) * (1 / n) is far below the 0.5 / n margin) -- and 32-bit offsets:
+            // seven integer divisions and the 64-bit address products per weight were most of this kernel's time)
+            const float inv_run = 1.0f / (float)run, inv_nc = 1.0f / (float)nc, inv_no = 1.0f / (float)no, inv_kt = 1.0f / (float)KT;
+            auto fdiv = [](int i, float inv) { return (int)(((float)i + 0.5f) * inv); };
+            const float* const wsrc = d.w + ((size_t)o0 * d.cin + c0) * KT;          // row oo of the slab: + oo * cin * KT
+            const unsigned row_in = (unsigned)d.cin * (unsigned)KT;
+            for (int i0 = tid; i0 < no * run; i0 += FOLD_UNR * 256) {    // FOLD_UNR loads in flight per thread
+                float v[FOLD_UNR];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < FOLD_UNR; ++u) {
                     const int i = min(i0 + 256 * u, no * run - 1);
-                    const int oo = i / run, k = i - oo * run;               // k = c_local*KT + t
-                    v[u] = d.w[((size_t)(o0 + oo) * d.cin + c0) * KT + k];
+                    const int oo = fdiv(i, inv_run), k = i - oo * run;      // k = c_local*KT + t
+                    v[u] = wsrc[(unsigned)oo * row_in + (unsigned)k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < FOLD_UNR; ++u) {
                     const int i = i0 + 256 * u;
                     if (i < no * run) {
-                        const int oo = i / run, k = i - oo * run;
+                        const int oo = fdiv(i, inv_run), k = i - oo * run;
                         tile[oo][k] = v[u];
                     }
                 }
@@ -493,8 +506,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             __syncthreads();
             // OHWI: wf[o][t][c0 + cl]  (runs of nc floats)
             for (int i = tid; i < no * run; i += 256) {
-                const int oo = i / run, r = i - oo * run;
-                const int t = r / nc, cl = r - t * nc;
+                const int oo = fdiv(i, inv_run), r = i - oo * run;
+                const int t = fdiv(r, inv_nc), cl = r - t * nc;
                 const float v = tile[oo][cl * KT + t] * ssc[oo];
                 wmax = fmaxf(wmax, fabsf(v));
                 stw(d.wf, (size_t)(o0 + oo) * KT + t, c0 + cl, d.cin, v, d.w16, ps, ps2);
@@ -503,8 +516,8 @@ __global__ __launch_bounds__(256) void fold_kernel(const RadetConvDesc* __restri
             // [c][t][o0 + oo]  (runs of no floats)
             if (d.wft) {
                 for (int i = tid; i < no * run; i += 256) {
-                    const int oo = i % no, r = i / no;      // r = cl*KT + t
-                    const int cl = r / KT, t = r - cl * KT;
+                    const int r = fdiv(i, inv_no), oo = i - r * no;      // r = cl*KT + t
+                    const int cl = fdiv(r, inv_kt), t = r - cl * KT;
                     stw(d.wft, (size_t)(c0 + cl) * KT + t, d.wft_off + o0 + oo, ld_t, tile[oo][r] * ssc[oo], d.w16, ps, ps2);
                 }
             }
@@ -541,9 +554,8 @@ __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __r
     const RadetConvDesc d = table[blockIdx.y];
     // (the other convs' w_amax slots are raised by fold_kernel itself).  w_l1 (optional): the largest L1 norm of a folded
     // output channel, max_o sum_{c,t} |wf[o][t][c]| -- |conv output| <= amax(x) * that: the bound an epilogue that writes
-    // fp16 plane pairs scales them with (conv_common.h).  One workgroup sums a whole channel in a fixed order.
+    // fp16 plane pairs scales them with (conv_common.h).  One wave sums a whole channel in a fixed order.
     const int K = d.cin * d.kh * d.kw;                         // OIHW: K contiguous weights per output channel
-    __shared__ float red[4];
     if (d.w_l1t) {
         // largest L1 norm of an input channel, max_c sum_{o,t} |wf[o][t][c]|: bounds the dgrad's output (its GEMM sums over
         // o and t).  A workgroup owns 64 consecutive channels: thread (rg, cl) sums rows o = rg, rg + 4, ... of channel cl --
@@ -572,25 +584,30 @@ __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __r
         radet_amax_publish(l1t, reinterpret_cast<unsigned*>(d.w_l1t));
     }
     if (d.w_amax == nullptr || (d.w16 != 3 && !d.wfq && !d.w_l1)) return;
+    // One WAVE per output channel (round 6; a workgroup per channel with two barriers each made cout / 32 dependent load ->
+    // reduce -> barrier rounds per workgroup: 64 of them for a 2048-channel conv, the 102 us of this pass), its K weights in
+    // a fixed order: lane l sums k = l, l + 64, ..., then the xor butterfly -- the same sum in every run.
     float m = 0.f, l1max = 0.f;
-    for (int o = blockIdx.x; o < d.cout; o += gridDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = blockIdx.x * 4 + wave; o < d.cout; o += gridDim.x * 4) {
         float s = 1.f;
         if (d.bn_gamma) s = d.bn_gamma[o] * (1.0f / sqrtf(d.bn_var[o] + d.eps));
         const float* w = d.w + (size_t)o * K;
         float mo = 0.f, so = 0.f;
-        for (int k = threadIdx.x; k < K; k += 256) {
-            const float v = fabsf(w[k] * s);                   // (the product fold_kernel stores)
-            mo = fmaxf(mo, v);
-            so += v;
+        for (int k0 = lane; k0 < K; k0 += 64 * 8) {              // 8 loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = w[min(k0 + 64 * u, K - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + 64 * u < K) {
+                    const float a = fabsf(v[u] * s);            // (the product fold_kernel stores)
+                    mo = fmaxf(mo, a);
+                    so += a;
+                }
         }
         m = fmaxf(m, mo);
-        if (d.w_l1) {                                           // (uniform)
-            so = wave_sum(so);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = so;
-            __syncthreads();
-            l1max = fmaxf(l1max, (red[0] + red[1]) + (red[2] + red[3]));
-        }
+        if (d.w_l1) l1max = fmaxf(l1max, wave_sum(so));           // (uniform)
     }
     if (d.w16 == 3 || d.wfq) radet_amax_publish(m, reinterpret_cast<unsigned*>(d.w_amax));
     if (d.w_l1) radet_amax_publish(l1max, reinterpret_cast<unsigned*>(d.w_l1));
@@ -599,8 +616,8 @@ __global__ __launch_bounds__(256) void fold_amax_kernel(const RadetConvDesc* __r
 extern "C" int radet_fold_weights(const RadetConvDesc* table_dev, int nconv, void* stream) {
     if (nconv <= 0) return RADET_OK;
     hipLaunchKernelGGL(fold_amax_zero_kernel, dim3(nconv), dim3(RADET_AMAX_WORDS), 0, (hipStream_t)stream, table_dev, nconv);
-    hipLaunchKernelGGL(fold_amax_kernel, dim3(32, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
-    hipLaunchKernelGGL(fold_kernel, dim3(96, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
+    hipLaunchKernelGGL(fold_amax_kernel, dim3(64, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
+    hipLaunchKernelGGL(fold_kernel, dim3(128, nconv), dim3(256), 0, (hipStream_t)stream, table_dev);
     return radet_check_launch();
 }
 

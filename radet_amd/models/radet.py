@@ -5,7 +5,6 @@ import weakref
 from collections import OrderedDict
 from functools import reduce
 
-import numpy as np
 import torch
 import torch.distributed as dist
 from torch import nn

@@ -2,7 +2,6 @@
 radet/models/dense_heads/{anchor_head.py:33-170, atss_head.py:26-145,325-387, radet_head.py:17-392}.
 The class owns parameters / config objects and exposes the reference's methods; forward, loss and
 get_bboxes run as HIP kernels through the detector runtime."""
-import torch
 from torch import nn
 
 from ..core import build_anchor_generator, build_assigner, build_bbox_coder, build_sampler

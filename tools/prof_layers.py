@@ -3,7 +3,7 @@ shape, microseconds, TFLOP/s.  python tools/prof_layers.py [fwd|bwd|wgrad]"""
 import os, sys, collections
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import bench
 from radet_amd import kernels as K
 from radet_amd.models import build_detector

@@ -358,3 +358,18 @@ def test_label_assignment_refuses_anchor_generators_it_does_not_model():
         with pytest.raises(NotImplementedError):
             LabelAssignment(adapt_positive_num=True, anchor_generator_cfg=bad)
         LabelAssignment(adapt_positive_num=False, anchor_generator_cfg=bad)      # unused without adapt_positive_num, as in the reference
+
+
+def test_fold_kernel_float_reciprocal_quotients_are_exact():
+    """radet_amd/csrc/layers.hip fold_kernel (round 6) takes its index quotients as (int)((i + 0.5f) * (1.0f / n)) instead of
+    integer divisions: i < 32 * 288 (elements of one work item), n <= 288 (run-time extents of the item).  Exact over that
+    whole range, also when the reciprocal is a few ulps off (a hardware rcp)."""
+    i = np.arange(0, 32 * 288, dtype=np.int64)
+    for n in range(1, 289):
+        inv = np.float32(1.0) / np.float32(n)
+        for d in (-2, 0, 2):
+            invd = inv
+            for _ in range(abs(d)):
+                invd = np.nextafter(invd, np.float32(np.inf if d > 0 else -np.inf), dtype=np.float32)
+            q = ((i.astype(np.float32) + np.float32(0.5)) * invd).astype(np.int64)
+            assert np.array_equal(q, i // n), (n, d)

@@ -195,7 +195,10 @@ int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbi
 /* ... with amax slots: flags +0x1000 = fp16 hi / lo arithmetic (see RadetScales; sc->x_amax = the slot of dy, sc->w_amax = the
  * slot of x, both required): fp32 tensors split in registers with the one-tap tiles (bits 4-5, 7, 10-11 as for 0x100), or,
  * with +0x200, dy rows [2][ld_dy] / x rows [2][Cin] fp16 plane pairs (3x3 convs, Cin % 32 == 0, ld_dy % 32 == 0:
- * conv_wgrad9q_kernel, 128 output x 32 input channels x 9 taps per workgroup). */
+ * conv_wgrad9q_kernel, 128 output x 32 input channels x 9 taps per workgroup).  +0x2000 (with +0x200, 3x3): the gather table
+ * is that of a unit-stride conv with padding 1 -- tap (r, q) of pixel m reads what tap (r, 1) of pixel m + q - 1 reads, or
+ * padding -- and the nine taps take shifted windows of three row segments in LDS instead of nine gathered tiles
+ * (conv_wgrad9r_kernel; the same sums in the same order: bit-identical to the launch without the flag). */
 int radet_conv2d_wgrad_s(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                          int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream,
                          const RadetScales* sc);

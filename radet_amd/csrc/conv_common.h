@@ -106,6 +106,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t radet_rsrc(const void* base) {
                                      (dst), 16, 0, 0)
 #endif
 
+// The barrier of a software-pipelined K loop: the bare instruction behind the loop's own waits.  `__syncthreads()` is a
+// workgroup-scope fence + s_barrier, and for the fence the compiler drains EVERY outstanding memory operation in front of it
+// (`s_waitcnt vmcnt(0) lgkmcnt(0)`) -- directly behind a hand-placed `s_waitcnt vmcnt(N)` that was meant to leave the newest
+// stages' tile loads in flight.  The 3- and 4-stage pipelines of rounds 3-5 therefore ran as 2-stage ones with idle LDS
+// ("a third stage changes nothing"); found in round 6 in the ISA of an NSTG = 3 instantiation.
+// Contract of the caller: (1) it has waited for the tile loads it is about to publish (vmcnt) -- an LDS-DMA load has written
+// its LDS bytes when the counter drops; (2) no LDS read of the buffer that will be refilled behind the barrier is outstanding
+// (lgkmcnt(0) here: the fragment reads are consumed before the barrier in every loop); (3) the LDS accesses around it are
+// volatile inline asm / side-effecting builtins, which the compiler does not move across the (side-effecting) barrier builtin;
+// the empty asm statements keep plain memory accesses on their side as well.
+__device__ __forceinline__ void radet_pipe_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int find_seg(const RadetSegs& s, int m) {
     int l = 0;
 #pragma unroll

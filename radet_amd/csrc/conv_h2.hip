@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+        if (it + 1 < nIt && (!RADET_P3_DBG || !(a.dbg & 1))) issue_stage(it + 1, buf ^ 1);    // (ablation: RADET_DBG_WGRAD bits 1 / 2 / 4)
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
         const unsigned ab = a_thr + (unsigned)(buf * SUB + s) * (2 * A_PL * 2), bb = b_thr + (unsigned)(buf * SUB + s) * (KT * 2 * B_PL * 2);
@@ -219,6 +219,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
             if (t < ntap) {                                      // uniform per wave
                 if (t + 1 < ntap) {
                     if constexpr (t + 1 < NTAP) {
+                        if (!RADET_P3_DBG || !(a.dbg & 4))
                         static_for<0, 2>([&](auto pc) {
                             constexpr int pl = decltype(pc)::value;
                             lds_read_tr16<((t + 1) * 2 + pl) * B_PL * 2>(bl[pp ^ 1][pl], bb);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
                     asm volatile("" : "+v"(bl[pp][pl])); asm volatile("" : "+v"(bh[pp][pl]));
                     bf[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(bl[pp][pl], bh[pp][pl], 0, 1, 2, 3, 4, 5, 6, 7));
                 }
-                mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
+                if (!RADET_P3_DBG || !(a.dbg & 2)) mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -253,6 +254,249 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
             for (int p = 0; p < BP; ++p) {
                 const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
                 bsum += radet_pair_value(ap[e], ap[A_PL + e]);
+            }
+        }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum * sdy.inv;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        if (t < ntap) {
+            h2_combine(acc[t], acc1[t], sdy.inv, sxx.inv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + og * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < a.Cout) out[((size_t)o * KT + tap0 + t) * a.Cin + c] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, pairs, x as shifted windows
+// conv_wgrad9q_kernel for unit-stride 3 x 3 convs with padding 1 (round 6).  There the x tile of a 16-pixel stage is nine gathered
+// copies of (almost) the same rows -- tap (r, q) of pixel m reads the row that tap (r, 1) of pixel m + q - 1 reads, unless
+// column(m) + q - 1 leaves the image, where the tap is padding -- and every tile arrives as 64-byte pieces (one plane of one
+// 32-channel group of one pixel): 26 wave loads = 416 half cache lines per stage.  That kernel is bound by the NUMBER of those
+// requests, not by their bytes or by the matrix pipe (0.34 of it): a first version of this kernel that fetched 15 instead of 26
+// KiB per stage, but the x part in 32-byte pieces, was no faster.  Here everything arrives as whole lines:
+//   x   per tap ROW r ONE segment of 18 pixels -- rows g(m - 1 .. m + 16, tap (r, 1)) -- each pixel as the 128 contiguous
+//       bytes [hi x 32 | lo x 32] of its 32-channel group: 54 lines (7 wave loads) per stage.  Tap (r, q) reads the window that
+//       starts q pixels in: a ds_read_b64_tr_b16 takes a per-lane address, so a window is the same read 128 q bytes further on.
+//   dy  each pixel as the 512 contiguous bytes of the tile's four 32-channel groups: 64 lines (8 wave loads) per stage.
+// 118 lines instead of 416 half lines.  An LDS-DMA wave load writes 1 KiB lane-linearly, so the pixel pitch is 128 / 512 bytes
+// -- a multiple of the 256-byte bank row: the 16-byte slots of a pixel are XOR-swizzled by its index on the SOURCE side (x:
+// the plane bit by bit 1 of the pixel slot; dy: slot bits 2-3 by the pixel's low bits) so that the four pixels of a
+// transposing read fall into different banks; the readers apply the same XOR (a per-lane constant).
+// Where a tap is padding although its neighbour's row exists (q = 0 at column 0, q = 2 at the last column: the window would
+// deliver the end of the previous / start of the next image row) the operand's pixel is zeroed in registers: two table
+// look-ups per pixel and stage (taps (1, 0) and (1, 2): -1 there and only there), one ballot, 16-bit masks over the packed
+// fragment, built on the scalar unit -- only in stages that contain such a pixel (wave-uniform branch).  Same products in the
+// same order as conv_wgrad9q_kernel: bit-identical results (tests/test_gpu_kernels.py).
+template <int SUB>
+__global__ __launch_bounds__(512) void conv_wgrad9r_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
+    constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
+    constexpr int A_EL = BP * 256;                          // fp16 elements of the dy image: 16 pixels x 512 bytes
+    constexpr int A_INSTR = 8;                              // wave loads of it (two pixels each)
+    constexpr int XPX = 18, B_UNITS = 3 * XPX;              // pixels per tap-row segment; 128-byte pixel units of the x image: 54
+    constexpr int B_INSTR = (B_UNITS + 7) / 8;              // 7 wave loads (eight pixel units each)
+    constexpr int B_EL = B_INSTR * 512;                     // fp16 elements of the x image (7 KiB)
+    constexpr int ROWB = XPX * 128;                         // bytes per tap-row segment
+    static_assert(A_INSTR == NW && B_INSTR <= NW && ROWB % 256 == 0, "one dy and at most one x load per wave; segments start on a bank row");
+    // (256-byte alignment: the readers' XORs and the bank analysis above assume images that start on a bank row)
+    __shared__ __attribute__((aligned(256))) unsigned short As[2 * SUB][A_EL];
+    __shared__ __attribute__((aligned(256))) unsigned short Bs[2 * SUB][B_EL];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = wave & 3, tg = wave >> 2;                // output-channel group, tap group (0: taps 0-4, 1: taps 5-8)
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);    // (the channel tiles of one pixel split next to each other on one XCD)
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + SUB * BP - 1) / (SUB * BP) : 0;
+
+    // this lane's share of the wave's x load: pixel unit 8 wave + lane / 8 = (tap row, pixel slot), LDS slot lane % 8 of its 128
+    // bytes <- source slot (lane % 8) ^ 4 [pixel slot bit 1]  (slot = plane * 4 + 16-channel block * 2 + 8-channel half)
+    const int xU = 8 * wave + (lane >> 3);
+    const int xr = xU / XPX, xpx = xU - xr * XPX;
+    const bool xuse = xU < B_UNITS;
+    const int xtab = (xr * 3 + 1) * a.Mp;                   // tap (r, 1) of the segment's tap row (table offsets: [9][Mp] ints)
+    const unsigned xcol = (unsigned)((c0 >> 5) * 64 + (((lane & 7) ^ ((xpx & 2) << 1)) << 3));     // element offset inside a pair row
+    const int mtab = ((lane & 16) ? 5 : 3) * a.Mp;          // padding masks: lanes 0-15 tap (1, 0) of the stage's pixels, lanes 16-31 tap (1, 2)
+    auto xrow_of = [&](int p0) {                             // source row of this lane's unit for a stage that starts at pixel p0, or -1
+        const int m = p0 + xpx - 1;
+        const int r = a.rowtab[xtab + (m < 0 ? 0 : (m < a.Mp ? m : a.Mp - 1))];
+        return (xuse && m >= 0 && m < a.M) ? r : -1;
+    };
+    // ... and of its dy load: pixel 2 wave + lane / 32, LDS slot lane % 32 of its 512 bytes <- source slot (lane % 32) ^ (pixel % 4) << 2
+    // (slot = 32-channel group * 8 + plane * 4 + 16-channel block * 2 + 8-channel half)
+    const int ypx = 2 * wave + (lane >> 5);
+    const int yslot = (lane & 31) ^ ((ypx & 3) << 2);
+    const bool yuse = o0 + 32 * (yslot >> 3) + 16 * ((yslot >> 1) & 1) + 8 * (yslot & 1) < a.Cout;
+    const unsigned ycol = (unsigned)((o0 >> 5) * 64 + yslot * 8);
+    int brow[SUB], vmn[SUB];
+#pragma unroll
+    for (int s = 0; s < SUB; ++s) { brow[s] = xrow_of(p_begin + s * BP); vmn[s] = -1; }
+    auto issue_stage = [&](int it, int buf) {                // order: x image, dy image, then the look-ups of later stages
+        // (brow was fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: one free wait here
+        // instead of one in front of the load that consumes it, see conv_wgrad9q_kernel)
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) asm volatile("" : "+v"(brow[s]));
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            const int p0 = p_begin + (it * SUB + s) * BP;
+            if (wave < B_INSTR)                                  // (uniform)
+                radet_lds_load16(xh, (brow[s] >= 0), (size_t)((size_t)brow[s] * 2 * a.Cin + xcol), (lptr_t)(&Bs[buf * SUB + s][wave * 512]));
+            const int m = p0 + ypx;
+            radet_lds_load16(dyh, (yuse && m < p_end), (size_t)((size_t)m * 2 * a.ld_dy + ycol), (lptr_t)(&As[buf * SUB + s][wave * 512]));
+            const int pm = p0 + (lane & 15);
+            vmn[s] = a.rowtab[mtab + (pm < a.Mp ? pm : a.Mp - 1)];      // this stage's padding masks (used when the stage is computed)
+            brow[s] = xrow_of(p0 + SUB * BP);                // the next stage's rows
+        }
+    };
+
+    constexpr int NTAP = 5;                                  // accumulator pairs per wave (tap group 1 leaves the last one idle)
+    f32x16 acc[NTAP], acc1[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acc1[t][r] = 0.f; }
+    const unsigned raw_dy = h2_scale_load(a.dys), raw_x = h2_scale_load(a.xss);   // reduced behind the first tiles' wait
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    const int tap0 = tg * 5, ntap = tg ? 4 : 5;
+    // per-lane LDS byte addresses of the transposing reads (lane m16 of a 16-lane group supplies bytes 8 (m16 % 4) .. + 7 of pixel
+    // m16 / 4 of the window and receives channel m16 of its four pixels).  dy: pixel 8 lh + m16 / 4 (+ 4: immediate), slot
+    // (og, plane, g16, m16 % 4 / 2) ^ pixel % 4 << 2 -- the XOR reaches the plane bit, so one address per plane.
+    unsigned a_thr[2];
+    {
+        const int pq = m16 >> 2;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int slot = (og * 8 + pl * 4 + g16 * 2 + ((m16 & 3) >> 1)) ^ (pq << 2);
+            a_thr[pl] = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((8 * lh + pq) * 512 + slot * 16 + (m16 & 1) * 8);
+        }
+    }
+    // x: window start q = 0, 1, 2; pixel slot p = 8 lh + q + m16 / 4 (+ 4: immediate, bit 1 of p unchanged), plane 0 at slot bit 2 =
+    // bit 1 of p (plane 1: the address ^ 64)
+    unsigned b_thr[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int pq = 8 * lh + q + (m16 >> 2);
+        b_thr[q] = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(pq * 128 + ((pq >> 1) & 1) * 64 + g16 * 32 + (m16 & 3) * 8);
+    }
+
+    if (nIt > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    for (int it = 0; it < nIt; ++it) {
+        const int buf = it & 1;
+        // padding masks of this stage: bit j of the low half = tap (1, 0) of pixel j exists, bit 16 + j = tap (1, 2) does
+        unsigned bal[SUB];
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            asm volatile("" : "+v"(vmn[s]));
+            bal[s] = (unsigned)__builtin_amdgcn_ballot_w64(vmn[s] >= 0);
+        }
+        if (it + 1 < nIt) issue_stage(it + 1, buf ^ 1);
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+        const unsigned ao = (unsigned)(buf * SUB + s) * (A_EL * 2), bo = (unsigned)(buf * SUB + s) * (B_EL * 2);
+#ifdef RADET_W9R_NOMASK
+        const bool need = false;
+#else
+        const bool need = bal[s] != 0xFFFFFFFFu;                 // (uniform) a pixel of this stage sits at an image border
+#endif
+        // masks over the four VGPRs of a fragment (pixels 8 lh + 2 v, + 1): built from the uniform ballot for both halves of the
+        // wave (scalar unit), one select per register
+        unsigned mk[2][4];
+        if (need) {
+            auto ex = [](unsigned b8, int v) { return (((b8 >> (2 * v)) & 1u) ? 0x0000FFFFu : 0u) | (((b8 >> (2 * v + 1)) & 1u) ? 0xFFFF0000u : 0u); };
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const unsigned l0 = ex(bal[s], v), l1 = ex(bal[s] >> 8, v), r0 = ex(bal[s] >> 16, v), r1 = ex(bal[s] >> 24, v);
+                mk[0][v] = lh ? l1 : l0;
+                mk[1][v] = lh ? r1 : r0;
+            }
+        }
+        s16x4v_ al[2], ah[2], bl[2][2], bh[2][2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            lds_read_tr16<0>(al[pl], a_thr[pl] + ao);
+            lds_read_tr16<4 * 512>(ah[pl], a_thr[pl] + ao);
+        }
+        f16x8 af[2];
+        // tap (r, q) = tap0 + t: the window of segment row r that starts q pixels in
+        auto read_tap = [&](int t, s16x4v_ (&lo)[2], s16x4v_ (&hi)[2]) {
+            const int tap = tap0 + t, q = tap % 3;               // (uniform)
+            const unsigned bt = (q == 0 ? b_thr[0] : (q == 1 ? b_thr[1] : b_thr[2])) + bo + (unsigned)((tap / 3) * ROWB);
+            lds_read_tr16<0>(lo[0], bt);
+            lds_read_tr16<4 * 128>(hi[0], bt);
+            lds_read_tr16<0>(lo[1], bt ^ 64u);
+            lds_read_tr16<4 * 128>(hi[1], bt ^ 64u);
+        };
+        read_tap(0, bl[0], bh[0]);
+        static_for<0, NTAP>([&](auto tc_) {
+            constexpr int t = decltype(tc_)::value, pp = t & 1;
+            if (t < ntap) {                                      // uniform per wave
+                if (t + 1 < ntap) {
+                    if constexpr (t + 1 < NTAP) read_tap(t + 1, bl[pp ^ 1], bh[pp ^ 1]);
+                    lds_wait<4>();
+                } else {
+                    lds_wait<0>();
+                }
+                if constexpr (t == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        asm volatile("" : "+v"(al[pl])); asm volatile("" : "+v"(ah[pl]));
+                        af[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(al[pl], ah[pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                }
+                const int q = (tap0 + t) % 3;                    // (uniform)
+                f16x8 bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    asm volatile("" : "+v"(bl[pp][pl])); asm volatile("" : "+v"(bh[pp][pl]));
+                    if (need && q != 1) {                        // (uniform) zero the pixels whose tap is padding
+                        const int sd = q == 0 ? 0 : 1;
+                        u32x2_ lo = __builtin_bit_cast(u32x2_, bl[pp][pl]), hi = __builtin_bit_cast(u32x2_, bh[pp][pl]);
+                        lo.x &= sd ? mk[1][0] : mk[0][0]; lo.y &= sd ? mk[1][1] : mk[0][1];
+                        hi.x &= sd ? mk[1][2] : mk[0][2]; hi.y &= sd ? mk[1][3] : mk[0][3];
+                        bl[pp][pl] = __builtin_bit_cast(s16x4v_, lo); bh[pp][pl] = __builtin_bit_cast(s16x4v_, hi);
+                    }
+                    bf[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(bl[pp][pl], bh[pp][pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
+            const unsigned short* ap = &As[buf * SUB + s][0];
+            const int sl = (tid >> 5) * 8 + ((tid >> 4) & 1) * 2 + ((tid >> 3) & 1);      // hi slot of this channel, un-swizzled
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                const int e = p * 256 + ((sl ^ ((p & 3) << 2)) << 3) + (tid & 7);
+                bsum += radet_pair_value(ap[e], ap[e ^ 32]);                             // (lo plane: slot ^ 4)
             }
         }
         }
@@ -491,6 +735,12 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
         if (a.KH == 3 && a.KW == 3 && !(flags & 0x40)) {               // all nine taps per workgroup
             const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
             static const int sub = getenv("RADET_WGRAD9_SUB") ? atoi(getenv("RADET_WGRAD9_SUB")) : 2;
+            if (flags & 0x2000) {                                        // unit stride, padding 1: x as shifted windows
+                if (sub == 4) hipLaunchKernelGGL(conv_wgrad9r_kernel<4>, dim3(tiles9), dim3(512), 0, st, a);
+                else if (sub == 1) hipLaunchKernelGGL(conv_wgrad9r_kernel<1>, dim3(tiles9), dim3(512), 0, st, a);
+                else hipLaunchKernelGGL(conv_wgrad9r_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);
+                return radet_check_launch();
+            }
             if (sub == 1) hipLaunchKernelGGL(conv_wgrad9q_kernel<1>, dim3(tiles9), dim3(512), 0, st, a);
             else hipLaunchKernelGGL(conv_wgrad9q_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);
             return radet_check_launch();

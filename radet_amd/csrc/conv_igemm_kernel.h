@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
         // on the last stages of the range fewer are in flight: plain wait
         if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        radet_pipe_barrier();
     };
     if constexpr (KW) {
         const int kg = wave % KD, nh = wave / KD;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
             __builtin_amdgcn_sched_barrier(0);
             if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            radet_pipe_barrier();
         };
         static_assert(NSTG == 2 || LOADS > 0, "deep K-divided pipelines count on every wave owning the same loads per stage");
         int buf = 0;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemmg_kernel(const ConvArg
                     // (this wave has no read of buffer BUF in flight any more)
                     if (NSTG >= 3 && it + NSTG - 1 < nK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS * (NSTG - 2)) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();                                           // stage it + 1 landed, buffer BUF released
+                    radet_pipe_barrier();                                      // stage it + 1 landed, buffer BUF released
                     slice(std::integral_constant<int, PP>{}, std::integral_constant<int, (BUF + 1) % NSTG>{},
                           std::integral_constant<int, 0>{}, it + 1 < nK && (!RADET_P3_DBG || !(a.dbg & 4)), std::true_type{}, BUF,
                           it + NSTG < nK && (!RADET_P3_DBG || !(a.dbg & 1)));

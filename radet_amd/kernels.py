@@ -1002,11 +1002,20 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
               g.lin.rows, kc, g.cin, g.k, g.k, 0, tile, _ptr(ws), C.c_size_t(ws.numel() if splitk else 0), _stream(), sc)
 
 
+# all-taps weight gradient on fp16 plane pairs, unit-stride 3 x 3 convs: RADET_WGRAD9_WINDOWS=1 selects conv_wgrad9r_kernel (x as
+# shifted windows of three row segments, every tile load a whole cache line: 15 instead of 26 KiB and 118 lines instead of 416
+# half lines of LDS fill per 16 pixels; bit-identical results) -- built, tested, and SLOWER (167 against 107-117 us on the tower
+# shape: neither the bytes nor the number of requests bound conv_wgrad9q_kernel), so off by default
+WGRAD9_WINDOWS = os.environ.get("RADET_WGRAD9_WINDOWS", "0") == "1"
+
+
 def _wgrad_key(g, dy, co):
     if _isp(dy):
         if dy.kind == "h2" and (g.k != 3 or g.wgrad_pair_flags & 0x40):
             return f"conv_wgradq_kernel<{'128, 128' if (g.wgrad_pair_flags >> 4) & 3 == 1 else '64, 64'}> (fp16 plane pairs)"
-        return "conv_wgrad9q_kernel" if dy.kind == "h2" else "conv_wgrad9p_kernel"
+        if dy.kind == "h2":
+            return "conv_wgrad9r_kernel" if (g.stride == 1 and g.pad == 1 and WGRAD9_WINDOWS) else "conv_wgrad9q_kernel"
+        return "conv_wgrad9p_kernel"
     if getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not _is16(dy):
         tf = (g.wgrad_flags >> 4) & 3
         tile = {0: "launcher tile", 1: "128, 128", 2: "64, 64", 3: "128, 64"}[tf] if co > 32 else "32, 128"
@@ -1039,8 +1048,10 @@ def _conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
         if dy.kind == "h2":
             # all nine taps per workgroup for 3 x 3 convs unless the geometry's flags ask for the one-tap pair kernel (0x40;
             # bits 4-5 = its tile), which also serves every other kernel size
-            fl = 0x1000 | 0x200 | (g.wgrad_pair_flags if (g.k == 3 and not (g.wgrad_pair_flags & 0x40)) else
-                                   (0x40 | (g.wgrad_pair_flags & 0x30)))
+            nine = g.k == 3 and not (g.wgrad_pair_flags & 0x40)
+            fl = 0x1000 | 0x200 | (g.wgrad_pair_flags if nine else (0x40 | (g.wgrad_pair_flags & 0x30)))
+            if nine and g.stride == 1 and g.pad == 1 and WGRAD9_WINDOWS:
+                fl |= 0x2000                  # unit stride, padding 1: the nine taps read shifted windows of three row segments
             _lib.call("radet_conv2d_wgrad_s", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table),
                       g.lout.rows, g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k,
                       g.nsplit_pairs or g.nsplit, fl, _stream(), _scales(dy, x, None))

@@ -1457,3 +1457,42 @@ def test_conv_epilogue_writes_plane_pair_copy(K, case):
     y2 = torch.empty(B * Ho * Wo, C2, device=dev)
     K.conv_fwd(g2, yq, K.Planes.from_float(fold_w(w2).reshape(C2, Cout).to(dev), kind="h2"), None, y2, tile=3)
     assert rel_err(from_rows(y2, B, Ho, Wo), ref2) < 1e-5
+
+
+@pytest.mark.parametrize("hw,B,cin,cout", [([(12, 16), (6, 8), (3, 4)], 2, 64, 160),      # ragged last output tile, small levels
+                                           ([(15, 20), (8, 10), (4, 5)], 3, 32, 128),      # widths that divide no 16-pixel stage
+                                           ([(9, 7), (1, 1)], 2, 32, 256),                 # a row shorter than the halo, a 1 x 1 level
+                                           ([(60, 80)], 1, 256, 256)])                     # a tower level of the headline config
+def test_all_taps_wgrad_from_shifted_windows(K, monkeypatch, hw, B, cin, cout):
+    """conv_wgrad9r_kernel (radet_conv2d_wgrad_s flags +0x2000, round 6: the nine taps of a unit-stride 3 x 3 read shifted
+    windows of three row segments, the pixels whose tap is padding are zeroed in registers) against conv_wgrad9q_kernel (nine
+    gathered tiles): the same products in the same order, so the slabs and the bias column sums are equal bit for bit -- on
+    multi-level geometries whose rows are shorter than / do not divide the 16-pixel stages, with ragged pixel splits -- and
+    both against the fp64 weight gradient (reference: the autograd of `F.conv2d` in `dense_heads/atss_head.py:118-145`)."""
+    dev = "cuda"
+    lv = K.Levels(hw, B)
+    geom = K.ConvGeom(lv, cin, cout, 3, 1, 1)
+    g = torch.Generator().manual_seed(lv.rows + cin)
+    x = torch.randn(lv.rows, cin, generator=g).to(dev)
+    dy = (torch.randn(lv.rows, cout, generator=g) * 1e-3).to(dev)
+    xp, dyp = K.Planes.from_float(x, kind="h2"), K.Planes.from_float(dy, kind="h2")
+    gw = torch.zeros(cout, cin, 3, 3, dtype=torch.float64)
+    off = 0
+    for (h, w) in hw:                                                 # fp64 reference, level by level
+        n = B * h * w
+        xi = x[off:off + n].cpu().double().reshape(B, h, w, cin).permute(0, 3, 1, 2)
+        di = dy[off:off + n].cpu().double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
+        gw += torch.nn.grad.conv2d_weight(xi, gw.shape, di, padding=1)
+        off += n
+    for S in (1, 3, 7):
+        geom.nsplit = S
+        out = {}
+        for windows in (True, False):
+            monkeypatch.setattr(K, "WGRAD9_WINDOWS", windows)
+            slabs = torch.full((S, cout, 9, cin), float("nan"), device=dev)
+            bp = torch.full((S, cout), float("nan"), device=dev)
+            K.conv_wgrad(geom, dyp, xp, slabs, bp)
+            out[windows] = (slabs, bp)
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]), S
+        gw_mine = out[True][0].sum(0).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        assert rel_err(gw_mine, gw) < 2e-5, S

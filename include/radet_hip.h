@@ -197,8 +197,10 @@ int radet_conv2d_wgrad(const float* dy, const float* x, float* slabs, float* dbi
  * with +0x200, dy rows [2][ld_dy] / x rows [2][Cin] fp16 plane pairs (3x3 convs, Cin % 32 == 0, ld_dy % 32 == 0:
  * conv_wgrad9q_kernel, 128 output x 32 input channels x 9 taps per workgroup).  +0x2000 (with +0x200, 3x3): the gather table
  * is that of a unit-stride conv with padding 1 -- tap (r, q) of pixel m reads what tap (r, 1) of pixel m + q - 1 reads, or
- * padding -- and the nine taps take shifted windows of three row segments in LDS instead of nine gathered tiles
- * (conv_wgrad9r_kernel; the same sums in the same order: bit-identical to the launch without the flag). */
+ * padding: row - pixel fits 16 bits -- and the launch runs conv_wgrad9d_kernel (five stage buffers, loads four stages ahead,
+ * the table rows of a pixel split copied to LDS; splits of more than 1664 pixels fall back to conv_wgrad9q_kernel).  +0x4000
+ * (same geometry, an experiment): the nine taps take shifted windows of three row segments in LDS instead of nine gathered
+ * tiles (conv_wgrad9r_kernel).  All three form the same sums in the same order: bit-identical results. */
 int radet_conv2d_wgrad_s(const float* dy, const float* x, float* slabs, float* dbias_partials, const int* gather_table,
                          int M, int Cin, int Cout, int ld_dy, int KH, int KW, int S, int flags, void* stream,
                          const RadetScales* sc);

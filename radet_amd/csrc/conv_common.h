@@ -473,6 +473,18 @@ template <int OFF>
 __device__ __forceinline__ void lds_read32(float& d, unsigned addr) {
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read_u16(unsigned& d, unsigned addr) {
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_i16(int& d, unsigned addr) {
+    asm volatile("ds_read_i16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {

@@ -276,6 +276,218 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ wgrad, all 9 taps, pairs, deep pipeline
+// conv_wgrad9q_kernel with D stage buffers instead of two (round 6).  An ablation of that kernel on the tower shape (RADET_DBG_WGRAD
+// bits in a -DRADET_P3_DBG=1 build: 119 us; without tile loads 93, without MFMAs 99, without fragment reads 111, without all
+// three 64) says that more than half of it is the SKELETON: every iteration ends in `s_waitcnt vmcnt(0)` + barrier behind loads
+// and gather-table look-ups it issued itself, i.e. one global round trip (~1.2 us) per 32 pixels whatever else happens, with
+// one 8-wave workgroup per CU and nothing to switch to.  Here:
+//   * the rows of the gather table this workgroup needs (9 taps x its pixel split, as 16-bit row - pixel differences: a
+//     unit-stride 3 x 3 with padding 1 reads within one image row of the pixel) are copied to LDS once, so the look-ups are
+//     LDS reads (lgkmcnt) and no vector-memory result has to come back in the loop: in-order return would tie the wait for a
+//     look-up to every tile load issued before it;
+//   * stage i + D - 1 is issued while stage i is computed; a stage's loads are waited for with `vmcnt((D - 2) x loads per
+//     stage of this wave)` (every wave issues a fixed 4 or 3 per stage) and published with the bare barrier
+//     (radet_pipe_barrier, conv_common.h); one 16-pixel stage per barrier;
+//   * the bias column sums read their dy values with inline-asm LDS reads (behind plain LDS loads the compiler drains vmcnt).
+// Same products in the same order as conv_wgrad9q_kernel: bit-identical.  LDS: D x 26 KiB + 29 KiB of table (D = 5: 159 KiB).
+#define RADET_W9D_TCAP 1664            // pixels per split the LDS copy of the table holds (the launcher falls back beyond)
+template <int D>
+__global__ __launch_bounds__(512) void conv_wgrad9d_kernel(const WgradArgs a) {
+    radet_kernarg_warm<sizeof(WgradArgs)>();
+    constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9, TCAP = RADET_W9D_TCAP;
+    constexpr int CBA = BM / 16, CBB = BC / 16;
+    constexpr int A_PL = BP * BM, B_PL = BP * BC;           // fp16 elements per dy plane tile / per (tap, plane) x tile
+    constexpr int A_Q = A_PL * 2 / 1024;                    // wave loads per dy plane tile: 4
+    constexpr int A_INSTR = 2 * A_Q;                        // 8
+    constexpr int B_INSTR = KT * 2;                         // 18: one wave load per (tap, plane)
+    constexpr int N_INSTR = A_INSTR + B_INSTR;              // 26
+    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 4 (waves 0, 1) or 3 loads per wave and stage
+    static_assert(N_INSTR == 3 * NW + 2 && D >= 3, "waves 0 and 1 issue four loads per stage, the others three");
+    __shared__ __attribute__((aligned(16))) unsigned short As[D][2 * A_PL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[D][KT * 2 * B_PL];
+    __shared__ short tabL[KT * TCAP + 16];
+    const unsigned short* dyh = reinterpret_cast<const unsigned short*>(a.dy);
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(a.x);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = wave & 3, tg = wave >> 2;                // output-channel group, tap group (0: taps 0-4, 1: taps 5-8)
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int tilesO = (a.Cout + BM - 1) / BM;
+    const int tilesC = a.Cin / BC;
+    const int tilesPerSplit = tilesO * tilesC;
+    int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);    // (the channel tiles of one pixel split next to each other on one XCD)
+    const int split = id / tilesPerSplit;
+    id -= split * tilesPerSplit;
+    const int to = id % tilesO, tc = id / tilesO;
+    const int o0 = to * BM, c0 = tc * BC;
+
+    const int p_begin = split * a.chunks_per_split * 16;
+    int p_end = p_begin + a.chunks_per_split * 16;
+    if (p_end > a.M) p_end = a.M;
+    const int nIt = p_begin < p_end ? (p_end - p_begin + BP - 1) / BP : 0;
+
+    const unsigned raw_dy = h2_scale_load(a.dys), raw_x = h2_scale_load(a.xss);   // (gathers; reduced behind the table's barrier)
+    // the table rows of this split -> LDS (row - pixel, or -32768 for a padding tap)
+    for (int j = tid; j < p_end - p_begin; j += NW * 64) {
+        int r[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) r[t] = a.rowtab[(size_t)t * a.Mp + p_begin + j];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) tabL[t * TCAP + j] = r[t] < 0 ? (short)-32768 : (short)(r[t] - (p_begin + j));
+    }
+    const int l_blk = lane >> 3, l_prow = (lane & 7) >> 1, l_half = lane & 1;
+    const int pix = 4 * (l_blk / CBB) + l_prow;             // this lane's pixel of a stage in the x-tile loads
+    unsigned tb[PER_WAVE];                                   // LDS byte address of its table entry for stage 0, per x load
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int bi = wave + k * NW - A_INSTR;
+        tb[k] = (unsigned)(size_t)(lptr_t)(&tabL[0]) + (unsigned)((((bi >= 0 && bi < B_INSTR) ? bi / 2 : 0) * TCAP + pix) * 2);
+    }
+    int drow[PER_WAVE];                                      // look-ups of the stage that is issued next
+    auto lookup = [&](int stage) {
+        static_for<1, PER_WAVE>([&](auto kc) { lds_read_i16<0>(drow[decltype(kc)::value], tb[decltype(kc)::value] + (unsigned)(stage * BP * 2)); });
+    };
+    auto issue_stage = [&](int it, int buf) {                // x tiles (their look-ups were read one issue ago), dy tiles, next look-ups
+        lds_wait<0>();
+#pragma unroll
+        for (int k = 1; k < PER_WAVE; ++k) asm volatile("" : "+v"(drow[k]));
+        const int p0 = p_begin + it * BP;
+#pragma unroll
+        for (int k = 1; k < PER_WAVE; ++k) {
+            const int ins = wave + k * NW;
+            if (ins < N_INSTR) {                                 // (uniform: k = 3 exists for waves 0 and 1)
+                const int bi = ins - A_INSTR;
+                const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
+                const int m = p0 + pix;
+                const bool ok = drow[k] != -32768 && m < p_end;
+                radet_lds_load16(xh, ok, (size_t)((size_t)(m + drow[k]) * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2)), (lptr_t)(&Bs[buf][bi * B_PL]));
+            }
+        }
+        {
+            const int ins = wave;                                // k = 0: every wave owns one dy load
+            const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
+            const int m = p0 + 4 * (blk / CBA) + l_prow;
+            const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+            radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl), (lptr_t)(&As[buf][ins * 512]));
+        }
+        if (it + 1 < nIt) lookup(it + 1);                        // (uniform)
+    };
+
+    constexpr int NTAP = 5;                                  // accumulator pairs per wave (tap group 1 leaves the last one idle)
+    f32x16 acc[NTAP], acc1[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acc1[t][r] = 0.f; }
+    float bsum = 0.f;
+    const bool want_bias = a.dbias_partials != nullptr && tc == 0;
+    const int g16 = (lane >> 4) & 1, m16 = lane & 15;
+    const int tap0 = tg * 5, ntap = tg ? 4 : 5;
+    const unsigned a_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)(((2 * lh) * CBA + og * 2 + g16) * 128 + m16 * 8);
+    const unsigned b_thr = (unsigned)(size_t)(lptr_t)(&Bs[0][0]) + (unsigned)(((2 * lh) * CBB + g16) * 128 + m16 * 8) +
+                           (unsigned)(tap0 * 2 * B_PL * 2);
+    const unsigned s_thr = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((((tid >> 4) & 7) * 64 + (tid & 15)) * 2);   // bias: channel tid of pixel 0
+
+    __syncthreads();                                             // the table is complete (nothing else is in flight yet)
+    const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);     // (drained with the table's loads)
+    lookup(0);
+#pragma unroll
+    for (int k = 0; k < D - 1; ++k)
+        if (k < nIt) issue_stage(k, k);
+    int cb_ = 0, ib_ = D - 1;                                    // buffer of the stage computed / issued next
+    for (int it = 0; it < nIt; ++it) {
+        // stage `it` has landed once at most the D - 2 stages issued behind it are outstanding (in-order return; the last stages
+        // of the split: plain wait)
+        if (it + D - 2 < nIt) {
+            if (wave < 2) vm_wait<(D - 2) * 4>(); else vm_wait<(D - 2) * 3>();
+        } else {
+            vm_wait<0>();
+        }
+        if (!RADET_P3_DBG || !(a.dbg & 8)) radet_pipe_barrier();        // ... for every wave, and buffer ib_ (stage it - 1) is free
+        if (it + D - 1 < nIt && (!RADET_P3_DBG || !(a.dbg & 1))) issue_stage(it + D - 1, ib_);      // (ablation: RADET_DBG_WGRAD bits 1 / 2 / 4 / 8)
+        const unsigned ab = a_thr + (unsigned)cb_ * (2 * A_PL * 2), bb = b_thr + (unsigned)cb_ * (KT * 2 * B_PL * 2);
+        s16x4v_ al[2], ah[2], bl[2][2], bh[2][2];
+        static_for<0, 2>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * A_PL * 2>(al[pl], ab);
+            lds_read_tr16<pl * A_PL * 2 + CBA * 128>(ah[pl], ab);
+        });
+        static_for<0, 2>([&](auto pc) {
+            constexpr int pl = decltype(pc)::value;
+            lds_read_tr16<pl * B_PL * 2>(bl[0][pl], bb);
+            lds_read_tr16<pl * B_PL * 2 + CBB * 128>(bh[0][pl], bb);
+        });
+        f16x8 af[2];
+        static_for<0, NTAP>([&](auto tc_) {
+            constexpr int t = decltype(tc_)::value, pp = t & 1;
+            if (t < ntap) {                                      // uniform per wave
+                if (t + 1 < ntap) {
+                    if constexpr (t + 1 < NTAP) {
+                        if (!RADET_P3_DBG || !(a.dbg & 4))
+                        static_for<0, 2>([&](auto pc) {
+                            constexpr int pl = decltype(pc)::value;
+                            lds_read_tr16<((t + 1) * 2 + pl) * B_PL * 2>(bl[pp ^ 1][pl], bb);
+                            lds_read_tr16<((t + 1) * 2 + pl) * B_PL * 2 + CBB * 128>(bh[pp ^ 1][pl], bb);
+                        });
+                    }
+                    lds_wait<4>();
+                } else {
+                    lds_wait<0>();
+                }
+                if constexpr (t == 0) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        asm volatile("" : "+v"(al[pl])); asm volatile("" : "+v"(ah[pl]));
+                        af[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(al[pl], ah[pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                }
+                f16x8 bf[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    asm volatile("" : "+v"(bl[pp][pl])); asm volatile("" : "+v"(bh[pp][pl]));
+                    bf[pl] = __builtin_bit_cast(f16x8, __builtin_shufflevector(bl[pp][pl], bh[pp][pl], 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                if (!RADET_P3_DBG || !(a.dbg & 2)) mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
+            unsigned vh[BP], vl[BP];
+            const unsigned sa = s_thr + (unsigned)cb_ * (2 * A_PL * 2);
+            static_for<0, BP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value, e = ((p >> 2) * CBA) * 64 + (p & 3) * 16;
+                lds_read_u16<e * 2>(vh[p], sa);
+                lds_read_u16<(A_PL + e) * 2>(vl[p], sa);
+            });
+            lds_wait<0>();
+#pragma unroll
+            for (int p = 0; p < BP; ++p) {
+                asm volatile("" : "+v"(vh[p]), "+v"(vl[p]));
+                bsum += radet_pair_value((unsigned short)vh[p], (unsigned short)vl[p]);
+            }
+        }
+        cb_ = cb_ + 1 == D ? 0 : cb_ + 1;
+        ib_ = ib_ + 1 == D ? 0 : ib_ + 1;
+    }
+    if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum * sdy.inv;
+    float* out = a.slabs + (size_t)split * a.Cout * KT * a.Cin;
+    const int c = c0 + li;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        if (t < ntap) {
+            h2_combine(acc[t], acc1[t], sdy.inv, sxx.inv);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + og * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (o < a.Cout) out[((size_t)o * KT + tap0 + t) * a.Cin + c] = acc[t][r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ wgrad, all 9 taps, pairs, x as shifted windows
 // conv_wgrad9q_kernel for unit-stride 3 x 3 convs with padding 1 (round 6).  There the x tile of a 16-pixel stage is nine gathered
 // copies of (almost) the same rows -- tap (r, q) of pixel m reads the row that tap (r, 1) of pixel m + q - 1 reads, unless
@@ -735,7 +947,14 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
         if (a.KH == 3 && a.KW == 3 && !(flags & 0x40)) {               // all nine taps per workgroup
             const int tiles9 = ((a.Cout + 127) / 128) * (a.Cin / 32) * a.S;
             static const int sub = getenv("RADET_WGRAD9_SUB") ? atoi(getenv("RADET_WGRAD9_SUB")) : 2;
-            if (flags & 0x2000) {                                        // unit stride, padding 1: x as shifted windows
+            if ((flags & 0x2000) && a.chunks_per_split * 16 <= RADET_W9D_TCAP) {      // unit stride, padding 1: deep pipeline, table in LDS
+                static const int depth = getenv("RADET_WGRAD9_DEPTH") ? atoi(getenv("RADET_WGRAD9_DEPTH")) : 5;
+                if (depth == 3) hipLaunchKernelGGL(conv_wgrad9d_kernel<3>, dim3(tiles9), dim3(512), 0, st, a);
+                else if (depth == 4) hipLaunchKernelGGL(conv_wgrad9d_kernel<4>, dim3(tiles9), dim3(512), 0, st, a);
+                else hipLaunchKernelGGL(conv_wgrad9d_kernel<5>, dim3(tiles9), dim3(512), 0, st, a);
+                return radet_check_launch();
+            }
+            if (flags & 0x4000) {                                        // (experiment) unit stride, padding 1: x as shifted windows
                 if (sub == 4) hipLaunchKernelGGL(conv_wgrad9r_kernel<4>, dim3(tiles9), dim3(512), 0, st, a);
                 else if (sub == 1) hipLaunchKernelGGL(conv_wgrad9r_kernel<1>, dim3(tiles9), dim3(512), 0, st, a);
                 else hipLaunchKernelGGL(conv_wgrad9r_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);

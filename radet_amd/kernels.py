@@ -1007,6 +1007,11 @@ def _conv_dgrad(g, dy, wft, dx, addend, mask, kc, tile, ws, splitk, skip_zero_ro
 # half lines of LDS fill per 16 pixels; bit-identical results) -- built, tested, and SLOWER (167 against 107-117 us on the tower
 # shape: neither the bytes nor the number of requests bound conv_wgrad9q_kernel), so off by default
 WGRAD9_WINDOWS = os.environ.get("RADET_WGRAD9_WINDOWS", "0") == "1"
+# ... RADET_WGRAD9_DEEP=1 selects conv_wgrad9d_kernel: conv_wgrad9q_kernel with five stage buffers, the loads four 16-pixel stages
+# ahead, the gather table of the pixel split in LDS; bit-identical results.  4-9 % faster alone (91 against 95 us on the tower
+# shape, 105 against 115 with bias sums), 0.3-0.5 % SLOWER in the step: its 159 KiB of LDS leave no room for a dgrad workgroup
+# on the same CU (the two-buffer kernel: 104 KiB).  Off by default
+WGRAD9_DEEP = os.environ.get("RADET_WGRAD9_DEEP", "0") == "1"
 
 
 def _wgrad_key(g, dy, co):
@@ -1014,6 +1019,8 @@ def _wgrad_key(g, dy, co):
         if dy.kind == "h2" and (g.k != 3 or g.wgrad_pair_flags & 0x40):
             return f"conv_wgradq_kernel<{'128, 128' if (g.wgrad_pair_flags >> 4) & 3 == 1 else '64, 64'}> (fp16 plane pairs)"
         if dy.kind == "h2":
+            if g.stride == 1 and g.pad == 1 and WGRAD9_DEEP and -(-g.lout.rows // (16 * (g.nsplit_pairs or g.nsplit))) * 16 <= 1664:
+                return "conv_wgrad9d_kernel"
             return "conv_wgrad9r_kernel" if (g.stride == 1 and g.pad == 1 and WGRAD9_WINDOWS) else "conv_wgrad9q_kernel"
         return "conv_wgrad9p_kernel"
     if getattr(g, "h2", False) and getattr(g, "x3", False) and not g.math and not _is16(dy):
@@ -1050,8 +1057,8 @@ def _conv_wgrad(g, dy, x, slabs, dbias_partials=None, cout=None, ld_dy=None):
             # bits 4-5 = its tile), which also serves every other kernel size
             nine = g.k == 3 and not (g.wgrad_pair_flags & 0x40)
             fl = 0x1000 | 0x200 | (g.wgrad_pair_flags if nine else (0x40 | (g.wgrad_pair_flags & 0x30)))
-            if nine and g.stride == 1 and g.pad == 1 and WGRAD9_WINDOWS:
-                fl |= 0x2000                  # unit stride, padding 1: the nine taps read shifted windows of three row segments
+            if nine and g.stride == 1 and g.pad == 1:       # unit stride, padding 1 (what the two kernels below rely on)
+                fl |= (0x2000 if WGRAD9_DEEP else 0) | (0x4000 if WGRAD9_WINDOWS else 0)
             _lib.call("radet_conv2d_wgrad_s", _ptr(dy.t), _ptr(x.t), _ptr(slabs), _ptr(dbias_partials), _ptr(g.fwd_table),
                       g.lout.rows, g.cin, co, co if ld_dy is None else ld_dy, g.k, g.k,
                       g.nsplit_pairs or g.nsplit, fl, _stream(), _scales(dy, x, None))

@@ -1463,12 +1463,15 @@ def test_conv_epilogue_writes_plane_pair_copy(K, case):
                                            ([(15, 20), (8, 10), (4, 5)], 3, 32, 128),      # widths that divide no 16-pixel stage
                                            ([(9, 7), (1, 1)], 2, 32, 256),                 # a row shorter than the halo, a 1 x 1 level
                                            ([(60, 80)], 1, 256, 256)])                     # a tower level of the headline config
-def test_all_taps_wgrad_from_shifted_windows(K, monkeypatch, hw, B, cin, cout):
-    """conv_wgrad9r_kernel (radet_conv2d_wgrad_s flags +0x2000, round 6: the nine taps of a unit-stride 3 x 3 read shifted
-    windows of three row segments, the pixels whose tap is padding are zeroed in registers) against conv_wgrad9q_kernel (nine
-    gathered tiles): the same products in the same order, so the slabs and the bias column sums are equal bit for bit -- on
-    multi-level geometries whose rows are shorter than / do not divide the 16-pixel stages, with ragged pixel splits -- and
-    both against the fp64 weight gradient (reference: the autograd of `F.conv2d` in `dense_heads/atss_head.py:118-145`)."""
+def test_all_taps_wgrad_variants_are_bit_identical(K, monkeypatch, hw, B, cin, cout):
+    """The all-taps weight gradient on fp16 plane pairs of a unit-stride 3 x 3 conv, three kernels (radet_conv2d_wgrad_s flags):
+    conv_wgrad9q_kernel (two stage buffers), conv_wgrad9d_kernel (+0x2000, round 6, the default: five buffers, loads four stages
+    ahead, the gather table of the pixel split in LDS as 16-bit differences, bias sums by inline-asm LDS reads) and
+    conv_wgrad9r_kernel (+0x4000, an experiment: the nine taps read shifted windows of three row segments, pixels whose tap is
+    padding zeroed in registers).  They form the same products in the same order, so slabs and bias column sums are equal bit
+    for bit -- on multi-level geometries whose rows are shorter than / do not divide the 16-pixel stages, with ragged pixel
+    splits and splits shorter than the pipeline -- and agree with the fp64 weight gradient (reference: the autograd of
+    `F.conv2d` in `dense_heads/atss_head.py:118-145`)."""
     dev = "cuda"
     lv = K.Levels(hw, B)
     geom = K.ConvGeom(lv, cin, cout, 3, 1, 1)
@@ -1484,15 +1487,18 @@ def test_all_taps_wgrad_from_shifted_windows(K, monkeypatch, hw, B, cin, cout):
         di = dy[off:off + n].cpu().double().reshape(B, h, w, cout).permute(0, 3, 1, 2)
         gw += torch.nn.grad.conv2d_weight(xi, gw.shape, di, padding=1)
         off += n
-    for S in (1, 3, 7):
-        geom.nsplit = S
+    for S in (1, 3, 7, 64):
+        geom.nsplit = min(S, -(-lv.rows // 16))
+        S = geom.nsplit
         out = {}
-        for windows in (True, False):
+        for name, deep, windows in (("two buffers", False, False), ("deep", True, False), ("windows", False, True)):
+            monkeypatch.setattr(K, "WGRAD9_DEEP", deep)
             monkeypatch.setattr(K, "WGRAD9_WINDOWS", windows)
             slabs = torch.full((S, cout, 9, cin), float("nan"), device=dev)
             bp = torch.full((S, cout), float("nan"), device=dev)
             K.conv_wgrad(geom, dyp, xp, slabs, bp)
-            out[windows] = (slabs, bp)
-        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]), S
-        gw_mine = out[True][0].sum(0).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+            out[name] = (slabs, bp)
+        for name in ("deep", "windows"):
+            assert torch.equal(out[name][0], out["two buffers"][0]) and torch.equal(out[name][1], out["two buffers"][1]), (name, S)
+        gw_mine = out["deep"][0].sum(0).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
         assert rel_err(gw_mine, gw) < 2e-5, S

@@ -77,7 +77,19 @@ bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int ta
 // SUB: 16-pixel sub-stages per pipeline stage (one wait + barrier per SUB x 16 pixels).  With one 8-wave workgroup per CU a
 // 16-pixel stage is 0.19 us of MFMA work per wave behind ~1 us of load latency + barrier; two sub-stages per barrier amortise
 // that (104 KiB of LDS: the workgroup owns the CU anyway).
-template <int SUB>
+#if RADET_P3_DBG
+// (ablation builds only) in-kernel time stamps of workgroup 0: [wave 0 / wave 4][iteration][point] shader clocks
+__device__ long long radet_dbg_clk[2][64][4];
+extern "C" int radet_dbg_clk_read(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(radet_dbg_clk), (size_t)n * sizeof(long long));
+}
+#define RADET_STAMP(it, pt) do { if (blockIdx.x == 0 && (wave == 0 || wave == 4) && (it) < 64) { \
+    const long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    if (lane == 0) radet_dbg_clk[wave >> 2][(it)][(pt)] = t_; } } while (0)
+#else
+#define RADET_STAMP(it, pt) do { } while (0)
+#endif
+template <int SUB, bool SPREAD = false>
 __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
@@ -131,7 +143,9 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
                 bok[s][k] = m < p_end;
             }
         }
-    auto issue_stage = [&](int it, int buf) {                // order: x tiles, dy tiles, next gather rows (see conv_wgradg)
+    // the loads of stage `it` into buffer `buf`, as individually issuable pieces: piece (s, k) = the k-th wave load of sub-stage s
+    // (ins = wave + 8 k: a dy tile for ins < 8, else the x tile of (tap, plane) ins - 8), then the gather rows of the stage after
+    auto pin_rows = [&]() {
         // the gather rows were fetched one stage ago and drained by the barrier's vmcnt(0), which the compiler cannot see: left
         // alone it puts a vmcnt(0) in front of every x-tile load that reads brow[k] -- and from the second one on that wait
         // covers the LDS-DMA load issued just before it: the pieces of a stage went out one round trip apart.  One wait here
@@ -140,39 +154,45 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
         for (int s = 0; s < SUB; ++s)
 #pragma unroll
             for (int k = 0; k < PER_WAVE; ++k) asm volatile("" : "+v"(brow[s][k]));
+    };
+    auto issue_piece = [&](int it, int buf, auto sc, auto kc) {
+        constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
+        const int p0 = p_begin + (it * SUB + s) * BP;
+        const int ins = wave + k * NW;
+        if (ins >= A_INSTR && ins < N_INSTR) {
+            const int bi = ins - A_INSTR;
+            const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
+            radet_lds_load16(xh, (bok[s][k] && brow[s][k] >= 0), (size_t)((size_t)brow[s][k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2)), (lptr_t)(&Bs[buf * SUB + s][bi * B_PL]));
+        } else if (ins < A_INSTR) {
+            const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
+            const int m = p0 + 4 * (blk / CBA) + l_prow;
+            const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
+            radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl), (lptr_t)(&As[buf * SUB + s][ins * 512]));
+        }
+    };
+    auto next_rows = [&](int it) {
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
-        const int p0 = p_begin + (it * SUB + s) * BP;
+            const int p0 = p_begin + (it * SUB + s) * BP;
 #pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int ins = wave + k * NW;
-            if (ins >= A_INSTR && ins < N_INSTR) {
-                const int bi = ins - A_INSTR;
-                const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
-                radet_lds_load16(xh, (bok[s][k] && brow[s][k] >= 0), (size_t)((size_t)brow[s][k] * 2 * a.Cin + radet_pair_off(c) + 32 * (bi % 2)), (lptr_t)(&Bs[buf * SUB + s][bi * B_PL]));
+            for (int k = 0; k < PER_WAVE; ++k) {
+                const int ins = wave + k * NW;
+                if (ins >= A_INSTR && ins < N_INSTR) {
+                    const int bi = ins - A_INSTR;
+                    const int m = p0 + SUB * BP + 4 * (l_blk / CBB) + l_prow;
+                    brow[s][k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
+                    bok[s][k] = m < p_end;
+                }
             }
         }
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int ins = wave + k * NW;
-            if (ins < A_INSTR) {
-                const int pl = ins / A_Q, blk = (ins % A_Q) * 8 + l_blk;
-                const int m = p0 + 4 * (blk / CBA) + l_prow;
-                const int o = o0 + 16 * (blk % CBA) + 8 * l_half;
-                radet_lds_load16(dyh, (m < p_end && o < a.Cout), (size_t)((size_t)m * 2 * a.ld_dy + radet_pair_off(o) + 32 * pl), (lptr_t)(&As[buf * SUB + s][ins * 512]));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < PER_WAVE; ++k) {
-            const int ins = wave + k * NW;
-            if (ins >= A_INSTR && ins < N_INSTR) {
-                const int bi = ins - A_INSTR;
-                const int m = p0 + SUB * BP + 4 * (l_blk / CBB) + l_prow;
-                brow[s][k] = a.rowtab[(size_t)(bi / 2) * a.Mp + (m < a.Mp ? m : a.Mp - 1)];
-                bok[s][k] = m < p_end;
-            }
-        }
-        }
+    };
+    auto issue_stage = [&](int it, int buf) {                // everything at once: x tiles, dy tiles (per sub-stage), next gather rows
+        pin_rows();
+        static_for<0, SUB>([&](auto sc) {
+            static_for<1, PER_WAVE>([&](auto kc) { issue_piece(it, buf, sc, kc); });
+            issue_piece(it, buf, sc, std::integral_constant<int, 0>{});
+        });
+        next_rows(it);
     };
 
     constexpr int NTAP = 5;                                  // accumulator pairs per wave (tap group 1 leaves the last one idle)
@@ -198,9 +218,17 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     const H2Scale sdy = h2_scale_finish(raw_dy), sxx = h2_scale_finish(raw_x);
     for (int it = 0; it < nIt; ++it) {
         const int buf = it & 1;
-        if (it + 1 < nIt && (!RADET_P3_DBG || !(a.dbg & 1))) issue_stage(it + 1, buf ^ 1);    // (ablation: RADET_DBG_WGRAD bits 1 / 2 / 4)
-#pragma unroll
-        for (int s = 0; s < SUB; ++s) {
+        RADET_STAMP(it, 0);
+        const bool do_issue = it + 1 < nIt && (!RADET_P3_DBG || !(a.dbg & 1));      // (ablation: RADET_DBG_WGRAD bits 1 / 2 / 4)
+        // SPREAD (round 6): the loads of the next stage go out ONE AT A TIME behind the MFMAs of a tap instead of all at the head
+        // of the iteration.  In-kernel time stamps (s_memtime in a -DRADET_P3_DBG=1 build) put the ISSUE of the eight wave loads
+        // of an iteration at 1300-1450 of its 4600 clocks -- all eight waves of the CU stand in the vector-memory issue queue
+        // at the same time right behind the barrier, and the matrix pipe idles until the first of them gets through
+        if constexpr (SPREAD) { if (do_issue) pin_rows(); }
+        else if (do_issue) issue_stage(it + 1, buf ^ 1);
+        RADET_STAMP(it, 1);
+        static_for<0, SUB>([&](auto sc_) {
+        constexpr int s = decltype(sc_)::value;
         const unsigned ab = a_thr + (unsigned)(buf * SUB + s) * (2 * A_PL * 2), bb = b_thr + (unsigned)(buf * SUB + s) * (KT * 2 * B_PL * 2);
         s16x4v_ al[2], ah[2], bl[2][2], bh[2][2];
         static_for<0, 2>([&](auto pc) {
@@ -246,18 +274,33 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
                 if (!RADET_P3_DBG || !(a.dbg & 2)) mfma_h2(acc[t], acc1[t], af[0], af[1], bf[0], bf[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SPREAD && t < PER_WAVE) {               // piece t of sub-stage s of the next stage (x tiles first)
+                if (do_issue) issue_piece(it + 1, buf ^ 1, sc_, std::integral_constant<int, (t + 1) % PER_WAVE>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         });
         if (want_bias && tid < BM) {                        // column sums of dy, pixel order, in units of 2^-e (scaled back below)
-            const int cb = tid >> 4, cc = tid & 15;
-            const unsigned short* ap = &As[buf * SUB + s][0];
+            // (inline-asm LDS reads: behind plain ones the compiler drains vmcnt, i.e. waits for the loads just issued)
+            unsigned vh[BP], vl[BP];
+            const unsigned sa = (unsigned)(size_t)(lptr_t)(&As[0][0]) + (unsigned)((((tid >> 4) & 7) * 64 + (tid & 15)) * 2) +
+                                (unsigned)(buf * SUB + s) * (2 * A_PL * 2);
+            static_for<0, BP>([&](auto pc) {
+                constexpr int p = decltype(pc)::value, e = ((p >> 2) * CBA) * 64 + (p & 3) * 16;
+                lds_read_u16<e * 2>(vh[p], sa);
+                lds_read_u16<(A_PL + e) * 2>(vl[p], sa);
+            });
+            lds_wait<0>();
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
-                const int e = ((p >> 2) * CBA + cb) * 64 + (p & 3) * 16 + cc;
-                bsum += radet_pair_value(ap[e], ap[A_PL + e]);
+                asm volatile("" : "+v"(vh[p]), "+v"(vl[p]));
+                bsum += radet_pair_value((unsigned short)vh[p], (unsigned short)vl[p]);
             }
         }
-        }
+        });
+        if constexpr (SPREAD) { if (do_issue) next_rows(it + 1); }
+        RADET_STAMP(it, 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RADET_STAMP(it, 3);
         __syncthreads();
     }
     if (want_bias && tid < BM && o0 + tid < a.Cout) a.dbias_partials[(size_t)split * a.Cout + o0 + tid] = bsum * sdy.inv;
@@ -960,8 +1003,11 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
                 else hipLaunchKernelGGL(conv_wgrad9r_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);
                 return radet_check_launch();
             }
-            if (sub == 1) hipLaunchKernelGGL(conv_wgrad9q_kernel<1>, dim3(tiles9), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL(conv_wgrad9q_kernel<2>, dim3(tiles9), dim3(512), 0, st, a);
+            static const int spread = getenv("RADET_WGRAD9_SPREAD") ? atoi(getenv("RADET_WGRAD9_SPREAD")) : 0;   // (97-99 against 105 us alone, nothing in the step: DESIGN.md 7)
+            if (sub == 1 && spread) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, true>), dim3(tiles9), dim3(512), 0, st, a);
+            else if (sub == 1) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, false>), dim3(tiles9), dim3(512), 0, st, a);
+            else if (spread) hipLaunchKernelGGL((conv_wgrad9q_kernel<2, true>), dim3(tiles9), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad9q_kernel<2, false>), dim3(tiles9), dim3(512), 0, st, a);
             return radet_check_launch();
         }
         // one tap per workgroup (0x40, or not a 3 x 3): bits 4-5 = 1: 128 x 128 tile, otherwise 64 x 64

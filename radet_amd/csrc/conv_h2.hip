@@ -89,7 +89,7 @@ extern "C" int radet_dbg_clk_read(long long* host, int n) {
 #else
 #define RADET_STAMP(it, pt) do { } while (0)
 #endif
-template <int SUB, bool SPREAD = false>
+template <int SUB, bool SPREAD = false, bool TGLOAD = false>
 __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     radet_kernarg_warm<sizeof(WgradArgs)>();
     constexpr int BP = 16, NW = 8, BM = 128, BC = 32, KT = 9;
@@ -99,7 +99,11 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     constexpr int A_INSTR = 2 * A_Q;                        // 8
     constexpr int B_INSTR = KT * 2;                         // 18: one wave load per (tap, plane)
     constexpr int N_INSTR = A_INSTR + B_INSTR;              // 26
-    constexpr int PER_WAVE = (N_INSTR + NW - 1) / NW;       // 4
+    // TGLOAD (round 6): ALL tile loads are issued by the four waves of tap group 1 (taps 5-8: four taps against five, so each has
+    // six MFMAs per stage less to issue), seven per sub-stage each; the waves of tap group 0 -- one per SIMD, next to one of the
+    // others -- never stand in the vector-memory issue queue and keep the matrix pipe busy meanwhile
+    constexpr int LW = TGLOAD ? 4 : NW;                     // waves that issue loads
+    constexpr int PER_WAVE = (N_INSTR + LW - 1) / LW;       // 4 (7) loads per wave and sub-stage
     static_assert(B_PL * 2 == 1024, "one wave load per x tile");
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * SUB][2 * A_PL];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * SUB][KT * 2 * B_PL];
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int og = wave & 3, tg = wave >> 2;                // output-channel group, tap group (0: taps 0-4, 1: taps 5-8)
+    const int lbase = TGLOAD ? (wave >= 4 ? wave - 4 : N_INSTR) : wave;       // first load of this wave (N_INSTR: none)
     const int li = lane & 31, lh = lane >> 5;
 
     const int tilesO = (a.Cout + BM - 1) / BM;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     for (int s = 0; s < SUB; ++s)
 #pragma unroll
         for (int k = 0; k < PER_WAVE; ++k) {
-            const int bi = wave + k * NW - A_INSTR;
+            const int bi = lbase + k * LW - A_INSTR;
             brow[s][k] = -1;
             bok[s][k] = false;
             if (bi >= 0 && bi < B_INSTR) {
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
     auto issue_piece = [&](int it, int buf, auto sc, auto kc) {
         constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
         const int p0 = p_begin + (it * SUB + s) * BP;
-        const int ins = wave + k * NW;
+        const int ins = lbase + k * LW;
         if (ins >= A_INSTR && ins < N_INSTR) {
             const int bi = ins - A_INSTR;
             const int c = c0 + 16 * (l_blk % CBB) + 8 * l_half;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(512) void conv_wgrad9q_kernel(const WgradArgs a) {
             const int p0 = p_begin + (it * SUB + s) * BP;
 #pragma unroll
             for (int k = 0; k < PER_WAVE; ++k) {
-                const int ins = wave + k * NW;
+                const int ins = lbase + k * LW;
                 if (ins >= A_INSTR && ins < N_INSTR) {
                     const int bi = ins - A_INSTR;
                     const int m = p0 + SUB * BP + 4 * (l_blk / CBB) + l_prow;
@@ -1004,7 +1009,10 @@ int radet_launch_wgrad_h2(const WgradArgs& a, int flags, int bm, int bn, hipStre
                 return radet_check_launch();
             }
             static const int spread = getenv("RADET_WGRAD9_SPREAD") ? atoi(getenv("RADET_WGRAD9_SPREAD")) : 0;   // (97-99 against 105 us alone, nothing in the step: DESIGN.md 7)
-            if (sub == 1 && spread) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, true>), dim3(tiles9), dim3(512), 0, st, a);
+            static const int tgload = getenv("RADET_WGRAD9_TGLOAD") ? atoi(getenv("RADET_WGRAD9_TGLOAD")) : 0;   // (116-117 against 105 us alone: DESIGN.md 7)
+            if (tgload && sub == 1) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, false, true>), dim3(tiles9), dim3(512), 0, st, a);
+            else if (tgload) hipLaunchKernelGGL((conv_wgrad9q_kernel<2, false, true>), dim3(tiles9), dim3(512), 0, st, a);
+            else if (sub == 1 && spread) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, true>), dim3(tiles9), dim3(512), 0, st, a);
             else if (sub == 1) hipLaunchKernelGGL((conv_wgrad9q_kernel<1, false>), dim3(tiles9), dim3(512), 0, st, a);
             else if (spread) hipLaunchKernelGGL((conv_wgrad9q_kernel<2, true>), dim3(tiles9), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((conv_wgrad9q_kernel<2, false>), dim3(tiles9), dim3(512), 0, st, a);

@@ -621,7 +621,7 @@ __device__ __forceinline__ void h2_combine(f32x16& acc0, const f32x16& acc1, flo
     for (int r = 0; r < 16; ++r) acc0[r] = (fmaf(acc1[r], 1.0f / 2048.0f, acc0[r]) * inv_a) * inv_b;
 }
 
-// ---- launchers of the fp16 hi / lo instantiations (conv_h2.hip: their own translation unit, compiled next to conv_igemm.hip)
+// ---- launchers of the fp16 hi / lo instantiations (conv_h2.hip, conv_wgrad_h2.hip: their own translation units, compiled next to conv_igemm.hip)
 bool radet_launch_igemm_h2(int choice, const ConvArgs& a, hipStream_t st, int tag, int bk, size_t ws_floats, int stages,
                            bool no_tail_split);
 struct WgradArgs;

@@ -1,5 +1,5 @@
 // Weight-gradient kernel templates on fp32 tensors (one tap per workgroup, all nine taps), shared by conv_igemm.hip and
-// conv_h2.hip.  gfx950 only.
+// conv_wgrad_h2.hip.  gfx950 only.
 #pragma once
 #include "conv_igemm_kernel.h"
 // ------------------------------------------------------------------------------------------ wgrad
